@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: molecules/sec of one full WGAN-GP iteration.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is the reference's inner loop body (train.py:351-384): reset_grad ->
+discriminator_loss -> backward -> AdamW(D) -> reset_grad -> generator_loss ->
+backward -> AdamW(G), on synthetic molecule graphs already resident in HBM.
+Workload = BASELINE.json configs[1]: DrugGEN default (dim 128, 8 heads, 4 layers,
+mlp_ratio 3), N=45 atoms, E=5 bond classes, M=13 atom classes, batch 256 per GPU,
+fp32.  Multi-GPU: one process per GPU, the batch is sharded (weak scaling: 256
+molecules per rank), gradients averaged with one RCCL all-reduce per backward.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      attention-core forward kernel (the HBM-bound kernel north_star
+                names): algorithmic bytes / HIP-event time measured during the
+                timed steps, against the 8 TB/s HBM3E peak;
+  kernels       the same figure for every profiled HIP kernel;
+  cpu_baseline  the oracle (CPU restatement of the reference path) timed on the
+                host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOAD = dict(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int):
+    """Oracle GAN step on the host CPU: c2 shape, reduced batch (bounded sample)."""
+    from oracle import druggen_oracle as orc
+    from druggen_amd import synth
+    cfg = orc.NetConfig(**WORKLOAD)
+    torch.manual_seed(0)
+    G = orc.OracleNet("G", cfg, {k: torch.from_numpy(v) for k, v in
+                                 synth.fill_parameters(orc.generator_schema(cfg), 1, 1.0).items()})
+    D = orc.OracleNet("D", cfg, {k: torch.from_numpy(v) for k, v in
+                                 synth.fill_parameters(orc.discriminator_schema(cfg), 2, 1.0).items()})
+    g_opt, d_opt = orc.make_optimizers(G, D)
+    a, x, _, _ = synth.molecule_batch(batch, cfg.vertexes, cfg.edges, cfg.nodes, seed=1234)
+    da, dx, _, _ = synth.molecule_batch(batch, cfg.vertexes, cfg.edges, cfg.nodes, seed=2234)
+    ee, en = synth.interpolation_eps(batch, 1234)
+    t = lambda v: torch.from_numpy(v)
+    args = (t(da), t(dx), t(a), t(x), 10.0, t(ee), t(en))
+    threads = torch.get_num_threads()
+    orc.gan_step(G, D, g_opt, d_opt, *args)          # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while steps < 5 and (steps < 1 or time.perf_counter() - t0 < 10.0):
+        orc.gan_step(G, D, g_opt, d_opt, *args)
+        steps += 1
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "molecules/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch CPU restatement of src/model) GAN step, configs[1] shape at batch {batch}, "
+                      f"{steps} step(s) after 1 warm-up, {threads} threads of {os.cpu_count()} logical cores"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: druggen_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from druggen_amd import _lib, functional as dgf, synth
+    from druggen_amd.model import Discriminator, Generator
+    from druggen_amd.trainer import GANStep, broadcast_parameters
+
+    w = WORKLOAD
+    ctor = (w["act"], w["vertexes"], w["edges"], w["nodes"], w["dropout"])
+    kw = dict(dim=w["dim"], depth=w["depth"], heads=w["heads"], mlp_ratio=w["mlp_ratio"])
+    torch.manual_seed(0)                       # PyTorch default init, on CPU, then moved
+    G, D = Generator(*ctor, **kw).to(dev), Discriminator(*ctor, **kw).to(dev)
+    broadcast_parameters(G)
+    broadcast_parameters(D)
+    B = args.batch
+    a, x, _, _ = synth.molecule_batch(B, w["vertexes"], w["edges"], w["nodes"], seed=1234 + rank)
+    da, dx, _, _ = synth.molecule_batch(B, w["vertexes"], w["edges"], w["nodes"], seed=2234 + rank)
+    gen_edge, gen_node = torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)
+    disc_edge, disc_node = torch.from_numpy(da).to(dev), torch.from_numpy(dx).to(dev)
+    stepper = GANStep(G, D, lambda_gp=10.0)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    losses = None
+    for _ in range(args.warmup):
+        losses = stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+    _lib.prof_reset()
+    dgf.traffic_reset()
+    _lib.prof_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+    sync()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    d_loss, g_loss = (float(v.item()) for v in losses)
+    if not (d_loss == d_loss and g_loss == g_loss):
+        raise SystemExit(f"non-finite losses d={d_loss} g={g_loss}")
+
+    if rank == 0:
+        kernels = {}
+        for name in _lib.KERNEL_IDS:
+            n, ms = _lib.prof_read(name)
+            nbytes = dgf.traffic_bytes(name)
+            if n:
+                gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algorithmic_MB_per_launch": nbytes / n / 1e6,
+                                 "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                                 "share_of_step": ms * 1e-3 / elapsed}
+        dom = kernels.get("attn_fwd", {})
+        traffic = None
+        side = os.path.join(ROOT, "profiles", "traffic.json")     # PMC pass (rocprofv3 --pmc), per launch, bytes
+        if os.path.exists(side):
+            try:
+                traffic = json.load(open(side)).get("attn_fwd_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs",
+            "value": B * world * args.steps / elapsed,
+            "unit": "molecules/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DrugGEN default 4-layer/8-head dim128 mlp_ratio3, N=45, E=5, "
+                                   "M=13, fp32, full WGAN-GP step (train.py:351-384) incl. gradient penalty + 2x AdamW",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"kernel": "attn_core_fwd", "bound": "hbm", "achieved": dom.get("achieved_GBps"),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic},
+            "kernels": kernels,
+            "losses": {"d_loss": d_loss, "g_loss": g_loss},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

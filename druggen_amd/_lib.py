@@ -1,0 +1,104 @@
+"""ctypes binding of libdruggen_hip.so -- the C ABI in include/druggen_hip.h.
+
+This is the stub a reference maintainer would add: raw device
+pointers from ``tensor.data_ptr()``, the caller's HIP stream, integer status
+codes turned into ``RuntimeError(dg_last_error_string())``.  There is no CPU
+fallback: if the shared object is missing or the tensors are not on a GPU the
+call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdruggen_hip.so")
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/druggen_hip.h one to one
+SIGNATURES = {
+    "dg_version": (c_int, []),
+    "dg_last_error_string": (c_char_p, []),
+    "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, _P]),
+    "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, _P]),
+    "dg_attn_core_bwd2": (c_int, [_P] * 16 + [c_int, c_int, c_int, c_float, _P]),
+    "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P]),
+    "dg_ln_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, _P]),
+    "dg_ln_residual_bwd2": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
+    "dg_prof_enable": (c_int, [c_int]),
+    "dg_prof_reset": (c_int, []),
+    "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
+}
+
+KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not found: build it with `python -m druggen_amd.build` "
+                "(druggen_amd has no CPU / eager fallback)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().dg_last_error_string()
+        raise RuntimeError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32 GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("druggen_amd kernels need GPU tensors (no CPU fallback); got device "
+                           f"{t.device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"druggen_amd kernels are float32; got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("druggen_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_of(t) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ---- profiler ---------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    check(load().dg_prof_enable(1 if on else 0), "dg_prof_enable")
+
+
+def prof_reset() -> None:
+    check(load().dg_prof_reset(), "dg_prof_reset")
+
+
+def prof_read(kernel: str):
+    n, ms = c_int64(0), c_double(0.0)
+    check(load().dg_prof_read(KERNEL_IDS[kernel], ctypes.byref(n), ctypes.byref(ms)), "dg_prof_read")
+    return int(n.value), float(ms.value)

@@ -1,0 +1,493 @@
+// Graph attention core of DrugGEN's MHA (reference src/model/layers.py:119-134)
+// as three streaming kernels for gfx950: forward, backward, backward-of-backward.
+//
+//   s_ij = alpha q_i k_j (e_ij^2 + e_ij)     p_ij = softmax_j s_ij     o_i = sum_j p_ij v_j
+//
+// Everything is elementwise in the channel c; there is no contraction over the
+// head dimension, hence no MFMA work: the kernels are bound by the HBM traffic
+// of the [B,N,N,C] tensors (fwd: read e, write s; bwd: read e, ws, write de;
+// bwd2: read e, ws, te, write ge, gws).
+//
+// Work decomposition (all three kernels)
+//   * a wave owns one molecule b and one 32-channel slice (8 float4 "quads");
+//     lane = (phase, quad): quad = lane & 7 selects the float4, phase = lane >> 3
+//     selects the neighbours j = phase, phase+8, ... (JPL of them per lane).
+//     One wave-wide float4 load therefore covers 8 neighbours x 128 contiguous
+//     bytes -- full 128 B lines, 16 B per lane.
+//   * the wave walks over the query rows i it is responsible for.  The softmax
+//     over j is a per-lane loop over its JPL slots plus a 3-step xor butterfly
+//     across the 8 phases (lane bits 3..5); no LDS, no barrier.
+//   * k_j, v_j (and in the backward the accumulators dk_j, dv_j, which are sums
+//     over i) belong to fixed (j, channel) pairs, i.e. to fixed lanes: they stay
+//     in registers for the whole walk, so the cross-row reductions need no
+//     atomics and are bit-reproducible.  Row groups of one block are combined
+//     once at the end through LDS in a fixed order.
+//   * narrow models (C < 32) use fewer quads per slice (LQS) and more phases.
+#include "common.h"
+
+namespace dg {
+namespace {
+
+constexpr float kNegBig = -3.0e38f;
+
+template <int LQS, int JPL>
+struct Lane {
+    static constexpr int QS = 1 << LQS;   // quads per slice
+    static constexpr int P = 64 >> LQS;   // neighbour phases per wave
+    int quad, phase;
+    bool cok;          // this lane's channels exist
+    int c0;            // channel offset (clamped to 0 when !cok)
+    unsigned off[JPL]; // element offset of (neighbour slot, channel) inside one [N,C] row block
+    bool jok[JPL];     // slot holds a real neighbour
+    __device__ __forceinline__ Lane(int lane, int slice, int N, int C) {
+        quad = lane & (QS - 1);
+        phase = lane >> LQS;
+        const int cq = slice * QS + quad;
+        cok = cq * 4 < C;
+        c0 = cok ? cq * 4 : 0;
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const int j = phase + t * P;
+            jok[t] = j < N;
+            off[t] = static_cast<unsigned>((jok[t] ? j : 0) * C + c0);   // clamped: loads stay in bounds, results are masked
+        }
+    }
+};
+
+// ---------------------------------------------------------------- forward ----
+template <int LQS, int JPL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const float* __restrict__ e,
+                                                      float* __restrict__ s, float* __restrict__ o, int N, int C,
+                                                      float alpha, int RG) {
+    constexpr int QS = 1 << LQS;
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (slice * QS * 4 >= C) return;  // wave-uniform; no barriers in this kernel
+    const int b = blockIdx.x / RG, rg = blockIdx.x % RG;
+    const Lane<LQS, JPL> L(lane, slice, N, C);
+    const size_t NC = static_cast<size_t>(N) * C;
+
+    float4 kk[JPL], vv[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) {
+        kk[t] = ld4(k + b * NC + L.off[t]);
+        vv[t] = ld4(v + b * NC + L.off[t]);
+    }
+    for (int i = rg; i < N; i += RG) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        const float4 aq = alpha * ld4(q + row * C + L.c0);
+        const float* er = e + row * NC;
+        float* sr = s + row * NC;
+        float4 sv[JPL];
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) sv[t] = ld4_stream(er + L.off[t]);
+        float4 m = f4(kNegBig);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 ee = sv[t];
+            sv[t] = aq * kk[t] * fma4(ee, ee, ee);
+            if (L.jok[t]) {
+                m = max4(m, sv[t]);
+                if (L.cok && s) st4_stream(sr + L.off[t], sv[t]);
+            }
+        }
+        m = xor_max4<QS>(m);
+        float4 l = f4(0.f), acc = f4(0.f);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 pe = L.jok[t] ? exp4(sv[t] - m) : f4(0.f);
+            l += pe;
+            acc = fma4(pe, vv[t], acc);
+        }
+        l = xor_sum4<QS>(l);
+        acc = xor_sum4<QS>(acc);
+        if (L.phase == 0 && L.cok) st4(o + row * C + L.c0, acc * rcp4(l));
+    }
+}
+
+// --------------------------------------------------------------- backward ----
+template <int LQS, int JPL, int RW>
+__global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ e, const float* __restrict__ ws, const float* __restrict__ wo,
+    float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ de, int N, int C,
+    float alpha) {
+    constexpr int QS = 1 << LQS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // k_j, v_j in the lane layout, shared by the RW waves: kv[2][JPL][64]; then the reduction area
+    float4* kv = reinterpret_cast<float4*>(smem_raw);
+    float4* red = kv + 2 * JPL * 64;  // [(RW-1)][2*JPL][64]
+    const int lane = threadIdx.x & 63;
+    const int rw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, slice = blockIdx.y;
+    const Lane<LQS, JPL> L(lane, slice, N, C);
+    const size_t NC = static_cast<size_t>(N) * C;
+
+    if (rw == 0) {
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            kv[(0 * JPL + t) * 64 + lane] = ld4(k + b * NC + L.off[t]);
+            kv[(1 * JPL + t) * 64 + lane] = ld4(v + b * NC + L.off[t]);
+        }
+    }
+    __syncthreads();
+    float4 dkk[JPL], dvv[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) dkk[t] = dvv[t] = f4(0.f);
+    for (int i = rw; i < N; i += RW) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        int kl = lane;                       // opaque per row: keeps the LDS operand reads inside the
+        asm volatile("" : "+v"(kl));         // loop instead of hoisting 2*JPL float4 into registers
+        const float4 aq = alpha * ld4(q + row * C + L.c0);
+        const float4 woi = ld4(wo + row * C + L.c0);
+        const float* er = e + row * NC;
+        const float* wr = ws + row * NC;
+        float* der = de + row * NC;
+        float4 ee[JPL], wss[JPL], pe[JPL];
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            ee[t] = ld4_stream(er + L.off[t]);
+            wss[t] = ws ? ld4_stream(wr + L.off[t]) : f4(0.f);
+        }
+        float4 m = f4(kNegBig);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            pe[t] = aq * kv[(0 * JPL + t) * 64 + kl] * fma4(ee[t], ee[t], ee[t]);
+            if (L.jok[t]) m = max4(m, pe[t]);
+        }
+        m = xor_max4<QS>(m);
+        float4 l = f4(0.f), A = f4(0.f);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            pe[t] = L.jok[t] ? exp4(pe[t] - m) : f4(0.f);
+            l += pe[t];
+            A = fma4(pe[t], woi * kv[(1 * JPL + t) * 64 + kl], A);
+        }
+        l = xor_sum4<QS>(l);
+        A = xor_sum4<QS>(A);
+        const float4 inv = rcp4(l);
+        const float4 abar = A * inv;
+        float4 dqa = f4(0.f);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 kk = kv[(0 * JPL + t) * 64 + kl];
+            const float4 p = pe[t] * inv;
+            float4 ds = fma4(p, woi * kv[(1 * JPL + t) * 64 + kl] - abar, wss[t]);
+            if (!L.jok[t]) ds = f4(0.f);
+            dvv[t] = fma4(p, woi, dvv[t]);
+            const float4 g = fma4(ee[t], ee[t], ee[t]);
+            const float4 dsg = ds * g;
+            dqa = fma4(dsg, kk, dqa);
+            dkk[t] = fma4(dsg, aq, dkk[t]);
+            const float4 g1 = fma4(f4(2.f), ee[t], f4(1.f));
+            if (L.jok[t] && L.cok) st4_stream(der + L.off[t], ds * aq * kk * g1);
+            __builtin_amdgcn_sched_barrier(0);   // one slot at a time: bounds the live temporaries
+        }
+        dqa = xor_sum4<QS>(dqa);
+        if (L.phase == 0 && L.cok) st4(dq + row * C + L.c0, alpha * dqa);
+    }
+    // fixed-order combine of the RW row groups (bit-reproducible)
+    if (RW > 1) {
+        if (rw > 0) {
+#pragma unroll
+            for (int t = 0; t < JPL; ++t) {
+                red[((rw - 1) * 2 * JPL + 2 * t) * 64 + lane] = dkk[t];
+                red[((rw - 1) * 2 * JPL + 2 * t + 1) * 64 + lane] = dvv[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (rw == 0) {
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            float4 a = dkk[t], c = dvv[t];
+            for (int w = 0; w < RW - 1; ++w) {
+                a += red[(w * 2 * JPL + 2 * t) * 64 + lane];
+                c += red[(w * 2 * JPL + 2 * t + 1) * 64 + lane];
+            }
+            if (L.jok[t] && L.cok) {
+                st4(dk + b * NC + L.off[t], a);
+                st4(dv + b * NC + L.off[t], c);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------- backward of backward ----
+// Inputs of the first-order backward: (q,k,v,e,ws,wo); (tq,tk,tv,te) are the
+// adjoints of its outputs (dq,dk,dv,de).  See tests/kernel_math.py::attn_core_bwd2
+// for the closed form (verified against autograd in float64).
+template <int LQS, int JPL, int RW>
+__global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ e, const float* __restrict__ ws, const float* __restrict__ wo,
+    const float* __restrict__ tq, const float* __restrict__ tk, const float* __restrict__ tv,
+    const float* __restrict__ te, float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv,
+    float* __restrict__ ge, float* __restrict__ gws, float* __restrict__ gwo, int N, int C, float alpha) {
+    constexpr int QS = 1 << LQS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // per-neighbour operands live in LDS (read-only, shared by the RW waves):
+    // kv[4][JPL][64] = k, v, tk, tv in the lane layout; then the reduction area.
+    float4* kv = reinterpret_cast<float4*>(smem_raw);
+    float4* red = kv + 4 * JPL * 64;  // [(RW-1)][2*JPL][64]
+    const int lane = threadIdx.x & 63;
+    const int rw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, slice = blockIdx.y;
+    const Lane<LQS, JPL> L(lane, slice, N, C);
+    const size_t NC = static_cast<size_t>(N) * C;
+
+    if (rw == 0) {
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const size_t off = b * NC + L.off[t];
+            kv[(0 * JPL + t) * 64 + lane] = ld4(k + off);
+            kv[(1 * JPL + t) * 64 + lane] = ld4(v + off);
+            kv[(2 * JPL + t) * 64 + lane] = ld4(tk + off);
+            kv[(3 * JPL + t) * 64 + lane] = ld4(tv + off);
+        }
+    }
+    __syncthreads();
+    float4 gkk[JPL], gvv[JPL];
+#pragma unroll
+    for (int t = 0; t < JPL; ++t) gkk[t] = gvv[t] = f4(0.f);
+
+    for (int i = rw; i < N; i += RW) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        int kl = lane;
+        asm volatile("" : "+v"(kl));
+        const float4 qi = ld4(q + row * C + L.c0);
+        const float4 aq = alpha * qi;
+        const float4 woi = ld4(wo + row * C + L.c0);
+        const float4 tqi = ld4(tq + row * C + L.c0);
+        const float* er = e + row * NC;
+        const float* wr = ws + row * NC;
+        const float* tr = te + row * NC;
+        float4 ee[JPL], wss[JPL], tee[JPL], pe[JPL], sd[JPL];
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const unsigned off = L.off[t];
+            ee[t] = ld4_stream(er + off);
+            wss[t] = ws ? ld4_stream(wr + off) : f4(0.f);
+            tee[t] = ld4_stream(tr + off);
+        }
+        float4 m = f4(kNegBig);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 kk = kv[(0 * JPL + t) * 64 + kl];
+            pe[t] = aq * kk * fma4(ee[t], ee[t], ee[t]);
+            if (L.jok[t]) m = max4(m, pe[t]);
+        }
+        m = xor_max4<QS>(m);
+        float4 l = f4(0.f), A = f4(0.f);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 vv = kv[(1 * JPL + t) * 64 + kl];
+            pe[t] = L.jok[t] ? exp4(pe[t] - m) : f4(0.f);
+            l += pe[t];
+            A = fma4(pe[t], woi * vv, A);
+        }
+        l = xor_sum4<QS>(l);
+        A = xor_sum4<QS>(A);
+        const float4 inv = rcp4(l);
+        const float4 abar = A * inv;
+        // tangent of s along t, and m = sum_j p sdot
+        float4 mm = f4(0.f);
+        float* gwr = gws + row * NC;
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 kk = kv[(0 * JPL + t) * 64 + kl];
+            const float4 tkk = kv[(2 * JPL + t) * 64 + kl];
+            const float4 g = fma4(ee[t], ee[t], ee[t]);
+            const float4 g1 = fma4(f4(2.f), ee[t], f4(1.f));
+            pe[t] = pe[t] * inv;  // p
+            sd[t] = alpha * (g * fma4(tqi, kk, qi * tkk) + qi * kk * g1 * tee[t]);
+            if (L.jok[t] && L.cok && gws) st4_stream(gwr + L.off[t], sd[t]);
+            mm = fma4(pe[t], sd[t], mm);
+        }
+        mm = xor_sum4<QS>(mm);
+        float4 od = f4(0.f), PB = f4(0.f);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 vv = kv[(1 * JPL + t) * 64 + kl];
+            const float4 tvv = kv[(3 * JPL + t) * 64 + kl];
+            const float4 a = woi * vv;
+            const float4 pdot = pe[t] * (sd[t] - mm);
+            od = fma4(pdot, vv, fma4(pe[t], tvv, od));
+            const float4 pbar = sd[t] * (a - abar) - mm * a + woi * tvv;
+            PB = fma4(pe[t], pbar, PB);
+        }
+        od = xor_sum4<QS>(od);
+        PB = xor_sum4<QS>(PB);
+        if (L.phase == 0 && L.cok) st4(gwo + row * C + L.c0, od);
+        float4 gqa = f4(0.f);
+        float* ger = ge + row * NC;
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const float4 kk = kv[(0 * JPL + t) * 64 + kl];
+            const float4 vv = kv[(1 * JPL + t) * 64 + kl];
+            const float4 tkk = kv[(2 * JPL + t) * 64 + kl];
+            const float4 tvv = kv[(3 * JPL + t) * 64 + kl];
+            const float4 p = pe[t];
+            const float4 a = woi * vv;
+            const float4 g = fma4(ee[t], ee[t], ee[t]);
+            const float4 g1 = fma4(f4(2.f), ee[t], f4(1.f));
+            float4 ds = fma4(p, a - abar, wss[t]);
+            if (!L.jok[t]) ds = f4(0.f);
+            const float4 pdot = p * (sd[t] - mm);
+            const float4 pbar = sd[t] * (a - abar) - mm * a + woi * tvv;
+            const float4 sbar = p * (pbar - PB);
+            const float4 g1te = g1 * tee[t];
+            // gq_i += sbar alpha k g + ds alpha (tk g + k g1 te)
+            gqa += sbar * kk * g + ds * fma4(tkk, g, kk * g1te);
+            // gk_j += sbar alpha q g + ds alpha (tq g + q g1 te)
+            gkk[t] += sbar * aq * g + alpha * (ds * fma4(tqi, g, qi * g1te));
+            gvv[t] = fma4(pdot, woi, gvv[t]);
+            // ge = sbar alpha q k g1 + ds alpha (tq k g1 + q tk g1 + 2 q k te)
+            const float4 gev = sbar * aq * kk * g1 +
+                               alpha * (ds * (g1 * fma4(tqi, kk, qi * tkk) + 2.f * (qi * kk * tee[t])));
+            if (L.jok[t] && L.cok) st4_stream(ger + L.off[t], gev);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gqa = xor_sum4<QS>(gqa);
+        if (L.phase == 0 && L.cok) st4(gq + row * C + L.c0, alpha * gqa);
+    }
+    if (RW > 1) {
+        if (rw > 0) {
+#pragma unroll
+            for (int t = 0; t < JPL; ++t) {
+                red[((rw - 1) * 2 * JPL + 2 * t) * 64 + lane] = gkk[t];
+                red[((rw - 1) * 2 * JPL + 2 * t + 1) * 64 + lane] = gvv[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (rw == 0) {
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            float4 a = gkk[t], c = gvv[t];
+            for (int w = 0; w < RW - 1; ++w) {
+                a += red[(w * 2 * JPL + 2 * t) * 64 + lane];
+                c += red[(w * 2 * JPL + 2 * t + 1) * 64 + lane];
+            }
+            if (L.jok[t] && L.cok) {
+                st4(gk + b * NC + L.off[t], a);
+                st4(gv + b * NC + L.off[t], c);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dispatch ----
+struct Geometry {
+    int lqs, jpl, slices;
+};
+
+bool pick_geometry(int N, int C, Geometry* g) {
+    if (C < 8 || (C & 3) || N < 1) return false;
+    const int cq = C / 4;
+    g->lqs = cq >= 5 ? 3 : (cq >= 3 ? 2 : 1);
+    const int qs = 1 << g->lqs, P = 64 >> g->lqs;
+    g->slices = (cq + qs - 1) / qs;
+    const int need = (N + P - 1) / P;
+    const int table[] = {1, 2, 3, 6, 12};
+    for (int t : table) {
+        if (t >= need) {
+            g->jpl = t;
+            // only the instantiated combinations
+            if (g->lqs == 1 && t > 3) return false;
+            if (g->lqs == 2 && t > 6) return false;
+            return true;
+        }
+    }
+    return false;
+}
+
+constexpr int kRW = 4;  // row groups (waves) per backward block
+
+#define DG_FOR_GEOMETRY(M)                                                          \
+    M(1, 1) M(1, 2) M(1, 3) M(2, 1) M(2, 2) M(2, 3) M(2, 6) M(3, 1) M(3, 2) M(3, 3) \
+        M(3, 6) M(3, 12)
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" int dg_attn_core_fwd(const float* q, const float* k, const float* v, const float* e, float* s, float* o,
+                                int B, int N, int C, float alpha, dg_stream_t stream_) {
+    if (!q || !k || !v || !e || !o) return fail(DG_E_ARG, "dg_attn_core_fwd: null pointer");  // s may be NULL
+    Geometry g;
+    if (B < 0 || !pick_geometry(N, C, &g))
+        return fail(DG_E_SHAPE, "dg_attn_core_fwd: unsupported shape B=%d N=%d C=%d (need C%%4==0, C>=8, N<=96)", B, N, C);
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int wpb = g.slices < 4 ? g.slices : 4;
+    const int rows_per_wave = 9;
+    int RG = (N + rows_per_wave - 1) / rows_per_wave;
+    if (const char* env = getenv("DG_ATTN_FWD_RG")) RG = atoi(env) > 0 ? atoi(env) : RG;
+    if (RG > N) RG = N;
+    dim3 grid(static_cast<unsigned>(B) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
+    ProfScope prof(DG_K_ATTN_FWD, stream);
+#define LAUNCH(LQS, JPL)                                                                                          \
+    if (g.lqs == LQS && g.jpl == JPL)                                                                             \
+        hipLaunchKernelGGL((attn_fwd_kernel<LQS, JPL>), grid, block, 0, stream, q, k, v, e, s, o, N, C, alpha, RG);
+    DG_FOR_GEOMETRY(LAUNCH)
+#undef LAUNCH
+    return check_launch("dg_attn_core_fwd");
+}
+
+extern "C" int dg_attn_core_bwd(const float* q, const float* k, const float* v, const float* e, const float* ws,
+                                const float* wo, float* dq, float* dk, float* dv, float* de, int B, int N, int C,
+                                float alpha, dg_stream_t stream_) {
+    if (!q || !k || !v || !e || !wo || !dq || !dk || !dv || !de)
+        return fail(DG_E_ARG, "dg_attn_core_bwd: null pointer");  // ws may be NULL (= zeros)
+    Geometry g;
+    if (B < 0 || !pick_geometry(N, C, &g))
+        return fail(DG_E_SHAPE, "dg_attn_core_bwd: unsupported shape B=%d N=%d C=%d", B, N, C);
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    dim3 grid(B, g.slices), block(64 * kRW);
+    ProfScope prof(DG_K_ATTN_BWD, stream);
+#define LAUNCH(LQS, JPL)                                                                                       \
+    if (g.lqs == LQS && g.jpl == JPL) {                                                                        \
+        constexpr int lds = (2 * JPL + (kRW - 1) * 2 * JPL) * 64 * 16;                                                     \
+        static const hipError_t attr = hipFuncSetAttribute(                                                    \
+            reinterpret_cast<const void*>(&attn_bwd_kernel<LQS, JPL, kRW>),                                    \
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                  \
+        (void)attr;                                                                                            \
+        hipLaunchKernelGGL((attn_bwd_kernel<LQS, JPL, kRW>), grid, block, lds, stream, q, k, v, e, ws, wo, dq, \
+                           dk, dv, de, N, C, alpha);                                                           \
+    }
+    DG_FOR_GEOMETRY(LAUNCH)
+#undef LAUNCH
+    return check_launch("dg_attn_core_bwd");
+}
+
+extern "C" int dg_attn_core_bwd2(const float* q, const float* k, const float* v, const float* e, const float* ws,
+                                 const float* wo, const float* tq, const float* tk, const float* tv, const float* te,
+                                 float* gq, float* gk, float* gv, float* ge, float* gws, float* gwo, int B, int N,
+                                 int C, float alpha, dg_stream_t stream_) {
+    if (!q || !k || !v || !e || !wo || !tq || !tk || !tv || !te || !gq || !gk || !gv || !ge || !gwo)  // ws, gws may be NULL
+        return fail(DG_E_ARG, "dg_attn_core_bwd2: null pointer");
+    Geometry g;
+    if (B < 0 || !pick_geometry(N, C, &g))
+        return fail(DG_E_SHAPE, "dg_attn_core_bwd2: unsupported shape B=%d N=%d C=%d", B, N, C);
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    dim3 grid(B, g.slices), block(64 * kRW);
+    ProfScope prof(DG_K_ATTN_BWD2, stream);
+#define LAUNCH(LQS, JPL)                                                                                          \
+    if (g.lqs == LQS && g.jpl == JPL) {                                                                           \
+        constexpr int lds = (4 * JPL + (kRW - 1) * 2 * JPL) * 64 * 16;                                            \
+        static const hipError_t attr = hipFuncSetAttribute(                                                       \
+            reinterpret_cast<const void*>(&attn_bwd2_kernel<LQS, JPL, kRW>),                                      \
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                     \
+        (void)attr;                                                                                               \
+        hipLaunchKernelGGL((attn_bwd2_kernel<LQS, JPL, kRW>), grid, block, lds, stream, q, k, v, e, ws, wo, tq,   \
+                           tk, tv, te, gq, gk, gv, ge, gws, gwo, N, C, alpha);                                    \
+    }
+    DG_FOR_GEOMETRY(LAUNCH)
+#undef LAUNCH
+    return check_launch("dg_attn_core_bwd2");
+}

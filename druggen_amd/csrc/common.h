@@ -1,0 +1,79 @@
+// Shared helpers of libdruggen_hip.so (gfx950 only, wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/druggen_hip.h"
+
+namespace dg {
+
+// ---- thread-local error text ------------------------------------------------
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- profiler (prof.hip) ----------------------------------------------------
+struct ProfScope {
+    int id;
+    hipStream_t stream;
+    void* slot;
+    ProfScope(int kernel_id, hipStream_t s);
+    ~ProfScope();
+};
+
+// ---- float4 arithmetic ------------------------------------------------------
+__device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float4& operator+=(float4& a, float4 b) { a = a + b; return a; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 exp4(float4 a) { return make_float4(__expf(a.x), __expf(a.y), __expf(a.z), __expf(a.w)); }
+__device__ __forceinline__ float4 rcp4(float4 a) { return make_float4(1.0f / a.x, 1.0f / a.y, 1.0f / a.z, 1.0f / a.w); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streamed once: keep it out of the way of the small reused operands
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+    v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+// butterfly over the lanes that differ in bits >= LOW of the lane id
+template <int LOW>
+__device__ __forceinline__ float xor_sum(float x) {
+#pragma unroll
+    for (int m = LOW; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+template <int LOW>
+__device__ __forceinline__ float xor_max(float x) {
+#pragma unroll
+    for (int m = LOW; m < 64; m <<= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+template <int LOW>
+__device__ __forceinline__ float4 xor_sum4(float4 a) {
+    return make_float4(xor_sum<LOW>(a.x), xor_sum<LOW>(a.y), xor_sum<LOW>(a.z), xor_sum<LOW>(a.w));
+}
+template <int LOW>
+__device__ __forceinline__ float4 xor_max4(float4 a) {
+    return make_float4(xor_max<LOW>(a.x), xor_max<LOW>(a.y), xor_max<LOW>(a.z), xor_max<LOW>(a.w));
+}
+
+}  // namespace dg

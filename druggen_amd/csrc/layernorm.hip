@@ -1,0 +1,361 @@
+// Residual + LayerNorm of DrugGEN's Encoder_Block (reference
+// src/model/layers.py:185-192):  y = LN(a + r) * gamma + beta over the last dim.
+//
+// HBM-bound row kernels.  A row of C floats is owned by a group of G lanes
+// (G = 8/16/32/64, each lane holds QPL float4), so a wave covers 64/G rows per
+// pass with 16-byte loads; mean/variance and the backward row sums are
+// butterflies over the group's lanes.  The column sums for dgamma / dbeta are
+// reduced in a fixed order (per-block partials in the workspace, then one
+// finishing kernel), so results are bit-reproducible.
+#include "common.h"
+
+namespace dg {
+namespace {
+
+// sum over the G lanes of a row group (G is a power of two <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+__device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+constexpr int kBlock = 256;
+
+struct RowMap {
+    int64_t row;
+    int lane_in_group;
+    bool ok;
+};
+
+template <int G>
+__device__ __forceinline__ RowMap map_row(int64_t pass, int64_t R) {
+    constexpr int RPB = kBlock / G;  // rows per block pass
+    RowMap m;
+    m.lane_in_group = threadIdx.x % G;
+    m.row = pass * RPB + threadIdx.x / G;
+    m.ok = m.row < R;
+    if (!m.ok) m.row = R - 1;  // clamp: loads stay in bounds, stores are masked
+    return m;
+}
+
+// ------------------------------------------------------------------ forward --
+template <int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t R,
+                                                      int C, float eps) {
+    constexpr int RPB = kBlock / G;
+    const int64_t passes = (R + RPB - 1) / RPB;
+    const float invC = 1.0f / static_cast<float>(C);
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const RowMap m = map_row<G>(pass, R);
+        float4 z[QPL];
+        bool cok[QPL];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            const int c = (m.lane_in_group + t * G) * 4;
+            cok[t] = c < C;
+            const int cc = cok[t] ? c : 0;
+            z[t] = ld4(a + m.row * C + cc);
+            if (r) z[t] += ld4(r + m.row * C + cc);
+            if (!cok[t]) z[t] = f4(0.f);
+            s += hsum(z[t]);
+        }
+        const float mu = group_sum<G>(s) * invC;
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            float4 d = z[t] - f4(mu);
+            if (!cok[t]) d = f4(0.f);
+            v += hsum(d * d);
+            z[t] = d;
+        }
+        const float rs = rsqrtf(group_sum<G>(v) * invC + eps);
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            const int c = (m.lane_in_group + t * G) * 4;
+            if (cok[t] && m.ok) st4(y + m.row * C + c, fma4(rs * z[t], ld4(gamma + c), ld4(beta + c)));
+        }
+        if (m.ok && m.lane_in_group == 0) {
+            mean[m.row] = mu;
+            rstd[m.row] = rs;
+        }
+    }
+}
+
+// ----------------------------------------------------------------- backward --
+// dz = rstd (u - mean(u) - xhat mean(u xhat)), u = gamma dy
+// dgamma = sum_rows dy xhat, dbeta = sum_rows dy  (block partials -> part[])
+template <int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ dy, float* __restrict__ dz,
+                                                      float* __restrict__ part, int64_t R, int C) {
+    constexpr int RPB = kBlock / G;
+    __shared__ float4 red[2][QPL][kBlock];
+    const int64_t passes = (R + RPB - 1) / RPB;
+    const float invC = 1.0f / static_cast<float>(C);
+    float4 gacc[QPL], bacc[QPL], gam[QPL];
+    bool cok[QPL];
+    int coff[QPL];
+    const int lig = threadIdx.x % G;
+#pragma unroll
+    for (int t = 0; t < QPL; ++t) {
+        const int c = (lig + t * G) * 4;
+        cok[t] = c < C;
+        coff[t] = cok[t] ? c : 0;
+        gam[t] = ld4(gamma + coff[t]);
+        gacc[t] = bacc[t] = f4(0.f);
+    }
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const RowMap m = map_row<G>(pass, R);
+        const float mu = mean[m.row], rs = rstd[m.row];
+        float4 xh[QPL], u[QPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            float4 z = ld4(a + m.row * C + coff[t]);
+            if (r) z += ld4(r + m.row * C + coff[t]);
+            float4 g = ld4(dy + m.row * C + coff[t]);
+            if (!cok[t] || !m.ok) g = f4(0.f);
+            xh[t] = rs * (z - f4(mu));
+            if (!cok[t]) xh[t] = f4(0.f);
+            gacc[t] = fma4(g, xh[t], gacc[t]);
+            bacc[t] += g;
+            u[t] = g * gam[t];
+            s1 += hsum(u[t]);
+            s2 += hsum(u[t] * xh[t]);
+        }
+        const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            if (cok[t] && m.ok) st4(dz + m.row * C + coff[t], rs * (u[t] - f4(c1) - c2 * xh[t]));
+        }
+    }
+    // block partial: sum over the RPB row groups in a fixed order
+#pragma unroll
+    for (int t = 0; t < QPL; ++t) {
+        red[0][t][threadIdx.x] = gacc[t];
+        red[1][t][threadIdx.x] = bacc[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            float4 gs = f4(0.f), bs = f4(0.f);
+            for (int g = 0; g < RPB; ++g) {
+                gs += red[0][t][g * G + threadIdx.x];
+                bs += red[1][t][g * G + threadIdx.x];
+            }
+            if (cok[t]) {
+                st4(part + (static_cast<size_t>(blockIdx.x) * 2 + 0) * C + coff[t], gs);
+                st4(part + (static_cast<size_t>(blockIdx.x) * 2 + 1) * C + coff[t], bs);
+            }
+        }
+    }
+}
+
+// out[k][c] = sum_blocks part[block][k][c]  (k < K), fixed order
+__global__ void ln_finish_kernel(const float* __restrict__ part, int nblocks, int K, int C, float* __restrict__ out0,
+                                 float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += part[(static_cast<size_t>(b) * K + k) * C + c];
+        float* out = k == 0 ? out0 : out1;
+        if (out) out[c] = s;
+    }
+}
+
+// ------------------------------------------------------- backward of backward --
+// tests/kernel_math.py::ln_bwd2:
+//   xdot = rstd (tz - mean(tz) - xhat mean(tz xhat))
+//   gdy = gamma xdot ; ggamma = sum_rows dy xdot
+//   gz = -rstd (xhat mean(xdot u) + xdot mean(u xhat) + w mean(tz xhat)),  u = gamma dy,
+//   w = rstd (u - mean(u) - xhat mean(u xhat))
+template <int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_bwd2_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                       const float* __restrict__ tz, float* __restrict__ gz,
+                                                       float* __restrict__ gdy, float* __restrict__ part, int64_t R,
+                                                       int C) {
+    constexpr int RPB = kBlock / G;
+    __shared__ float4 red[QPL][kBlock];
+    const int64_t passes = (R + RPB - 1) / RPB;
+    const float invC = 1.0f / static_cast<float>(C);
+    float4 gacc[QPL], gam[QPL];
+    bool cok[QPL];
+    int coff[QPL];
+    const int lig = threadIdx.x % G;
+#pragma unroll
+    for (int t = 0; t < QPL; ++t) {
+        const int c = (lig + t * G) * 4;
+        cok[t] = c < C;
+        coff[t] = cok[t] ? c : 0;
+        gam[t] = ld4(gamma + coff[t]);
+        gacc[t] = f4(0.f);
+    }
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const RowMap m = map_row<G>(pass, R);
+        const float mu = mean[m.row], rs = rstd[m.row];
+        float4 xh[QPL], u[QPL], tt[QPL], g[QPL];
+        float su = 0.f, sux = 0.f, st = 0.f, stx = 0.f;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            float4 z = ld4(a + m.row * C + coff[t]);
+            if (r) z += ld4(r + m.row * C + coff[t]);
+            g[t] = ld4(dy + m.row * C + coff[t]);
+            tt[t] = ld4(tz + m.row * C + coff[t]);
+            if (!cok[t] || !m.ok) {
+                g[t] = f4(0.f);
+                tt[t] = f4(0.f);
+            }
+            xh[t] = rs * (z - f4(mu));
+            if (!cok[t]) xh[t] = f4(0.f);
+            u[t] = g[t] * gam[t];
+            su += hsum(u[t]);
+            sux += hsum(u[t] * xh[t]);
+            st += hsum(tt[t]);
+            stx += hsum(tt[t] * xh[t]);
+        }
+        const float u1 = group_sum<G>(su) * invC, c2 = group_sum<G>(sux) * invC;
+        const float t1 = group_sum<G>(st) * invC, t2 = group_sum<G>(stx) * invC;
+        float sxu = 0.f;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            tt[t] = rs * (tt[t] - f4(t1) - t2 * xh[t]);  // xdot
+            if (!cok[t]) tt[t] = f4(0.f);
+            sxu += hsum(tt[t] * u[t]);
+            gacc[t] = fma4(g[t], tt[t], gacc[t]);
+        }
+        const float s1 = group_sum<G>(sxu) * invC;
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            if (cok[t] && m.ok) {
+                const float4 w = rs * (u[t] - f4(u1) - c2 * xh[t]);
+                st4(gdy + m.row * C + coff[t], gam[t] * tt[t]);
+                st4(gz + m.row * C + coff[t], (-rs) * (s1 * xh[t] + c2 * tt[t] + t2 * w));
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QPL; ++t) red[t][threadIdx.x] = gacc[t];
+    __syncthreads();
+    if (threadIdx.x < G) {
+#pragma unroll
+        for (int t = 0; t < QPL; ++t) {
+            float4 gs = f4(0.f);
+            for (int g2 = 0; g2 < RPB; ++g2) gs += red[t][g2 * G + threadIdx.x];
+            if (cok[t]) st4(part + static_cast<size_t>(blockIdx.x) * C + coff[t], gs);
+        }
+    }
+}
+
+// ----------------------------------------------------------------- dispatch --
+struct LnGeom {
+    int G, QPL;
+};
+
+bool ln_geometry(int C, LnGeom* g) {
+    if (C < 4 || (C & 3)) return false;
+    const int quads = C / 4;
+    int G = 8;
+    while (G < 64 && G < quads) G <<= 1;
+    const int qpl = (quads + G - 1) / G;
+    if (qpl > 4) return false;  // C <= 1024
+    g->G = G;
+    g->QPL = qpl == 3 ? 4 : qpl;
+    return true;
+}
+
+int ln_grid(int64_t R, int G) {
+    const int64_t rpb = kBlock / G;
+    int64_t passes = (R + rpb - 1) / rpb;
+    const int64_t cap = 2048;  // ~8 blocks per CU, grid-stride beyond
+    return static_cast<int>(passes < cap ? (passes < 1 ? 1 : passes) : cap);
+}
+
+#define DG_FOR_LN(M) M(8, 1) M(16, 1) M(32, 1) M(64, 1) M(64, 2) M(64, 4)
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" size_t dg_ln_workspace_bytes(int64_t R, int C) {
+    LnGeom g;
+    if (R < 1 || !ln_geometry(C, &g)) return 0;
+    return static_cast<size_t>(ln_grid(R, g.G)) * 2 * C * sizeof(float);
+}
+
+extern "C" int dg_ln_residual_fwd(const float* a, const float* r, const float* gamma, const float* beta, float* y,
+                                  float* mean, float* rstd, int64_t R, int C, float eps, dg_stream_t stream_) {
+    if (!a || !gamma || !beta || !y || !mean || !rstd) return fail(DG_E_ARG, "dg_ln_residual_fwd: null pointer");
+    LnGeom g;
+    if (R < 0 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_fwd: unsupported C=%d (C%%4==0, C<=1024)", C);
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int grid = ln_grid(R, g.G);
+    ProfScope prof(DG_K_LN_FWD, stream);
+#define LAUNCH(GG, QQ)            \
+    if (g.G == GG && g.QPL == QQ) \
+        hipLaunchKernelGGL((ln_fwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, beta, y, mean, rstd, R, C, eps);
+    DG_FOR_LN(LAUNCH)
+#undef LAUNCH
+    return check_launch("dg_ln_residual_fwd");
+}
+
+extern "C" int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma, const float* mean,
+                                  const float* rstd, const float* dy, float* dz, float* dgamma, float* dbeta,
+                                  void* workspace, size_t workspace_bytes, int64_t R, int C, dg_stream_t stream_) {
+    if (!a || !gamma || !mean || !rstd || !dy || !dz || !workspace)
+        return fail(DG_E_ARG, "dg_ln_residual_bwd: null pointer");
+    LnGeom g;
+    if (R < 1 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_bwd: unsupported R=%lld C=%d", (long long)R, C);
+    if (workspace_bytes < dg_ln_workspace_bytes(R, C)) return fail(DG_E_WORKSPACE, "dg_ln_residual_bwd: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int grid = ln_grid(R, g.G);
+    float* part = static_cast<float*>(workspace);
+    ProfScope prof(DG_K_LN_BWD, stream);
+#define LAUNCH(GG, QQ)            \
+    if (g.G == GG && g.QPL == QQ) \
+        hipLaunchKernelGGL((ln_bwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, dz, part, R, C);
+    DG_FOR_LN(LAUNCH)
+#undef LAUNCH
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, part, grid, 2, C, dgamma, dbeta);
+    return check_launch("dg_ln_residual_bwd");
+}
+
+extern "C" int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dy, const float* tz, float* gz, float* gdy,
+                                   float* ggamma, void* workspace, size_t workspace_bytes, int64_t R, int C,
+                                   dg_stream_t stream_) {
+    if (!a || !gamma || !mean || !rstd || !dy || !tz || !gz || !gdy || !workspace)
+        return fail(DG_E_ARG, "dg_ln_residual_bwd2: null pointer");
+    LnGeom g;
+    if (R < 1 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_bwd2: unsupported R=%lld C=%d", (long long)R, C);
+    if (workspace_bytes < dg_ln_workspace_bytes(R, C)) return fail(DG_E_WORKSPACE, "dg_ln_residual_bwd2: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int grid = ln_grid(R, g.G);
+    float* part = static_cast<float*>(workspace);
+    ProfScope prof(DG_K_LN_BWD2, stream);
+#define LAUNCH(GG, QQ)            \
+    if (g.G == GG && g.QPL == QQ) \
+        hipLaunchKernelGGL((ln_bwd2_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, tz, gz, gdy, part, R, C);
+    DG_FOR_LN(LAUNCH)
+#undef LAUNCH
+    if (ggamma)
+        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, part, grid, 1, C, ggamma,
+                           static_cast<float*>(nullptr));
+    return check_launch("dg_ln_residual_bwd2");
+}

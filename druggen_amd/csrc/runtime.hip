@@ -1,0 +1,112 @@
+// Error reporting and the opt-in event profiler of libdruggen_hip.so.
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace dg {
+
+char* error_buffer() {
+    static thread_local char buf[512] = "ok";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(static_cast<int>(err), "%s: %s", what, hipGetErrorString(err));
+    return 0;
+}
+
+// ---- profiler ---------------------------------------------------------------
+namespace {
+struct Span {
+    int id;
+    hipEvent_t start, stop;
+};
+std::mutex g_mu;
+bool g_enabled = false;
+std::vector<Span> g_spans;
+std::vector<hipEvent_t> g_free;
+
+hipEvent_t take_event() {
+    if (!g_free.empty()) {
+        hipEvent_t e = g_free.back();
+        g_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), stream(s), slot(nullptr) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_enabled) return;
+    Span sp{kernel_id, take_event(), take_event()};
+    (void)hipEventRecord(sp.start, stream);
+    g_spans.push_back(sp);
+    slot = reinterpret_cast<void*>(g_spans.size());  // index + 1
+}
+
+ProfScope::~ProfScope() {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    size_t idx = reinterpret_cast<size_t>(slot) - 1;
+    if (idx < g_spans.size()) (void)hipEventRecord(g_spans[idx].stop, stream);
+}
+
+}  // namespace dg
+
+extern "C" {
+
+int dg_version(void) { return DG_VERSION; }
+
+const char* dg_last_error_string(void) { return dg::error_buffer(); }
+
+int dg_prof_enable(int on) {
+    std::lock_guard<std::mutex> lock(dg::g_mu);
+    dg::g_enabled = on != 0;
+    return 0;
+}
+
+int dg_prof_reset(void) {
+    std::lock_guard<std::mutex> lock(dg::g_mu);
+    for (auto& sp : dg::g_spans) {
+        (void)hipEventSynchronize(sp.stop);
+        dg::g_free.push_back(sp.start);
+        dg::g_free.push_back(sp.stop);
+    }
+    dg::g_spans.clear();
+    return 0;
+}
+
+int dg_prof_read(int kernel_id, int64_t* launches, double* total_ms) {
+    if (!launches || !total_ms) return dg::fail(DG_E_ARG, "dg_prof_read: null output");
+    std::lock_guard<std::mutex> lock(dg::g_mu);
+    int64_t n = 0;
+    double ms = 0.0;
+    for (auto& sp : dg::g_spans) {
+        if (sp.id != kernel_id) continue;
+        hipError_t err = hipEventSynchronize(sp.stop);
+        if (err != hipSuccess) return dg::fail(static_cast<int>(err), "dg_prof_read: %s", hipGetErrorString(err));
+        float t = 0.f;
+        err = hipEventElapsedTime(&t, sp.start, sp.stop);
+        if (err != hipSuccess) return dg::fail(static_cast<int>(err), "dg_prof_read: %s", hipGetErrorString(err));
+        ms += t;
+        ++n;
+    }
+    *launches = n;
+    *total_ms = ms;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+"""Twice-differentiable autograd wrappers around the HIP kernels.
+
+Each op is a pair of ``torch.autograd.Function``s: the forward op, and its
+backward expressed as a second Function whose own backward calls the
+second-order kernel.  That keeps the reference's gradient penalty
+(``src/model/loss.py:32-39``: ``autograd.grad(..., create_graph=True)`` followed
+by ``d_loss.backward()``, ``train.py:367``) working unchanged on these modules.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+__all__ = ["attn_core", "ln_residual", "traffic_reset", "traffic_bytes"]
+
+# Algorithmic HBM bytes per kernel, accumulated per launch so that
+# bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
+_traffic = {}
+
+
+def traffic_reset() -> None:
+    _traffic.clear()
+
+
+def traffic_bytes(kernel: str) -> int:
+    return _traffic.get(kernel, 0)
+
+
+def _account(kernel: str, nbytes: int) -> None:
+    _traffic[kernel] = _traffic.get(kernel, 0) + nbytes
+
+
+def _dev(t):
+    """Run the launch with t's device current (nn.DataParallel replica threads)."""
+    if torch.cuda.current_device() == t.device.index:
+        return contextlib.nullcontext()
+    return torch.cuda.device(t.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------
+# graph attention core  (reference src/model/layers.py:119-134)
+# --------------------------------------------------------------------------
+def _attn_shapes(q, e):
+    B, N, C = q.shape
+    if tuple(e.shape) != (B, N, N, C):
+        raise RuntimeError(f"attn_core: edge tensor {tuple(e.shape)} does not match node tensor {tuple(q.shape)}")
+    return B, N, C
+
+
+class _AttnCore(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, e, alpha, need_s):
+        q, k, v, e = _c(q), _c(k), _c(v), _c(e)
+        B, N, C = _attn_shapes(q, e)
+        lib = _lib.load()
+        s = torch.empty_like(e) if need_s else None
+        o = torch.empty_like(q)
+        with _dev(q):
+            _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
+                                            _lib.ptr(o), B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_fwd")
+        _account("attn_fwd", 4 * B * ((2 if need_s else 1) * N * N * C + 4 * N * C))
+        ctx.save_for_backward(q, k, v, e)
+        ctx.alpha = alpha
+        ctx.set_materialize_grads(False)
+        if s is None:
+            s = q.new_empty(0)
+            ctx.mark_non_differentiable(s)
+        return s, o
+
+    @staticmethod
+    def backward(ctx, ws, wo):
+        q, k, v, e = ctx.saved_tensors
+        if wo is None:
+            wo = torch.zeros_like(q)
+        if ws is not None and ws.numel() == 0:
+            ws = None
+        dq, dk, dv, de = _AttnCoreBwd.apply(q, k, v, e, ws, wo, ctx.alpha)
+        return dq, dk, dv, de, None, None
+
+
+class _AttnCoreBwd(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, e, ws, wo, alpha):
+        B, N, C = _attn_shapes(q, e)
+        ws = None if ws is None else _c(ws)
+        wo = _c(wo)
+        lib = _lib.load()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        de = torch.empty_like(e)
+        with _dev(q):
+            _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws),
+                                            _lib.ptr(wo), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de),
+                                            B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd")
+        _account("attn_bwd", 4 * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
+        ctx.save_for_backward(q, k, v, e, ws, wo)
+        ctx.alpha = alpha
+        return dq, dk, dv, de
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, tq, tk, tv, te):
+        q, k, v, e, ws, wo = ctx.saved_tensors
+        B, N, C = _attn_shapes(q, e)
+        tq, tk, tv, te = _c(tq), _c(tk), _c(tv), _c(te)
+        lib = _lib.load()
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        ge = torch.empty_like(e)
+        gws = torch.empty_like(e) if ws is not None else None
+        gwo = torch.empty_like(q)
+        with _dev(q):
+            _lib.check(lib.dg_attn_core_bwd2(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws),
+                                             _lib.ptr(wo), _lib.ptr(tq), _lib.ptr(tk), _lib.ptr(tv), _lib.ptr(te),
+                                             _lib.ptr(gq), _lib.ptr(gk), _lib.ptr(gv), _lib.ptr(ge), _lib.ptr(gws),
+                                             _lib.ptr(gwo), B, N, C, ctx.alpha, _lib.stream_of(q)),
+                       "dg_attn_core_bwd2")
+        _account("attn_bwd2", 4 * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
+        return gq, gk, gv, ge, gws, gwo, None
+
+
+def attn_core(q, k, v, e, alpha: float, need_s: bool = True):
+    """(s, o) of the edge-modulated per-channel attention.
+
+    s[b,i,j,c] = alpha q[b,i,c] k[b,j,c] (e^2+e)[b,i,j,c];  o = sum_j softmax_j(s) v_j.
+    With ``need_s=False`` the [B,N,N,C] score tensor is not written (Discriminator's
+    last block never reads it, reference models.py:202-207) and ``s`` is None.
+    """
+    s, o = _AttnCore.apply(q, k, v, e, float(alpha), bool(need_s))
+    return (s if need_s else None), o
+
+
+# --------------------------------------------------------------------------
+# residual + LayerNorm  (reference src/model/layers.py:185-192)
+# --------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(ref, R, C):
+    lib = _lib.load()
+    need = int(lib.dg_ln_workspace_bytes(R, C))
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ref.device)
+        _ws_cache[key] = buf
+    return buf, need
+
+
+class _LNResidual(Function):
+    @staticmethod
+    def forward(ctx, a, r, gamma, beta, eps):
+        a = _c(a)
+        r = None if r is None else _c(r)
+        C = a.shape[-1]
+        R = a.numel() // C
+        lib = _lib.load()
+        y = torch.empty_like(a)
+        mean = torch.empty(R, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=a.device)
+        with _dev(a):
+            _lib.check(lib.dg_ln_residual_fwd(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(_c(beta)),
+                                              _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), R, C, eps,
+                                              _lib.stream_of(a)), "dg_ln_residual_fwd")
+        _account("ln_fwd", 4 * R * C * (3 if r is not None else 2))
+        ctx.save_for_backward(a, r, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, r, gamma, mean, rstd = ctx.saved_tensors
+        dz, dgamma, dbeta = _LNResidualBwd.apply(a, r, gamma, mean, rstd, dy)
+        return dz, (dz if r is not None else None), dgamma, dbeta, None
+
+
+class _LNResidualBwd(Function):
+    @staticmethod
+    def forward(ctx, a, r, gamma, mean, rstd, dy):
+        dy = _c(dy)
+        C = a.shape[-1]
+        R = a.numel() // C
+        lib = _lib.load()
+        dz = torch.empty_like(a)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with _dev(a):
+            ws, need = _workspace(a, R, C)
+            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(mean),
+                                              _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(dz), _lib.ptr(dgamma),
+                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, C, _lib.stream_of(a)),
+                       "dg_ln_residual_bwd")
+        _account("ln_bwd", 4 * R * C * (4 if r is not None else 3))
+        ctx.save_for_backward(a, r, gamma, mean, rstd, dy)
+        ctx.set_materialize_grads(False)
+        return dz, dgamma, dbeta
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, tz, tgamma, tbeta):
+        a, r, gamma, mean, rstd, dy = ctx.saved_tensors
+        if tgamma is not None or tbeta is not None:
+            # only reached when somebody differentiates parameter gradients again;
+            # the WGAN-GP path differentiates the input gradient only (loss.py:32-39)
+            raise RuntimeError("ln_residual: second-order terms through dgamma/dbeta are not implemented")
+        if tz is None:
+            return None, None, None, None, None, None
+        tz = _c(tz)
+        C = a.shape[-1]
+        R = a.numel() // C
+        lib = _lib.load()
+        gz, gdy = torch.empty_like(a), torch.empty_like(a)
+        ggamma = torch.empty_like(gamma)
+        with _dev(a):
+            ws, need = _workspace(a, R, C)
+            _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(mean),
+                                               _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(tz), _lib.ptr(gz),
+                                               _lib.ptr(gdy), _lib.ptr(ggamma), ws.data_ptr(), ws.numel(), R, C,
+                                               _lib.stream_of(a)), "dg_ln_residual_bwd2")
+        _account("ln_bwd2", 4 * R * C * (6 if r is not None else 5))
+        return gz, (gz if r is not None else None), ggamma, None, None, gdy
+
+
+def ln_residual(a, r, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(a + r) * gamma + beta over the last dim; ``r`` may be None."""
+    return _LNResidual.apply(a, r, gamma, beta, float(eps))

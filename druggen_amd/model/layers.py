@@ -1,0 +1,110 @@
+"""MI355X-native mirror of the reference's ``src/model/layers.py``.
+
+Module names, parameter names and call signatures follow the reference so its
+checkpoints load unchanged; the compute goes through the HIP kernels of
+``libdruggen_hip.so`` (``druggen_amd.functional``).  Dense ``nn.Linear``
+contractions use the ROCm BLAS behind ``F.linear``.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import functional as dgf
+
+
+class MLP(nn.Module):
+    """fc2(ReLU(fc1(x))) then dropout -- reference layers.py:7-54 (always ReLU)."""
+
+    def __init__(self, in_feat, hid_feat=None, out_feat=None, dropout=0.):
+        super().__init__()
+        hid_feat = hid_feat or in_feat
+        out_feat = out_feat or in_feat
+        self.fc1 = nn.Linear(in_feat, hid_feat)
+        self.act = nn.ReLU()
+        self.fc2 = nn.Linear(hid_feat, out_feat)
+        self.droprateout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.droprateout(self.fc2(F.relu(self.fc1(x))))
+
+
+class MHA(nn.Module):
+    """Edge-modulated per-channel attention -- reference layers.py:56-137.
+
+    Parameters q, k, v, e, out_e, out_n (six ``Linear(dim, dim)``).  The score
+    s = q_i k_j / sqrt(d_k) * (e^2 + e), its softmax over j and the aggregation
+    with v run in one fused HIP kernel (``dg_attn_core_fwd``).
+    """
+
+    def __init__(self, dim, heads, attention_dropout=0.):
+        super().__init__()
+        assert dim % heads == 0
+        self.heads = heads
+        self.scale = 1. / math.sqrt(dim)      # kept for parity; unused (reference layers.py:84)
+        self.q = nn.Linear(dim, dim)
+        self.k = nn.Linear(dim, dim)
+        self.v = nn.Linear(dim, dim)
+        self.e = nn.Linear(dim, dim)
+        self.d_k = dim // heads
+        self.out_e = nn.Linear(dim, dim)
+        self.out_n = nn.Linear(dim, dim)
+
+    def forward(self, node, edge, need_edge=True):
+        q, k, v = self.q(node), self.k(node), self.v(node)
+        e = self.e(edge)
+        s, o = dgf.attn_core(q, k, v, e, 1.0 / math.sqrt(self.d_k), need_s=need_edge)
+        node_out = self.out_n(o)
+        edge_out = self.out_e(s) if need_edge else None
+        return node_out, edge_out
+
+
+class Encoder_Block(nn.Module):
+    """Reference layers.py:139-193.  LayerNorms ln1, ln3, ln4, ln5, ln6 (no ln2);
+    the node residual uses the normalised input x1."""
+
+    def __init__(self, dim, heads, act, mlp_ratio=4, drop_rate=0.):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(dim)
+        self.attn = MHA(dim, heads, drop_rate)
+        self.ln3 = nn.LayerNorm(dim)
+        self.ln4 = nn.LayerNorm(dim)
+        self.mlp = MLP(dim, dim * mlp_ratio, dim, dropout=drop_rate)
+        self.mlp2 = MLP(dim, dim * mlp_ratio, dim, dropout=drop_rate)
+        self.ln5 = nn.LayerNorm(dim)
+        self.ln6 = nn.LayerNorm(dim)
+
+    @staticmethod
+    def _ln(ln, a, r=None):
+        return dgf.ln_residual(a, r, ln.weight, ln.bias, ln.eps)
+
+    def forward(self, x, y, need_edge=True):
+        x1 = self._ln(self.ln1, x)
+        x2, y1 = self.attn(x1, y, need_edge)
+        x2 = self._ln(self.ln3, x1, x2)
+        x = self._ln(self.ln5, x2, self.mlp(x2))
+        if not need_edge:
+            return x, None
+        y2 = self._ln(self.ln4, y, y1)
+        y = self._ln(self.ln6, y2, self.mlp2(y2))
+        return x, y
+
+
+class TransformerEncoder(nn.Module):
+    """Reference layers.py:195-234: ``depth`` blocks in ``Encoder_Blocks``."""
+
+    def __init__(self, dim, depth, heads, act, mlp_ratio=4, drop_rate=0.1):
+        super().__init__()
+        self.Encoder_Blocks = nn.ModuleList([
+            Encoder_Block(dim, heads, act, mlp_ratio, drop_rate) for _ in range(depth)
+        ])
+
+    def forward(self, x, y, need_edge=True):
+        """``need_edge=False`` skips the edge branch of the LAST block (its output
+        is dropped by the Discriminator, reference models.py:202-207)."""
+        last = len(self.Encoder_Blocks) - 1
+        for idx, block in enumerate(self.Encoder_Blocks):
+            x, y = block(x, y, need_edge or idx != last)
+        return x, y

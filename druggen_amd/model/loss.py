@@ -1,0 +1,43 @@
+"""WGAN-GP losses with the reference's signatures (``src/model/loss.py``)."""
+from __future__ import annotations
+
+import torch
+
+
+def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, batch_size, device, *, eps=None):
+    """Reference loss.py:4-49.  ``eps=(eps_edge, eps_node)`` injects the two
+    uniform draws (otherwise drawn like the reference: edge first, then node)."""
+    if eps is None:
+        eps_edge = torch.rand(batch_size, 1, 1, 1, device=device)
+        eps_node = torch.rand(batch_size, 1, 1, device=device)
+    else:
+        eps_edge, eps_node = eps
+    int_node = (eps_node * real_node + (1 - eps_node) * fake_node).requires_grad_(True)
+    int_edge = (eps_edge * real_edge + (1 - eps_edge) * fake_edge).requires_grad_(True)
+    logits = discriminator(int_edge, int_node)
+    grad_node, grad_edge = torch.autograd.grad(
+        outputs=logits, inputs=[int_node, int_edge], grad_outputs=torch.ones_like(logits),
+        create_graph=True, retain_graph=True, only_inputs=True)
+    grads = torch.cat([grad_node.reshape(batch_size, -1), grad_edge.reshape(batch_size, -1)], dim=1)
+    return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+
+
+def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, mol_annot, batch_size, device,
+                       lambda_gp, *, eps=None):
+    """Reference loss.py:52-72 -> (node, edge, d_loss).
+
+    The generator output only enters detached, so its forward runs without
+    recording a graph (the reference records one it never uses)."""
+    prediction_real = -torch.mean(discriminator(drug_adj, drug_annot))
+    with torch.no_grad():
+        node, edge, node_sample, edge_sample = generator(mol_adj, mol_annot)
+    prediction_fake = torch.mean(discriminator(edge_sample, node_sample))
+    gp = gradient_penalty(discriminator, drug_annot, drug_adj, node_sample, edge_sample, batch_size, device, eps=eps)
+    return node, edge, prediction_fake + prediction_real + lambda_gp * gp
+
+
+def generator_loss(generator, discriminator, mol_adj, mol_annot, batch_size):
+    """Reference loss.py:75-84 -> (g_loss, node, edge, node_sample, edge_sample)."""
+    node, edge, node_sample, edge_sample = generator(mol_adj, mol_annot)
+    g_loss = -torch.mean(discriminator(edge_sample, node_sample))
+    return g_loss, node, edge, node_sample, edge_sample

@@ -1,0 +1,93 @@
+"""MI355X-native mirror of the reference's ``src/model/models.py``."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .layers import TransformerEncoder
+
+
+def _activation(act):
+    """String -> module, as the reference does (models.py:39-46)."""
+    table = {"relu": nn.ReLU, "leaky": nn.LeakyReLU, "sigmoid": nn.Sigmoid, "tanh": nn.Tanh}
+    return table[act]() if isinstance(act, str) and act in table else act
+
+
+class _Trunk(nn.Module):
+    """Shared front of Generator and Discriminator: node/edge embedding MLPs,
+    edge symmetrisation, TransformerEncoder (reference models.py:52-65, 91-97)."""
+
+    def __init__(self, act, vertexes, edges, nodes, dropout, dim, depth, heads, mlp_ratio):
+        super().__init__()
+        self.vertexes, self.edges, self.nodes = vertexes, edges, nodes
+        self.depth, self.dim, self.heads = depth, dim, heads
+        self.mlp_ratio, self.dropout = mlp_ratio, dropout
+        act = _activation(act)
+        self.features = vertexes * vertexes * edges + vertexes * nodes
+        self.transformer_dim = vertexes * vertexes * dim + vertexes * dim
+        self.node_layers = nn.Sequential(nn.Linear(nodes, 64), act, nn.Linear(64, dim), act, nn.Dropout(dropout))
+        self.edge_layers = nn.Sequential(nn.Linear(edges, 64), act, nn.Linear(64, dim), act, nn.Dropout(dropout))
+        self.TransformerEncoder = TransformerEncoder(dim=dim, depth=depth, heads=heads, act=act,
+                                                     mlp_ratio=mlp_ratio, drop_rate=dropout)
+        self._act = act
+
+    def _encode(self, z_e, z_n, need_edge):
+        if not z_e.is_cuda:
+            raise RuntimeError("druggen_amd modules run on MI355X only (no CPU fallback): move the model and "
+                               "its inputs to a GPU device")
+        node = self.node_layers(z_n)
+        edge = self.edge_layers(z_e)
+        edge = (edge + edge.permute(0, 2, 1, 3)) / 2
+        return self.TransformerEncoder(node, edge, need_edge)
+
+
+class Generator(_Trunk):
+    """Reference models.py:5-103.  ``forward(z_e, z_n)`` -- edge tensor first --
+    returns (node, edge, node_sample, edge_sample) with raw logits."""
+
+    def __init__(self, act, vertexes, edges, nodes, dropout, dim, depth, heads, mlp_ratio):
+        super().__init__(act, vertexes, edges, nodes, dropout, dim, depth, heads, mlp_ratio)
+        self.readout_e = nn.Linear(dim, edges)
+        self.readout_n = nn.Linear(dim, nodes)
+        self.softmax = nn.Softmax(dim=-1)     # never applied (reference models.py:69)
+
+    def forward(self, z_e, z_n):
+        node, edge = self._encode(z_e, z_n, True)
+        return node, edge, self.readout_n(node), self.readout_e(edge)
+
+
+class Discriminator(_Trunk):
+    """Reference models.py:106-209.  ``forward(z_e, z_n)`` -> logits [B, 1]."""
+
+    def __init__(self, act, vertexes, edges, nodes, dropout, dim, depth, heads, mlp_ratio):
+        super().__init__(act, vertexes, edges, nodes, dropout, dim, depth, heads, mlp_ratio)
+        act = self._act
+        self.node_features = vertexes * dim
+        self.edge_features = vertexes * vertexes * dim
+        self.node_mlp = nn.Sequential(nn.Linear(self.node_features, 64), act, nn.Linear(64, 32), act,
+                                      nn.Linear(32, 16), act, nn.Linear(16, 1))
+
+    def forward(self, z_e, z_n):
+        node, _ = self._encode(z_e, z_n, False)
+        return self.node_mlp(node.reshape(node.shape[0], -1))
+
+
+class simple_disc(nn.Module):
+    """Reference models.py:212-269: plain MLP critic (imported by train.py:20,
+    never instantiated there).  Plain torch, kept importable for drop-in parity."""
+
+    def __init__(self, act, m_dim, vertexes, b_dim):
+        super().__init__()
+        if act not in ("relu", "leaky", "sigmoid", "tanh"):
+            raise ValueError("Unsupported activation function: {}".format(act))
+        act = _activation(act)
+        widths = [vertexes * m_dim + vertexes * vertexes * b_dim, 256, 128, 64, 32, 16, 1]
+        layers = []
+        for i in range(6):
+            layers.append(nn.Linear(widths[i], widths[i + 1]))
+            if i < 5:
+                layers.append(act)
+        self.predictor = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.predictor(x)

@@ -1,0 +1,121 @@
+/*
+ * druggen_hip.h -- C ABI of libdruggen_hip.so (gfx950 / MI355X).
+ *
+ * The reference (HUBioDataLab/DrugGEN) has no FFI, plugin table or native code:
+ * its hot path is PyTorch eager ops inside src/model/{layers,models,loss}.py.
+ * The entry points below are therefore cut at the op groups that path launches
+ * (SURVEY.md section 2.1 / 8b); each cites the reference lines it replaces.  A
+ * maintainer binds them with ctypes; druggen_amd/_lib.py
+ * is that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous float32, channel-last;
+ *    the caller (PyTorch) owns all memory, kernels never allocate or retain;
+ *  - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream);
+ *    calls only enqueue work and return, there is no implicit synchronisation;
+ *  - return value 0 = success, negative = library error (DG_E_*), positive =
+ *    hipError_t; dg_last_error_string() gives a thread-local description;
+ *  - no global mutable state except the opt-in profiler (dg_prof_*), so the
+ *    library is re-entrant for nn.DataParallel's one-thread-per-GPU replicas
+ *    (reference train.py:220-223).
+ *
+ * Shapes: B molecules, N = vertexes, C = dim (C % 4 == 0, C >= 8, N <= 96 for
+ * the attention kernels), R = number of rows of a [R, C] row matrix.
+ */
+#ifndef DRUGGEN_HIP_H
+#define DRUGGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_VERSION 100            /* 0.1.0 */
+#define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
+#define DG_E_ARG     (-2)         /* null pointer / bad argument */
+#define DG_E_WORKSPACE (-3)       /* workspace too small */
+
+typedef void* dg_stream_t;        /* hipStream_t */
+
+int         dg_version(void);
+const char* dg_last_error_string(void);
+
+/* ---- graph attention core: src/model/layers.py:119-134 (MHA.forward) --------
+ *   s[b,i,j,c] = alpha * q[b,i,c] * k[b,j,c] * (e^2 + e)[b,i,j,c]      (lines 119-125)
+ *   p = softmax_j(s);  o[b,i,c] = sum_j p[b,i,j,c] * v[b,j,c]          (lines 130-134)
+ * q,k,v,o: [B,N,C]   e,s: [B,N,N,C]   alpha = 1/sqrt(C/heads).
+ * `s` is the tensor the reference feeds to out_e (line 127); pass NULL to skip
+ * writing it (Discriminator's last block never reads it, models.py:202-207).      */
+int dg_attn_core_fwd(const float* q, const float* k, const float* v, const float* e,
+                     float* s, float* o, int B, int N, int C, float alpha, dg_stream_t stream);
+
+/* First-order backward of the core (what autograd runs for lines 119-134).
+ * ws = dL/ds [B,N,N,C], wo = dL/do [B,N,C]  ->  dq,dk,dv [B,N,C], de [B,N,N,C].
+ * Recomputes s and p from (q,k,e); nothing but the inputs is saved.
+ * ws may be NULL (treated as zeros).                                              */
+int dg_attn_core_bwd(const float* q, const float* k, const float* v, const float* e,
+                     const float* ws, const float* wo,
+                     float* dq, float* dk, float* dv, float* de,
+                     int B, int N, int C, float alpha, dg_stream_t stream);
+
+/* Second-order: backward of dg_attn_core_bwd, needed by the WGAN-GP gradient
+ * penalty (src/model/loss.py:32-39 create_graph=True, train.py:367).
+ * (tq,tk,tv,te) are the adjoints of (dq,dk,dv,de).  Outputs are the adjoints of
+ * the six inputs of dg_attn_core_bwd: gq,gk,gv [B,N,C], ge [B,N,N,C],
+ * gws [B,N,N,C], gwo [B,N,C].  ws and gws may be NULL.                           */
+int dg_attn_core_bwd2(const float* q, const float* k, const float* v, const float* e,
+                      const float* ws, const float* wo,
+                      const float* tq, const float* tk, const float* tv, const float* te,
+                      float* gq, float* gk, float* gv, float* ge, float* gws, float* gwo,
+                      int B, int N, int C, float alpha, dg_stream_t stream);
+
+/* ---- residual + LayerNorm: src/model/layers.py:185-192 ----------------------
+ *   y = LayerNorm(a + r) * gamma + beta, eps = 1e-5, over the last dim C.
+ * r may be NULL (ln1, layers.py:185).  a, r, y: [R,C]; mean, rstd: [R] (saved
+ * for the backward).                                                              */
+int dg_ln_residual_fwd(const float* a, const float* r, const float* gamma, const float* beta,
+                       float* y, float* mean, float* rstd, int64_t R, int C, float eps,
+                       dg_stream_t stream);
+
+/* Workspace (bytes) for the column reductions of the two calls below. */
+size_t dg_ln_workspace_bytes(int64_t R, int C);
+
+/* dy [R,C] -> dz [R,C] (gradient of both a and r), dgamma [C], dbeta [C].       */
+int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma,
+                       const float* mean, const float* rstd, const float* dy,
+                       float* dz, float* dgamma, float* dbeta,
+                       void* workspace, size_t workspace_bytes,
+                       int64_t R, int C, dg_stream_t stream);
+
+/* Backward of dg_ln_residual_bwd w.r.t. the adjoint tz of dz (the gradient
+ * penalty differentiates the first backward w.r.t. inputs only):
+ * -> gz [R,C] (adjoint of a and r), gdy [R,C] (adjoint of dy), ggamma [C].       */
+int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
+                        const float* mean, const float* rstd, const float* dy, const float* tz,
+                        float* gz, float* gdy, float* ggamma,
+                        void* workspace, size_t workspace_bytes,
+                        int64_t R, int C, dg_stream_t stream);
+
+/* ---- opt-in kernel timing with HIP events (bench.py roofline) ----------------
+ * When enabled, every launch of a profiled kernel is bracketed by two events on
+ * the caller's stream.  dg_prof_read() synchronises the recorded events and
+ * returns the number of launches and their total device time.                    */
+enum {
+    DG_K_ATTN_FWD = 0,
+    DG_K_ATTN_BWD = 1,
+    DG_K_ATTN_BWD2 = 2,
+    DG_K_LN_FWD = 3,
+    DG_K_LN_BWD = 4,
+    DG_K_LN_BWD2 = 5,
+    DG_K_COUNT = 16
+};
+int dg_prof_enable(int on);
+int dg_prof_reset(void);
+int dg_prof_read(int kernel_id, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRUGGEN_HIP_H */

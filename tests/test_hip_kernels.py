@@ -1,0 +1,177 @@
+"""GPU parity of the C-ABI kernels against the closed forms (tests/kernel_math.py,
+themselves proven against autograd) evaluated in float64 on the CPU."""
+import math
+
+import pytest
+import torch
+
+import kernel_math as km
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5     # fp32 kernels vs fp64 closed form, relative L2 (north_star bar: 1e-3)
+
+
+def _rel(got, want):
+    want = want.double()
+    den = want.norm().item()
+    return (got.double().cpu() - want).norm().item() / (den if den > 0 else 1.0)
+
+
+def _lib():
+    from druggen_amd import _lib
+    return _lib
+
+
+def _gen(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+ATTN_SHAPES = [(2, 5, 8), (3, 6, 16), (2, 7, 12), (2, 9, 128), (1, 17, 48), (2, 24, 32), (2, 45, 128),
+               (1, 90, 128), (1, 33, 256), (3, 1, 16), (1, 96, 64)]
+
+
+@pytest.mark.parametrize("B,N,C", ATTN_SHAPES)
+def test_attn_core_forward_backward_second_order(B, N, C):
+    from druggen_amd import functional as dgf
+    alpha = 1.0 / math.sqrt(C // 4 if C >= 4 else 1)
+    q, k, v = (_gen((B, N, C), s) for s in (1, 2, 3))
+    e = _gen((B, N, N, C), 4, 0.8)
+    ws, wo = _gen((B, N, N, C), 5), _gen((B, N, C), 6)
+    t = [_gen((B, N, C), 7), _gen((B, N, C), 8), _gen((B, N, C), 9), _gen((B, N, N, C), 10)]
+    s_ref, o_ref = km.attn_core_fwd(q, k, v, e, alpha)
+    g_ref = km.attn_core_bwd(q, k, v, e, ws, wo, alpha)
+    h_ref = km.attn_core_bwd2(q, k, v, e, ws, wo, *t, alpha)
+
+    dev = "cuda"
+    f = lambda x: x.float().to(dev).requires_grad_(True)
+    qd, kd, vd, ed, wsd, wod = map(f, (q, k, v, e, ws, wo))
+    s, o = dgf.attn_core(qd, kd, vd, ed, alpha)
+    assert _rel(s, s_ref) < TOL and _rel(o, o_ref) < TOL
+    grads = torch.autograd.grad([s, o], [qd, kd, vd, ed], [wsd, wod], create_graph=True)
+    for name, got, want in zip("dq dk dv de".split(), grads, g_ref):
+        assert _rel(got, want) < TOL, name
+    phi = sum((g * tt.float().to(dev)).sum() for g, tt in zip(grads, t))
+    second = torch.autograd.grad(phi, [qd, kd, vd, ed, wsd, wod])
+    for name, got, want in zip("gq gk gv ge gws gwo".split(), second, h_ref):
+        assert _rel(got, want) < 5 * TOL, name
+
+
+def test_attn_core_without_score_output_and_null_ws():
+    """Discriminator's last block: s is neither written nor differentiated."""
+    from druggen_amd import functional as dgf
+    B, N, C, alpha = 2, 11, 64, 0.25
+    q, k, v, e = _gen((B, N, C), 1), _gen((B, N, C), 2), _gen((B, N, C), 3), _gen((B, N, N, C), 4, 0.7)
+    wo = _gen((B, N, C), 5)
+    _, o_ref = km.attn_core_fwd(q, k, v, e, alpha)
+    g_ref = km.attn_core_bwd(q, k, v, e, torch.zeros_like(e), wo, alpha)
+    f = lambda x: x.float().cuda().requires_grad_(True)
+    qd, kd, vd, ed = map(f, (q, k, v, e))
+    s, o = dgf.attn_core(qd, kd, vd, ed, alpha, need_s=False)
+    assert s is None and _rel(o, o_ref) < TOL
+    grads = torch.autograd.grad(o, [qd, kd, vd, ed], wo.float().cuda(), create_graph=True)
+    for got, want in zip(grads, g_ref):
+        assert _rel(got, want) < TOL
+    # second order with ws == NULL
+    t = [_gen((B, N, C), 7), _gen((B, N, C), 8), _gen((B, N, C), 9), _gen((B, N, N, C), 10)]
+    h_ref = km.attn_core_bwd2(q, k, v, e, torch.zeros_like(e), wo, *t, alpha)
+    phi = sum((g * tt.float().cuda()).sum() for g, tt in zip(grads, t))
+    second = torch.autograd.grad(phi, [qd, kd, vd, ed])
+    for got, want in zip(second, h_ref[:4]):
+        assert _rel(got, want) < 5 * TOL
+
+
+def test_attn_core_is_bit_reproducible():
+    from druggen_amd import functional as dgf
+    B, N, C, alpha = 4, 45, 128, 0.25
+    f = lambda shape, s: _gen(shape, s).float().cuda().requires_grad_(True)
+    q, k, v, e = f((B, N, C), 1), f((B, N, C), 2), f((B, N, C), 3), f((B, N, N, C), 4)
+    ws, wo = _gen((B, N, N, C), 5).float().cuda(), _gen((B, N, C), 6).float().cuda()
+    outs = []
+    for _ in range(3):
+        s, o = dgf.attn_core(q, k, v, e, alpha)
+        g = torch.autograd.grad([s, o], [q, k, v, e], [ws, wo])
+        outs.append([s.detach().clone(), o.detach().clone()] + [x.clone() for x in g])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
+def test_attn_core_rejects_unsupported_shapes():
+    lib = _lib().load()
+    x = torch.zeros(4, device="cuda")
+    st = lib.dg_attn_core_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                              1, 200, 128, 0.25, None)
+    assert st == -1 and b"unsupported shape" in lib.dg_last_error_string()
+    st = lib.dg_attn_core_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                              1, 9, 6, 0.25, None)
+    assert st == -1
+    st = lib.dg_attn_core_fwd(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                              1, 9, 8, 0.25, None)
+    assert st == -2
+
+
+def test_attn_core_full_size_properties():
+    """BASELINE configs[1] shape (B=256, N=45, C=128): properties that need no
+    oracle run.  v == 1 -> o == 1 (softmax rows sum to one); o is linear in v;
+    s does not depend on v."""
+    from druggen_amd import functional as dgf
+    B, N, C, alpha = 256, 45, 128, 0.25
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q, k = (torch.randn(B, N, C, device="cuda", generator=g) for _ in range(2))
+    v1, v2 = (torch.randn(B, N, C, device="cuda", generator=g) for _ in range(2))
+    e = torch.randn(B, N, N, C, device="cuda", generator=g) * 0.5
+    s1, o1 = dgf.attn_core(q, k, v1, e, alpha)
+    s2, o2 = dgf.attn_core(q, k, v2, e, alpha)
+    _, o12 = dgf.attn_core(q, k, v1 + 2 * v2, e, alpha)
+    _, ones = dgf.attn_core(q, k, torch.ones_like(v1), e, alpha)
+    assert torch.equal(s1, s2)
+    assert (ones - 1).abs().max().item() < 1e-5
+    assert (o12 - (o1 + 2 * o2)).abs().max().item() < 1e-4 * max(1.0, o12.abs().max().item())
+    # s against the definition (elementwise, cheap on the GPU itself)
+    s_def = alpha * q.unsqueeze(2) * k.unsqueeze(1) * (e * e + e)
+    assert (s1 - s_def).abs().max().item() <= 1e-5 * s_def.abs().max().item()
+
+
+LN_SHAPES = [(7, 8), (33, 16), (5, 12), (1000, 128), (3, 384), (257, 32), (65, 1024), (2, 64)]
+
+
+@pytest.mark.parametrize("R,C", LN_SHAPES)
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_ln_residual_all_orders(R, C, with_residual):
+    from druggen_amd import functional as dgf
+    a, r = _gen((R, C), 1), _gen((R, C), 2)
+    gamma, beta = 1 + 0.2 * _gen((C,), 3), _gen((C,), 4)
+    dy, tz = _gen((R, C), 5), _gen((R, C), 6)
+    z = a + r if with_residual else a
+    y_ref, mu, rstd = km.ln_fwd(z, gamma, beta)
+    dz_ref, dg_ref, db_ref = km.ln_bwd(z, gamma, mu, rstd, dy)
+    gz_ref, gg_ref, gdy_ref = km.ln_bwd2(z, gamma, mu, rstd, dy, tz)
+    f = lambda x: x.float().cuda().requires_grad_(True)
+    ad, rd, gd, bd, dyd = map(f, (a, r, gamma, beta, dy))
+    y = dgf.ln_residual(ad, rd if with_residual else None, gd, bd)
+    assert _rel(y, y_ref) < TOL
+    ins = [ad, gd, bd] + ([rd] if with_residual else [])
+    grads = torch.autograd.grad(y, ins, dyd, create_graph=True)
+    assert _rel(grads[0], dz_ref) < TOL
+    assert _rel(grads[1], dg_ref) < TOL and _rel(grads[2], db_ref) < TOL
+    if with_residual:
+        assert torch.equal(grads[3], grads[0])
+    phi = (grads[0] * tz.float().cuda()).sum()
+    gz, gg, gdy = torch.autograd.grad(phi, [ad, gd, dyd])
+    assert _rel(gz, gz_ref) < 5 * TOL and _rel(gg, gg_ref) < 5 * TOL and _rel(gdy, gdy_ref) < 5 * TOL
+
+
+def test_ln_matches_torch_layer_norm_at_edge_tensor_size():
+    """configs[1] edge tensor rows (B*N*N = 518400, C=128) vs torch on the same GPU."""
+    from druggen_amd import functional as dgf
+    R, C = 256 * 45 * 45, 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(R, C, device="cuda", generator=g)
+    r = torch.randn(R, C, device="cuda", generator=g)
+    gamma = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
+    beta = torch.randn(C, device="cuda", generator=g)
+    y = dgf.ln_residual(a, r, gamma, beta)
+    want = torch.nn.functional.layer_norm(a + r, (C,), gamma, beta, 1e-5)
+    assert (y - want).abs().max().item() < 2e-5
