@@ -46,11 +46,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(32, logical cores)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int):
+def cpu_baseline(batch: int, threads: int = 0):
     """Oracle GAN step on the host CPU: c2 shape, reduced batch (bounded sample)."""
     from oracle import druggen_oracle as orc
     from druggen_amd import synth
@@ -66,7 +67,8 @@ def cpu_baseline(batch: int):
     ee, en = synth.interpolation_eps(batch, 1234)
     t = lambda v: torch.from_numpy(v)
     args = (t(da), t(dx), t(a), t(x), 10.0, t(ee), t(en))
-    threads = torch.get_num_threads()
+    threads = threads or min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     orc.gan_step(G, D, g_opt, d_opt, *args)          # warm-up
     steps, t0 = 0, time.perf_counter()
     while steps < 5 and (steps < 1 or time.perf_counter() - t0 < 10.0):
@@ -175,7 +177,7 @@ def main():
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

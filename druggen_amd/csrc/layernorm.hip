@@ -161,16 +161,24 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const float* __restrict_
     }
 }
 
-// out[k][c] = sum_blocks part[block][k][c]  (k < K), fixed order
-__global__ void ln_finish_kernel(const float* __restrict__ part, int nblocks, int K, int C, float* __restrict__ out0,
-                                 float* __restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    for (int k = 0; k < K; ++k) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += part[(static_cast<size_t>(b) * K + k) * C + c];
+// out[k][c] = sum_blocks part[block][k][c]  (k < K).  One block per (k, 32-column chunk):
+// 32 row groups stride over the partials, then a fixed-order LDS sum (bit-reproducible).
+__global__ __launch_bounds__(1024) void ln_finish_kernel(const float* __restrict__ part, int nblocks, int K, int C,
+                                                       float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float red[32][33];
+    const int k = blockIdx.y;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int g = threadIdx.x >> 5;
+    float s = 0.f;
+    if (c < C)
+        for (int b = g; b < nblocks; b += 32) s += part[(static_cast<size_t>(b) * K + k) * C + c];
+    red[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
         float* out = k == 0 ? out0 : out1;
-        if (out) out[c] = s;
+        if (out) out[c] = t;
     }
 }
 
@@ -332,7 +340,7 @@ extern "C" int dg_ln_residual_bwd(const float* a, const float* r, const float* g
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
     if (dgamma || dbeta)
-        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, part, grid, 2, C, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, stream, part, grid, 2, C, dgamma, dbeta);
     return check_launch("dg_ln_residual_bwd");
 }
 
@@ -355,7 +363,7 @@ extern "C" int dg_ln_residual_bwd2(const float* a, const float* r, const float* 
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
     if (ggamma)
-        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, part, grid, 1, C, ggamma,
+        hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, 1), dim3(1024), 0, stream, part, grid, 1, C, ggamma,
                            static_cast<float*>(nullptr));
     return check_launch("dg_ln_residual_bwd2");
 }
