@@ -1,0 +1,251 @@
+// Weight/bias gradient of nn.Linear over the edge rows -- the contraction the
+// reference runs as `mm(dy.t(), x)` + `sum(dy, 0)` in every Linear backward of
+// src/model/layers.py (q/k/v/e/out_e/out_n, MLP.fc1/fc2) and again inside the
+// gradient-penalty double backward (src/model/loss.py:32-39):
+//
+//     dW[n][k] = sum_r dy[r][n] * x[r][k]        db[n] = sum_r dy[r][n]
+//
+// with R = B*N*N (518 400 at configs[1]) and N,K in {64,128,384}: a tall-skinny
+// "TN" GEMM whose contraction runs over the huge row dimension.  fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, exact fp32): the full [N,K] output lives in the
+// accumulators of one workgroup (NT x KT tiles of 32x32 over WN x WK waves), the
+// workgroup streams its share of rows HBM -> LDS with the async LDS-DMA
+// (global_load_lds, 16 B/lane; a TR-row tile of a row-major matrix is one
+// contiguous chunk, so the LDS image is lane-linear), double buffered, and
+// feeds MFMA operands with conflict-free ds_read_b32 (lane&31 walks a row).
+// Split-K partials are reduced by a second kernel in a fixed order.
+#include "common.h"
+
+namespace dg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// Copy `rows` x W floats (contiguous in global memory starting at g) into LDS at l.
+// Rows >= valid_rows are skipped (their LDS bytes must have been zeroed before).
+template <int THREADS>
+__device__ __forceinline__ void stage_tile(const float* g, float* l, int W, int rows, int valid_rows) {
+    const int chunks = rows * W / 4;          // 16-byte chunks
+    const int valid = valid_rows * W / 4;
+    for (int c = threadIdx.x; c < chunks; c += THREADS) {
+        // the LDS destination of the DMA is (wave-uniform base) + lane*16: c is lane-linear per wave
+        if (c < valid) dma16(g + static_cast<size_t>(c) * 4, l + (c - (threadIdx.x & 63)) * 4);
+    }
+}
+
+template <int NT, int KT, int WN, int WK, int TR>
+__global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restrict__ dy,
+                                                           const float* __restrict__ x,
+                                                           float* __restrict__ part_w, float* __restrict__ part_b,
+                                                           int64_t R, int tiles_per_block) {
+    constexpr int N = NT * 32, K = KT * 32, THREADS = WN * WK * 64;
+    constexpr int TN = NT / WN, TK = KT / WK;   // tiles per wave
+    static_assert(NT % WN == 0 && KT % WK == 0, "wave grid must divide the tile grid");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    // buffers: [2][TR*(N+K)]  (dy tile then x tile)
+    constexpr int BUF = TR * (N + K);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave % WN, wk = wave / WN;
+    const int64_t total_tiles = (R + TR - 1) / TR;
+    const int64_t t_lo = static_cast<int64_t>(blockIdx.x) * tiles_per_block;
+    int64_t t_hi = t_lo + tiles_per_block;
+    if (t_hi > total_tiles) t_hi = total_tiles;
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    constexpr int H = THREADS >= 2 * N ? 2 : 1;   // row halves for the bias column sums
+    static_assert(THREADS >= N, "bias reduction needs one thread per column");
+    float bacc = 0.f;   // bias partial: thread t owns column t % N, row part t / N
+
+    auto issue = [&](int64_t t, int buf) {
+        const int64_t r0 = t * TR;
+        const int valid = static_cast<int>((R - r0) < TR ? (R - r0) : TR);
+        float* ldy = lds + buf * BUF;
+        float* lx = ldy + TR * N;
+        if (valid < TR) {   // zero the whole buffer first (block-uniform branch)
+            for (int c = threadIdx.x; c < BUF / 4; c += THREADS) st4(ldy + c * 4, f4(0.f));
+            __syncthreads();
+        }
+        stage_tile<THREADS>(dy + r0 * N, ldy, N, TR, valid);
+        stage_tile<THREADS>(x + r0 * K, lx, K, TR, valid);
+    };
+
+    if (t_lo < t_hi) issue(t_lo, 0);
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int buf = static_cast<int>((t - t_lo) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tile t landed for every wave; tile t-1 fully consumed
+        if (t + 1 < t_hi) issue(t + 1, buf ^ 1);
+        const float* ldy = lds + buf * BUF;
+        const float* lx = ldy + TR * N;
+        const int half = lane >> 5, col = lane & 31;
+#pragma unroll 4
+        for (int ks = 0; ks < TR / 2; ++ks) {
+            float a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = ldy[(2 * ks + half) * N + (wn * TN + i) * 32 + col];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = lx[(2 * ks + half) * K + (wk * TK + j) * 32 + col];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (part_b) {
+            if (threadIdx.x < N * H) {   // (column, row part)
+                const int c = threadIdx.x % N, h = threadIdx.x / N;
+                float s = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < TR / H; ++r) s += ldy[(h * (TR / H) + r) * N + c];
+                bacc += s;
+            }
+        }
+    }
+    // partial tile -> workspace
+    float* pw = part_w + static_cast<size_t>(blockIdx.x) * N * K;
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                pw[((wn * TN + i) * 32 + row) * K + (wk * TK + j) * 32 + col] = acc[i][j][reg];
+            }
+    if (part_b) {
+        // combine the two row halves in a fixed order through LDS
+        __syncthreads();
+        float* red = lds;
+        if (threadIdx.x < N * H) red[threadIdx.x] = bacc;
+        __syncthreads();
+        if (threadIdx.x < N)
+            part_b[static_cast<size_t>(blockIdx.x) * N + threadIdx.x] =
+                H == 2 ? red[threadIdx.x] + red[N + threadIdx.x] : red[threadIdx.x];
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i], fixed order, float4 per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t n4,
+                                                          float* __restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = f4(0.f);
+    for (int p = 0; p < S; ++p) s += ld4(part + (static_cast<size_t>(p) * n4 + i) * 4);
+    st4(out + i * 4, s);
+}
+
+struct WgradPlan {
+    int nt, kt, wn, wk, tr, threads, lds;
+};
+
+bool wgrad_plan(int N, int K, WgradPlan* p) {
+    if (N % 32 || K % 32 || N < 32 || K < 32) return false;
+    p->nt = N / 32;
+    p->kt = K / 32;
+    struct Row {
+        int nt, kt, wn, wk, tr;
+    };
+    static const Row table[] = {
+        {4, 4, 2, 2, 32},   // 128 x 128   (q,k,v,e,out_e,out_n)
+        {12, 4, 4, 2, 16},  // 384 x 128   (fc1: dW[3C, C])
+        {4, 12, 2, 4, 16},  // 128 x 384   (fc2: dW[C, 3C])
+        {4, 2, 2, 2, 32},   // 128 x 64    (embedding layer 2: Linear(64, C))
+        {2, 2, 2, 2, 32},   // 64 x 64
+        {1, 1, 1, 1, 32},   // 32 x 32     (tiny test models)
+        {2, 1, 2, 1, 32},   // 64 x 32
+        {1, 2, 1, 2, 32},   // 32 x 64
+        {3, 1, 3, 1, 32},   // 96 x 32
+        {1, 3, 1, 3, 32},   // 32 x 96
+    };
+    for (const Row& r : table)
+        if (r.nt == p->nt && r.kt == p->kt) {
+            p->wn = r.wn;
+            p->wk = r.wk;
+            p->tr = r.tr;
+            p->threads = r.wn * r.wk * 64;
+            p->lds = 2 * r.tr * (N + K) * 4;
+            return true;
+        }
+    return false;
+}
+
+int wgrad_blocks(int64_t R, const WgradPlan& p, int* tiles_per_block) {
+    const int64_t tiles = (R + p.tr - 1) / p.tr;
+    const int per_cu = p.lds > 80 * 1024 ? 1 : 2;
+    int64_t target = 256 * per_cu;
+    if (target > tiles) target = tiles < 1 ? 1 : tiles;
+    const int64_t tpb = (tiles + target - 1) / target;
+    *tiles_per_block = static_cast<int>(tpb < 1 ? 1 : tpb);
+    return static_cast<int>((tiles + *tiles_per_block - 1) / *tiles_per_block);
+}
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
+    WgradPlan p;
+    if (R < 1 || !wgrad_plan(N, K, &p)) return 0;
+    int tpb;
+    const int S = wgrad_blocks(R, p, &tpb);
+    return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
+}
+
+extern "C" int dg_linear_wgrad(const float* dy, const float* x, float* dw, float* db, void* workspace,
+                               size_t workspace_bytes, int64_t R, int N, int K, dg_stream_t stream_) {
+    if (!dy || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
+    WgradPlan p;
+    if (R < 1 || !wgrad_plan(N, K, &p))
+        return fail(DG_E_SHAPE, "dg_linear_wgrad: unsupported shape R=%lld N=%d K=%d", (long long)R, N, K);
+    if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
+        return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int tpb;
+    const int S = wgrad_blocks(R, p, &tpb);
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
+    ProfScope prof(DG_K_LINEAR_WGRAD, stream);
+#define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                                                         \
+    if (p.nt == NT_ && p.kt == KT_) {                                                                           \
+        static const hipError_t attr =                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TR_ * (NT_ + KT_) * 32 * 4);    \
+        (void)attr;                                                                                             \
+        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_>), dim3(S), dim3(WN_* WK_ * 64), p.lds, stream, \
+                           dy, x, part_w, part_b, R, tpb);                                                      \
+    }
+    LAUNCH(4, 4, 2, 2, 32)
+    LAUNCH(12, 4, 4, 2, 16)
+    LAUNCH(4, 12, 2, 4, 16)
+    LAUNCH(4, 2, 2, 2, 32)
+    LAUNCH(2, 2, 2, 2, 32)
+    LAUNCH(1, 1, 1, 1, 32)
+    LAUNCH(2, 1, 2, 1, 32)
+    LAUNCH(1, 2, 1, 2, 32)
+    LAUNCH(3, 1, 3, 1, 32)
+    LAUNCH(1, 3, 1, 3, 32)
+#undef LAUNCH
+    const int64_t n4 = static_cast<int64_t>(N) * K / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, stream,
+                       part_w, S, n4, dw);
+    if (db)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, stream, part_b, S,
+                           static_cast<int64_t>(N / 4), db);
+    return check_launch("dg_linear_wgrad");
+}

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import threading
 
 import torch
 from torch.autograd import Function
@@ -17,7 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "traffic_reset", "traffic_bytes"]
+__all__ = ["attn_core", "ln_residual", "linear", "inputs_only_backward", "traffic_reset", "traffic_bytes"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -144,15 +145,19 @@ def attn_core(q, k, v, e, alpha: float, need_s: bool = True):
 _ws_cache = {}
 
 
-def _workspace(ref, R, C):
-    lib = _lib.load()
-    need = int(lib.dg_ln_workspace_bytes(R, C))
-    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+def _scratch(ref, need, tag="ln"):
+    """Per (device, stream, tag) scratch buffer owned by the caller side (PyTorch)."""
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ref.device)
         _ws_cache[key] = buf
-    return buf, need
+    return buf
+
+
+def _workspace(ref, R, C):
+    need = int(_lib.load().dg_ln_workspace_bytes(R, C))
+    return _scratch(ref, need, "ln"), need
 
 
 class _LNResidual(Function):
@@ -230,3 +235,97 @@ class _LNResidualBwd(Function):
 def ln_residual(a, r, gamma, beta, eps: float = 1e-5):
     """LayerNorm(a + r) * gamma + beta over the last dim; ``r`` may be None."""
     return _LNResidual.apply(a, r, gamma, beta, float(eps))
+
+
+# --------------------------------------------------------------------------
+# nn.Linear with the weight/bias gradient on the fp32-MFMA split-K kernel
+# (reference: every nn.Linear of src/model/layers.py; forward / input-gradient
+# contractions stay on the ROCm BLAS behind F.linear / matmul)
+# --------------------------------------------------------------------------
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def inputs_only_backward():
+    """Inside this context a backward pass skips parameter gradients of the
+    custom ops.  Used around the gradient penalty's first-order
+    ``autograd.grad(..., inputs=[int_node, int_edge])`` (loss.py:32-39), where
+    PyTorch's built-in ops skip them too but custom Functions cannot tell."""
+    prev = getattr(_tls, "inputs_only", False)
+    _tls.inputs_only = True
+    try:
+        yield
+    finally:
+        _tls.inputs_only = prev
+
+
+def _wgrad(dy2, x2, want_bias):
+    """dW [N,K] = dy2^T x2, db [N] = column sums of dy2 (or None)."""
+    R, N = dy2.shape
+    K = x2.shape[1]
+    lib = _lib.load()
+    need = int(lib.dg_linear_wgrad_workspace_bytes(R, N, K)) if dy2.is_cuda else 0
+    if need == 0:      # shape outside the kernel's table: library GEMM on the same device
+        return dy2.t().mm(x2), (dy2.sum(0) if want_bias else None)
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy2.device) if want_bias else None
+    with _dev(dy2):
+        ws = _scratch(dy2, need, "wgrad")
+        _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
+                                       ws.numel(), R, N, K, _lib.stream_of(dy2)), "dg_linear_wgrad")
+    _account("linear_wgrad", 4 * R * (N + K))
+    return dw, db
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
+        dx, dw, db = _LinearBwd.apply(x, w, dy, ctx.has_bias and need_w, ctx.needs_input_grad[0], need_w)
+        return dx, dw, db
+
+
+class _LinearBwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, dy, want_bias, need_x, need_w):
+        dy = _c(dy)
+        N, K = w.shape
+        dx = dy.matmul(w) if need_x else None
+        dw = db = None
+        if need_w:
+            dw, db = _wgrad(dy.reshape(-1, N), _c(x).reshape(-1, K), want_bias)
+        ctx.save_for_backward(x, w, dy)
+        ctx.set_materialize_grads(False)
+        return dx, dw, db
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, tdx, tdw, tdb):
+        x, w, dy = ctx.saved_tensors
+        N, K = w.shape
+        g_x = g_w = g_dy = None
+        if tdx is not None:
+            tdx = _c(tdx)
+            g_dy = torch.nn.functional.linear(tdx, w)
+            if not getattr(_tls, "inputs_only", False):
+                g_w, _ = _wgrad(dy.reshape(-1, N), tdx.reshape(-1, K), False)
+        if tdw is not None:
+            g_x = dy.matmul(tdw)
+            t = x.matmul(tdw.t())
+            g_dy = t if g_dy is None else g_dy + t
+        if tdb is not None:
+            g_dy = tdb.expand_as(dy) if g_dy is None else g_dy + tdb
+        return g_x, g_w, g_dy, None, None, None
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` whose weight/bias gradients (first and second order) run on
+    ``dg_linear_wgrad``."""
+    return _Linear.apply(x, weight, bias)

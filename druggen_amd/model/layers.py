@@ -28,7 +28,8 @@ class MLP(nn.Module):
         self.droprateout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self.droprateout(self.fc2(F.relu(self.fc1(x))))
+        h = F.relu(dgf.linear(x, self.fc1.weight, self.fc1.bias))
+        return self.droprateout(dgf.linear(h, self.fc2.weight, self.fc2.bias))
 
 
 class MHA(nn.Module):
@@ -53,11 +54,14 @@ class MHA(nn.Module):
         self.out_n = nn.Linear(dim, dim)
 
     def forward(self, node, edge, need_edge=True):
-        q, k, v = self.q(node), self.k(node), self.v(node)
-        e = self.e(edge)
+        lin = dgf.linear
+        q = lin(node, self.q.weight, self.q.bias)
+        k = lin(node, self.k.weight, self.k.bias)
+        v = lin(node, self.v.weight, self.v.bias)
+        e = lin(edge, self.e.weight, self.e.bias)
         s, o = dgf.attn_core(q, k, v, e, 1.0 / math.sqrt(self.d_k), need_s=need_edge)
-        node_out = self.out_n(o)
-        edge_out = self.out_e(s) if need_edge else None
+        node_out = lin(o, self.out_n.weight, self.out_n.bias)
+        edge_out = lin(s, self.out_e.weight, self.out_e.bias) if need_edge else None
         return node_out, edge_out
 
 

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import torch
 
+from .. import functional as dgf
+
 
 def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, batch_size, device, *, eps=None):
     """Reference loss.py:4-49.  ``eps=(eps_edge, eps_node)`` injects the two
@@ -15,9 +17,10 @@ def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, 
     int_node = (eps_node * real_node + (1 - eps_node) * fake_node).requires_grad_(True)
     int_edge = (eps_edge * real_edge + (1 - eps_edge) * fake_edge).requires_grad_(True)
     logits = discriminator(int_edge, int_node)
-    grad_node, grad_edge = torch.autograd.grad(
-        outputs=logits, inputs=[int_node, int_edge], grad_outputs=torch.ones_like(logits),
-        create_graph=True, retain_graph=True, only_inputs=True)
+    with dgf.inputs_only_backward():      # parameter gradients of this pass are never used
+        grad_node, grad_edge = torch.autograd.grad(
+            outputs=logits, inputs=[int_node, int_edge], grad_outputs=torch.ones_like(logits),
+            create_graph=True, retain_graph=True, only_inputs=True)
     grads = torch.cat([grad_node.reshape(batch_size, -1), grad_edge.reshape(batch_size, -1)], dim=1)
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
 

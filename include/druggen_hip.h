@@ -98,6 +98,20 @@ int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
                         void* workspace, size_t workspace_bytes,
                         int64_t R, int C, dg_stream_t stream);
 
+/* ---- Linear weight/bias gradient over the edge rows ---------------------------
+ * What autograd runs as mm(dy.t(), x) and sum(dy, 0) for every nn.Linear of
+ * src/model/layers.py (MHA q/k/v/e/out_e/out_n at :86-95, MLP fc1/fc2 at :36-38)
+ * and again in the gradient-penalty double backward (src/model/loss.py:32-39):
+ *   dw[n][k] = sum_r dy[r][n] x[r][k]   (dw: [N,K], nn.Linear layout)
+ *   db[n]    = sum_r dy[r][n]           (db may be NULL)
+ * dy: [R,N], x: [R,K].  fp32 MFMA, split over the rows, fixed-order reduction.
+ * Supported (N,K): multiples of 32 from the table in csrc/linear_wgrad.hip
+ * (128x128, 384x128, 128x384, 128x64, ...); others return DG_E_SHAPE.             */
+size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K);
+int dg_linear_wgrad(const float* dy, const float* x, float* dw, float* db,
+                    void* workspace, size_t workspace_bytes,
+                    int64_t R, int N, int K, dg_stream_t stream);
+
 /* ---- opt-in kernel timing with HIP events (bench.py roofline) ----------------
  * When enabled, every launch of a profiled kernel is bracketed by two events on
  * the caller's stream.  dg_prof_read() synchronises the recorded events and
@@ -109,6 +123,7 @@ enum {
     DG_K_LN_FWD = 3,
     DG_K_LN_BWD = 4,
     DG_K_LN_BWD2 = 5,
+    DG_K_LINEAR_WGRAD = 6,
     DG_K_COUNT = 16
 };
 int dg_prof_enable(int on);
