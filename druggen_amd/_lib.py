@@ -31,13 +31,16 @@ SIGNATURES = {
     "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, _P]),
     "dg_ln_residual_bwd2": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
     "dg_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "dg_linear_wgrad": (c_int, [_P] * 4 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_linear_wgrad": (c_int, [_P] * 5 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_row_gemm_packed_floats": (c_size_t, [c_int, c_int]),
+    "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "dg_row_gemm": (c_int, [_P] * 4 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
     "dg_prof_enable": (c_int, [c_int]),
     "dg_prof_reset": (c_int, []),
     "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6}
+KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7}
 
 _lock = threading.Lock()
 _lib = None

@@ -39,8 +39,9 @@ __device__ __forceinline__ void stage_tile(const float* g, float* l, int W, int 
     }
 }
 
-template <int NT, int KT, int WN, int WK, int TR>
+template <int NT, int KT, int WN, int WK, int TR, bool MASK>
 __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restrict__ dy,
+                                                           const float* __restrict__ dymask,
                                                            const float* __restrict__ x,
                                                            float* __restrict__ part_w, float* __restrict__ part_b,
                                                            int64_t R, int tiles_per_block) {
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
     static_assert(NT % WN == 0 && KT % WK == 0, "wave grid must divide the tile grid");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
-    // buffers: [2][TR*(N+K)]  (dy tile then x tile)
-    constexpr int BUF = TR * (N + K);
+    // buffers: [2][TR*(N+K)] (dy tile, x tile) or [2][TR*(2N+K)] (dy, x, mask tiles)
+    constexpr int BUF = TR * (N + K + (MASK ? N : 0));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave % WN, wk = wave / WN;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
         }
         stage_tile<THREADS>(dy + r0 * N, ldy, N, TR, valid);
         stage_tile<THREADS>(x + r0 * K, lx, K, TR, valid);
+        if (MASK) stage_tile<THREADS>(dymask + r0 * N, lx + TR * K, N, TR, valid);
     };
 
     if (t_lo < t_hi) issue(t_lo, 0);
@@ -96,7 +98,11 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
         for (int ks = 0; ks < TR / 2; ++ks) {
             float a[TN], b[TK];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) a[i] = ldy[(2 * ks + half) * N + (wn * TN + i) * 32 + col];
+            for (int i = 0; i < TN; ++i) {
+                const int o = (2 * ks + half) * N + (wn * TN + i) * 32 + col;
+                a[i] = ldy[o];
+                if (MASK) a[i] = lx[TR * K + o] > 0.f ? a[i] : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < TK; ++j) b[j] = lx[(2 * ks + half) * K + (wk * TK + j) * 32 + col];
 #pragma unroll
@@ -110,7 +116,10 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
                 const int c = threadIdx.x % N, h = threadIdx.x / N;
                 float s = 0.f;
 #pragma unroll 8
-                for (int r = 0; r < TR / H; ++r) s += ldy[(h * (TR / H) + r) * N + c];
+                for (int r = 0; r < TR / H; ++r) {
+                    const int o = (h * (TR / H) + r) * N + c;
+                    s += (MASK && !(lx[TR * K + o] > 0.f)) ? 0.f : ldy[o];
+                }
                 bacc += s;
             }
         }
@@ -139,18 +148,31 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i], fixed order, float4 per thread
+// out[i] = sum_s part[s][i] in a fixed order.  Block = 16 partial-groups x 16 float4 columns:
+// group g sums partials g, g+16, ... (independent 16 B loads, unrolled), then the 16 group
+// sums are added in order through LDS.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t n4,
                                                           float* __restrict__ out) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n4) return;
+    __shared__ float4 red[16][17];
+    const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + c;
     float4 s = f4(0.f);
-    for (int p = 0; p < S; ++p) s += ld4(part + (static_cast<size_t>(p) * n4 + i) * 4);
-    st4(out + i * 4, s);
+    if (i < n4) {
+#pragma unroll 8
+        for (int p = g; p < S; p += 16) s += ld4(part + (static_cast<size_t>(p) * n4 + i) * 4);
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+        float4 t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][c];
+        st4(out + i * 4, t);
+    }
 }
 
 struct WgradPlan {
-    int nt, kt, wn, wk, tr, threads, lds;
+    int nt, kt, wn, wk, tr, threads, lds, lds_mask;
 };
 
 bool wgrad_plan(int N, int K, WgradPlan* p) {
@@ -179,6 +201,7 @@ bool wgrad_plan(int N, int K, WgradPlan* p) {
             p->tr = r.tr;
             p->threads = r.wn * r.wk * 64;
             p->lds = 2 * r.tr * (N + K) * 4;
+            p->lds_mask = 2 * r.tr * (2 * N + K) * 4;
             return true;
         }
     return false;
@@ -186,7 +209,7 @@ bool wgrad_plan(int N, int K, WgradPlan* p) {
 
 int wgrad_blocks(int64_t R, const WgradPlan& p, int* tiles_per_block) {
     const int64_t tiles = (R + p.tr - 1) / p.tr;
-    const int per_cu = p.lds > 80 * 1024 ? 1 : 2;
+    const int per_cu = p.lds > 64 * 1024 ? 1 : 2;
     int64_t target = 256 * per_cu;
     if (target > tiles) target = tiles < 1 ? 1 : tiles;
     const int64_t tpb = (tiles + target - 1) / target;
@@ -207,7 +230,7 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
-extern "C" int dg_linear_wgrad(const float* dy, const float* x, float* dw, float* db, void* workspace,
+extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db, void* workspace,
                                size_t workspace_bytes, int64_t R, int N, int K, dg_stream_t stream_) {
     if (!dy || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
     WgradPlan p;
@@ -221,14 +244,20 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* x, float* dw, float
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     ProfScope prof(DG_K_LINEAR_WGRAD, stream);
-#define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                                                         \
-    if (p.nt == NT_ && p.kt == KT_) {                                                                           \
-        static const hipError_t attr =                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_>),          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TR_ * (NT_ + KT_) * 32 * 4);    \
-        (void)attr;                                                                                             \
-        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_>), dim3(S), dim3(WN_* WK_ * 64), p.lds, stream, \
-                           dy, x, part_w, part_b, R, tpb);                                                      \
+#define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                                                     \
+    {                                                                                                            \
+        constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * 4;                                  \
+        static const hipError_t attr =                                                                           \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                          \
+        (void)attr;                                                                                              \
+        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_>), dim3(S), dim3(WN_* WK_ * 64), lds_bytes,  \
+                           stream, dy, dy_mask, x, part_w, part_b, R, tpb);                                      \
+    }
+#define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                   \
+    if (p.nt == NT_ && p.kt == KT_) {                                     \
+        if (dy_mask) LAUNCH_M(NT_, KT_, WN_, WK_, TR_, true)              \
+        else LAUNCH_M(NT_, KT_, WN_, WK_, TR_, false)                     \
     }
     LAUNCH(4, 4, 2, 2, 32)
     LAUNCH(12, 4, 4, 2, 16)
@@ -240,12 +269,13 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* x, float* dw, float
     LAUNCH(1, 2, 1, 2, 32)
     LAUNCH(3, 1, 3, 1, 32)
     LAUNCH(1, 3, 1, 3, 32)
+#undef LAUNCH_M
 #undef LAUNCH
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 15) / 16)), dim3(256), 0, stream,
                        part_w, S, n4, dw);
     if (db)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, stream, part_b, S,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N / 4 + 15) / 16), dim3(256), 0, stream, part_b, S,
                            static_cast<int64_t>(N / 4), db);
     return check_launch("dg_linear_wgrad");
 }

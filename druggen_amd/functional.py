@@ -11,6 +11,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import threading
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -18,7 +19,8 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "linear", "inputs_only_backward", "traffic_reset", "traffic_bytes"]
+__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "inputs_only_backward",
+           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -259,21 +261,23 @@ def inputs_only_backward():
         _tls.inputs_only = prev
 
 
-def _wgrad(dy2, x2, want_bias):
+def _wgrad(dy2, x2, want_bias, dy_mask=None):
     """dW [N,K] = dy2^T x2, db [N] = column sums of dy2 (or None)."""
     R, N = dy2.shape
     K = x2.shape[1]
     lib = _lib.load()
     need = int(lib.dg_linear_wgrad_workspace_bytes(R, N, K)) if dy2.is_cuda else 0
     if need == 0:      # shape outside the kernel's table: library GEMM on the same device
+        if dy_mask is not None:
+            dy2 = dy2 * (dy_mask > 0)
         return dy2.t().mm(x2), (dy2.sum(0) if want_bias else None)
     dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
     db = torch.empty(N, dtype=torch.float32, device=dy2.device) if want_bias else None
     with _dev(dy2):
         ws = _scratch(dy2, need, "wgrad")
-        _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
+        _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
                                        ws.numel(), R, N, K, _lib.stream_of(dy2)), "dg_linear_wgrad")
-    _account("linear_wgrad", 4 * R * (N + K))
+    _account("linear_wgrad", 4 * R * (N * (2 if dy_mask is not None else 1) + K))
     return dw, db
 
 
@@ -329,3 +333,188 @@ def linear(x, weight, bias=None):
     """``F.linear`` whose weight/bias gradients (first and second order) run on
     ``dg_linear_wgrad``."""
     return _Linear.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------
+# fp32-MFMA row GEMM with fused prologue / epilogue (dg_row_gemm)
+# --------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def packed_weight(w, mode: int):
+    """MFMA-fragment-ordered copy of an nn.Linear weight (mode 0: forward, 1: input
+    gradient), cached per (storage, version): re-packed only after an optimizer step."""
+    key = (id(w), mode)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[3] == w.data_ptr():
+        return hit[2]
+    if len(_pack_cache) > 4096:       # entries of dead tensors (e.g. DataParallel replicas)
+        for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
+            del _pack_cache[k]
+    lib = _lib.load()
+    rows, cols = w.shape
+    n_out, k = (rows, cols) if mode == 0 else (cols, rows)
+    packed = torch.empty(int(lib.dg_row_gemm_packed_floats(n_out, k)), dtype=torch.float32, device=w.device)
+    wd = _c(w.detach())
+    with _dev(w):
+        _lib.check(lib.dg_row_gemm_pack(_lib.ptr(wd), _lib.ptr(packed), rows, cols, mode, _lib.stream_of(w)),
+                   "dg_row_gemm_pack")
+    _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr())
+    return packed
+
+
+def row_gemm_supported(K: int, N: int) -> bool:
+    return (K == 128 and N in (128, 384)) or (K == 384 and N == 128)
+
+
+def row_gemm(a2, packed, K, N, bias=None, relu=False, a_mask=None, out_mask=None, residual=None, ln=None,
+             want_pre=False):
+    """y = epi(pro(a2) @ B): see include/druggen_hip.h.  ``ln=(gamma, beta, eps)`` selects the
+    LayerNorm epilogue and returns (y, mean, rstd); otherwise returns y."""
+    R = a2.shape[0]
+    lib = _lib.load()
+    y = torch.empty(R, N, dtype=torch.float32, device=a2.device)
+    mean = rstd = gamma = beta = pre = None
+    eps = 0.0
+    if ln is not None and want_pre:
+        pre = torch.empty(R, N, dtype=torch.float32, device=a2.device)
+    if ln is not None:
+        gamma, beta, eps = ln
+        mean = torch.empty(R, dtype=torch.float32, device=a2.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=a2.device)
+    with _dev(a2):
+        _lib.check(lib.dg_row_gemm(_lib.ptr(a2), _lib.ptr(a_mask), _lib.ptr(packed), _lib.ptr(y), R, K, N,
+                                   _lib.ptr(bias), 1 if relu else 0, _lib.ptr(out_mask), _lib.ptr(residual),
+                                   _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre), float(eps),
+                                   _lib.stream_of(a2)), "dg_row_gemm")
+    nb = 4 * R * (K * (2 if a_mask is not None else 1) + N * (1 + (out_mask is not None) + (residual is not None)))
+    _account("row_gemm", nb)
+    if ln is None:
+        return y
+    return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
+
+
+# --------------------------------------------------------------------------
+# fused layers built on dg_row_gemm (first-order fast path)
+# --------------------------------------------------------------------------
+@contextlib.contextmanager
+def second_order_forward():
+    """Forward passes run inside this context will be differentiated twice
+    (gradient penalty, loss.py:28-39): modules then build their graph from the
+    twice-differentiable ops (linear / ln_residual / attn_core) instead of the
+    fused first-order ones, which would have to recompute."""
+    prev = getattr(_tls, "second_order", False)
+    _tls.second_order = True
+    try:
+        yield
+    finally:
+        _tls.second_order = prev
+
+
+def in_second_order_forward() -> bool:
+    return getattr(_tls, "second_order", False)
+
+
+def _double_backward_fallback(composite, inputs, grad_out):
+    """Backward of a fused op when the caller asked for create_graph=True: rebuild the
+    op from twice-differentiable pieces on the original (graph-attached) inputs."""
+    with torch.enable_grad():
+        out = composite(*inputs)
+        need = [t for t in inputs if isinstance(t, torch.Tensor) and t.requires_grad]
+        grads = iter(torch.autograd.grad(out, need, grad_out, create_graph=True, allow_unused=True))
+    return tuple(next(grads) if (isinstance(t, torch.Tensor) and t.requires_grad) else None for t in inputs)
+
+
+def _fusable(x, w):
+    N, K = w.shape
+    return x.is_cuda and x.dtype == torch.float32 and row_gemm_supported(K, N)
+
+
+def _composite_linear_relu(x, w, b):
+    return torch.relu(linear(x, w, b))
+
+
+class _LinearReLU(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        N, K = w.shape
+        x2 = _c(x).reshape(-1, K)
+        h = row_gemm(x2, packed_weight(w, 0), K, N, bias=b, relu=True)
+        ctx.save_for_backward(x, w, b, h)
+        return h.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, h = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return _double_backward_fallback(_composite_linear_relu, (x, w, b), dy)
+        N, K = w.shape
+        dy2 = _c(dy).reshape(-1, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx = (dy * (h > 0)) @ W : contraction over N, ReLU mask folded into the operand load
+            dx = row_gemm(dy2, packed_weight(w, 1), N, K, a_mask=h).view(x.shape)
+        if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
+            dw, db = _wgrad(dy2, _c(x).reshape(-1, K), b is not None, dy_mask=h)
+        return dx, dw, db
+
+
+def linear_relu(x, weight, bias):
+    """relu(x W^T + b) -- MLP.fc1 + act (reference layers.py:50-51) in one kernel; the
+    backward folds the ReLU mask into the dgrad / wgrad operand loads."""
+    if not _fusable(x, weight) or in_second_order_forward():
+        return _composite_linear_relu(x, weight, bias)
+    return _LinearReLU.apply(x, weight, bias)
+
+
+def _composite_linear_ln(x, w, b, residual, gamma, beta, eps):
+    return ln_residual(residual, linear(x, w, b), gamma, beta, eps)
+
+
+class _LinearLN(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual, gamma, beta, eps):
+        N, K = w.shape
+        x2 = _c(x).reshape(-1, K)
+        r2 = _c(residual).reshape(-1, N)
+        y, mean, rstd, pre = row_gemm(x2, packed_weight(w, 0), K, N, bias=b, residual=r2,
+                                      ln=(_c(gamma), _c(beta), eps), want_pre=True)
+        ctx.save_for_backward(x, w, b, residual, gamma, beta, mean, rstd, pre)
+        ctx.eps = eps
+        return y.view(residual.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, residual, gamma, beta, mean, rstd, pre = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            eps = ctx.eps
+            g = _double_backward_fallback(lambda *t: _composite_linear_ln(*t, eps),
+                                          (x, w, b, residual, gamma, beta), dy)
+            return g + (None,)
+        N, K = w.shape
+        R = pre.shape[0]
+        lib = _lib.load()
+        dy2 = _c(dy).reshape(-1, N)
+        dz = torch.empty_like(pre)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with _dev(pre):
+            ws, _ = _workspace(pre, R, N)
+            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean),
+                                              _lib.ptr(rstd), _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dgamma),
+                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
+                       "dg_ln_residual_bwd")
+        _account("ln_bwd", 4 * R * N * 3)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dz.matmul(w).view(x.shape)
+        if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
+            dw, db = _wgrad(dz, _c(x).reshape(-1, K), b is not None)
+        return dx, dw, db, dz.view(residual.shape), dgamma, dbeta, None
+
+
+def linear_ln(x, weight, bias, residual, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(residual + x W^T + b) * gamma + beta in one kernel: out_e + ln4 and
+    mlp2.fc2 + ln6 (reference layers.py:127,188,190,192) and their node twins."""
+    if not _fusable(x, weight) or weight.shape[0] != 128 or in_second_order_forward():
+        return _composite_linear_ln(x, weight, bias, residual, gamma, beta, float(eps))
+    return _LinearLN.apply(x, weight, bias, residual, gamma, beta, float(eps))

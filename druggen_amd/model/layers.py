@@ -28,8 +28,16 @@ class MLP(nn.Module):
         self.droprateout = nn.Dropout(dropout)
 
     def forward(self, x):
-        h = F.relu(dgf.linear(x, self.fc1.weight, self.fc1.bias))
+        h = dgf.linear_relu(x, self.fc1.weight, self.fc1.bias)
         return self.droprateout(dgf.linear(h, self.fc2.weight, self.fc2.bias))
+
+    def forward_residual_ln(self, x, ln):
+        """ln(x + self(x)) -- Encoder_Block lines 191-192 of the reference -- with fc2, the
+        residual add and the LayerNorm in one kernel when dropout is inactive."""
+        if self.droprateout.p > 0.0 and self.training:
+            return dgf.ln_residual(x, self.forward(x), ln.weight, ln.bias, ln.eps)
+        h = dgf.linear_relu(x, self.fc1.weight, self.fc1.bias)
+        return dgf.linear_ln(h, self.fc2.weight, self.fc2.bias, x, ln.weight, ln.bias, ln.eps)
 
 
 class MHA(nn.Module):
@@ -53,13 +61,17 @@ class MHA(nn.Module):
         self.out_e = nn.Linear(dim, dim)
         self.out_n = nn.Linear(dim, dim)
 
-    def forward(self, node, edge, need_edge=True):
+    def forward(self, node, edge, need_edge=True, raw=False):
+        """``raw=True`` returns the attention aggregates (o, s) before out_n / out_e so the
+        caller can fuse those projections with its residual + LayerNorm."""
         lin = dgf.linear
         q = lin(node, self.q.weight, self.q.bias)
         k = lin(node, self.k.weight, self.k.bias)
         v = lin(node, self.v.weight, self.v.bias)
         e = lin(edge, self.e.weight, self.e.bias)
         s, o = dgf.attn_core(q, k, v, e, 1.0 / math.sqrt(self.d_k), need_s=need_edge)
+        if raw:
+            return o, s
         node_out = lin(o, self.out_n.weight, self.out_n.bias)
         edge_out = lin(s, self.out_e.weight, self.out_e.bias) if need_edge else None
         return node_out, edge_out
@@ -85,14 +97,16 @@ class Encoder_Block(nn.Module):
         return dgf.ln_residual(a, r, ln.weight, ln.bias, ln.eps)
 
     def forward(self, x, y, need_edge=True):
+        a = self.attn
         x1 = self._ln(self.ln1, x)
-        x2, y1 = self.attn(x1, y, need_edge)
-        x2 = self._ln(self.ln3, x1, x2)
-        x = self._ln(self.ln5, x2, self.mlp(x2))
+        o, s = a(x1, y, need_edge, raw=True)
+        # out_n / out_e projections fused with the residual add and ln3 / ln4
+        x2 = dgf.linear_ln(o, a.out_n.weight, a.out_n.bias, x1, self.ln3.weight, self.ln3.bias, self.ln3.eps)
+        x = self.mlp.forward_residual_ln(x2, self.ln5)
         if not need_edge:
             return x, None
-        y2 = self._ln(self.ln4, y, y1)
-        y = self._ln(self.ln6, y2, self.mlp2(y2))
+        y2 = dgf.linear_ln(s, a.out_e.weight, a.out_e.bias, y, self.ln4.weight, self.ln4.bias, self.ln4.eps)
+        y = self.mlp2.forward_residual_ln(y2, self.ln6)
         return x, y
 
 

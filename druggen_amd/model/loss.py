@@ -16,7 +16,8 @@ def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, 
         eps_edge, eps_node = eps
     int_node = (eps_node * real_node + (1 - eps_node) * fake_node).requires_grad_(True)
     int_edge = (eps_edge * real_edge + (1 - eps_edge) * fake_edge).requires_grad_(True)
-    logits = discriminator(int_edge, int_node)
+    with dgf.second_order_forward():      # this graph is differentiated twice (create_graph below)
+        logits = discriminator(int_edge, int_node)
     with dgf.inputs_only_backward():      # parameter gradients of this pass are never used
         grad_node, grad_edge = torch.autograd.grad(
             outputs=logits, inputs=[int_node, int_edge], grad_outputs=torch.ones_like(logits),

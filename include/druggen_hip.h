@@ -105,12 +105,34 @@ int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
  *   dw[n][k] = sum_r dy[r][n] x[r][k]   (dw: [N,K], nn.Linear layout)
  *   db[n]    = sum_r dy[r][n]           (db may be NULL)
  * dy: [R,N], x: [R,K].  fp32 MFMA, split over the rows, fixed-order reduction.
+ * dy_mask (nullable, [R,N]): use dy * (dy_mask > 0), i.e. the ReLU backward of
+ * MLP.fc1 (layers.py:51) folded into the operand load.
  * Supported (N,K): multiples of 32 from the table in csrc/linear_wgrad.hip
  * (128x128, 384x128, 128x384, 128x64, ...); others return DG_E_SHAPE.             */
 size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K);
-int dg_linear_wgrad(const float* dy, const float* x, float* dw, float* db,
+int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db,
                     void* workspace, size_t workspace_bytes,
                     int64_t R, int N, int K, dg_stream_t stream);
+
+/* ---- fp32-MFMA row GEMM with fused prologue / epilogue -------------------------
+ * The dense layers applied to every edge / node row: MHA projections
+ * (src/model/layers.py:111-116,127,135) and MLP.fc1/fc2 (:50-53), forward and
+ * input-gradient, with the elementwise ops around them folded in:
+ *   y[R,N] = epi( pro(a)[R,K] . B ),  pro(a) = a or a*(a_mask>0),
+ *   epi(v) = LN?( relu?(v + bias) * (out_mask>0)? + residual? )
+ * `packed` is the weight in MFMA fragment order made by dg_row_gemm_pack from the
+ * nn.Linear weight w[rows,cols]: mode 0 -> B[k][n] = w[n][k] (forward, N=rows,
+ * K=cols); mode 1 -> B[k][n] = w[k][n] (input gradient dx = dy.w, N=cols, K=rows).
+ * (K,N) in {(128,128), (128,384), (384,128)}; others DG_E_SHAPE.  LayerNorm epilogue
+ * (gamma != NULL; layers.py:187-192) needs N == 128, writes mean/rstd [R] and,
+ * if pre_ln != NULL, the pre-LayerNorm sum [R,N] that its backward needs.         */
+size_t dg_row_gemm_packed_floats(int n_out, int k_contract);
+int dg_row_gemm_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
+int dg_row_gemm(const float* a, const float* a_mask, const float* packed, float* y,
+                int64_t R, int K, int N,
+                const float* bias, int relu, const float* out_mask, const float* residual,
+                const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
+                float eps, dg_stream_t stream);
 
 /* ---- opt-in kernel timing with HIP events (bench.py roofline) ----------------
  * When enabled, every launch of a profiled kernel is bracketed by two events on
@@ -124,6 +146,7 @@ enum {
     DG_K_LN_BWD = 4,
     DG_K_LN_BWD2 = 5,
     DG_K_LINEAR_WGRAD = 6,
+    DG_K_ROW_GEMM = 7,
     DG_K_COUNT = 16
 };
 int dg_prof_enable(int on);
