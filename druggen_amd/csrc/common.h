@@ -54,6 +54,32 @@ __device__ __forceinline__ void st4_stream(float* p, float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
 }
 
+// ---- async global -> LDS copy (LDS-DMA), 16 bytes per lane ----------------------------------
+// LDS destination = `lds_base` (wave-uniform byte address) + lane*16; global source is per lane.
+// Issued through inline asm on purpose: hipcc orders a builtin LDS-DMA before every later
+// ds_read with `s_waitcnt vmcnt(0)`, which would serialise the copy of tile t+1 with the compute
+// on tile t.  The caller owns the wait: `s_waitcnt vmcnt(0)` + barrier before reading the tile.
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+    return static_cast<unsigned>(reinterpret_cast<size_t>((const __attribute__((address_space(3))) void*)p));
+}
+__device__ __forceinline__ void dma16_async(const float* gsrc, unsigned lds_base) {
+    unsigned keep;
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(base)
+        : "memory");
+}
+__device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Same wait through the builtin, so that hipcc's own scoreboard also learns that its earlier
+// loads have returned (0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched on gfx9 encodings).
+__device__ __forceinline__ void wait_all_vmem_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // butterfly over the lanes that differ in bits >= LOW of the lane id
 template <int LOW>
 __device__ __forceinline__ float xor_sum(float x) {

@@ -21,21 +21,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void dma16(const float* g, float* l) {
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
-
 // Copy `rows` x W floats (contiguous in global memory starting at g) into LDS at l.
 // Rows >= valid_rows are skipped (their LDS bytes must have been zeroed before).
 template <int THREADS>
 __device__ __forceinline__ void stage_tile(const float* g, float* l, int W, int rows, int valid_rows) {
     const int chunks = rows * W / 4;          // 16-byte chunks
     const int valid = valid_rows * W / 4;
+    const unsigned base = lds_byte_address(l);
     for (int c = threadIdx.x; c < chunks; c += THREADS) {
         // the LDS destination of the DMA is (wave-uniform base) + lane*16: c is lane-linear per wave
-        if (c < valid) dma16(g + static_cast<size_t>(c) * 4, l + (c - (threadIdx.x & 63)) * 4);
+        if (c < valid) dma16_async(g + static_cast<size_t>(c) * 4, base + (c - (threadIdx.x & 63)) * 16);
     }
 }
 
@@ -88,7 +83,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
     if (t_lo < t_hi) issue(t_lo, 0);
     for (int64_t t = t_lo; t < t_hi; ++t) {
         const int buf = static_cast<int>((t - t_lo) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_all_vmem();
         __syncthreads();                       // tile t landed for every wave; tile t-1 fully consumed
         if (t + 1 < t_hi) issue(t + 1, buf ^ 1);
         const float* ldy = lds + buf * BUF;

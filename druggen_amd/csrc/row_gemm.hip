@@ -77,121 +77,170 @@ __device__ __forceinline__ float half_sum(float x) {
     return x;
 }
 
-// KC = K/128 contraction chunks, NC = N/128 output chunks; at most one of them > 1.
-template <int KC, int NC>
-__global__ __launch_bounds__(256, 2) void row_gemm_kernel(const float* __restrict__ a, const float* __restrict__ amask,
-                                                      const float* __restrict__ packed, float* __restrict__ y,
-                                                      int64_t R, Epilogue ep) {
-    constexpr int K = KC * 128, N = NC * 128;
-    static_assert(KC == 1 || NC == 1, "one of the two dimensions must be a single chunk");
-    __shared__ __attribute__((aligned(16))) float tile[kTR * kPitch];
+// Persistent row-GEMM workgroup.
+//   KC  = K/128 contraction chunks (B fragments for all of them stay in VGPRs for the whole kernel)
+//   NG  = N/128 output chunks, one 4-wave group each (all groups share the A tile)
+//   TR  = rows per tile (32 or 64)
+//   EXCH = epilogue through an LDS exchange tile (row-wise float4 residual loads / stores,
+//          optional LayerNorm; NG == 1); otherwise direct stores from the accumulator layout
+// A tiles arrive by LDS-DMA into a double buffer; the LDS image is the global image with the
+// 16-byte chunk index XOR-ed by (row & 15) inside every 512-byte segment (applied on the per-lane
+// SOURCE address, the DMA destination is lane-linear), which makes the ds_read_b128 fragment
+// reads bank-conflict free without padding.
+template <int KC, int NG, int TR, bool EXCH>
+__global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restrict__ a,
+                                                           const float* __restrict__ packed,
+                                                           float* __restrict__ y, int64_t R, Epilogue ep) {
+    constexpr int K = KC * 128, N = NG * 128, MT = TR / 32, WAVES = NG * 4;
+    constexpr int SLOTS = TR * K / 4;            // 16-byte slots per tile
+    static_assert(!EXCH || NG == 1, "exchange epilogue needs the whole row in one group");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);   // [2][TR*K]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = w >> 2, wq = w & 3;
     const int half = lane >> 5, col = lane & 31;
-    const int64_t tiles = (R + kTR - 1) / kTR;
+    const int64_t tiles = (R + TR - 1) / TR;
 
-    for (int64_t tix = blockIdx.x; tix < tiles; tix += gridDim.x) {
-        const int64_t r0 = tix * kTR;
-        f32x16 acc[2];
-#pragma unroll 1
-        for (int nc = 0; nc < NC; ++nc) {
+    float4 bf[KC][16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-#pragma unroll 1
-            for (int kc = 0; kc < KC; ++kc) {
-                // B fragments for (n tile 4nc+w, k chunk kc): 16 coalesced float4 per lane
-                float4 bf[16];
-                const float* pb = packed + (static_cast<size_t>((4 * nc + w) * KC + kc) * 16) * 64 * 4 + lane * 4;
+    for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) bf[q] = ld4(pb + q * 256);
-                if (nc == 0 || KC > 1) {
-                    // stage A[r0 .. r0+64, 128kc .. 128kc+128) -> LDS (pitch 132), prologue applied
-                    __syncthreads();   // previous users of `tile` are done
+        for (int q = 0; q < 16; ++q)
+            bf[kc][q] = ld4(packed + (static_cast<size_t>((4 * g + wq) * KC + kc) * 16 + q) * 256 + lane * 4);
+
+    auto dma_tile = [&](int64_t tile, int buf) {
+        const int64_t r0 = tile * TR;
+        const unsigned dst = lds_byte_address(lds + buf * (TR * K));
+        for (int ii = w; ii < SLOTS / 64; ii += WAVES) {
+            const int L = ii * 64 + lane;
+            const int row = L / (K / 4), cs = L % (K / 4);
+            const int src = (cs & ~31) | ((cs & 31) ^ (row & 15));
+            if (r0 + row < R) dma16_async(a + (r0 + row) * K + src * 4, dst + ii * 1024);
+        }
+    };
+
+    int64_t tix = blockIdx.x;
+    const int n = 128 * g + 32 * wq + col;
+    const float bias = ep.bias ? ep.bias[n] : 0.f;
+    wait_all_vmem_visible();   // B fragments and bias are in registers (and the compiler knows it)
+    if (tix < tiles) dma_tile(tix, 0);
+    wait_all_vmem();
+    __syncthreads();
+    int buf = 0;
+    for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
+        const int64_t r0 = tix * TR;
+        if (tix + gridDim.x < tiles) dma_tile(tix + gridDim.x, buf ^ 1);
+        const float* at = lds + buf * (TR * K);
+        f32x16 acc[MT];
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int chunk = it * 256 + threadIdx.x;   // 2048 float4 per tile
-                        const int rr = chunk >> 5, cc = (chunk & 31) * 4;
-                        const int64_t row = r0 + rr;
-                        float4 v = f4(0.f);
-                        if (row < R) {
-                            v = ld4(a + row * K + 128 * kc + cc);
-                            if (amask) {
-                                const float4 mk = ld4(amask + row * K + 128 * kc + cc);
-                                v.x = mk.x > 0.f ? v.x : 0.f;
-                                v.y = mk.y > 0.f ? v.y : 0.f;
-                                v.z = mk.z > 0.f ? v.z : 0.f;
-                                v.w = mk.w > 0.f ? v.w : 0.f;
-                            }
-                        }
-                        st4(tile + rr * kPitch + cc, v);
-                    }
-                    __syncthreads();
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        // A fragments are software-pipelined one step ahead of the MFMAs that consume them
+        float4 nxt[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) nxt[m] = ld4(at + (32 * m + col) * K + (((16 * half) ^ (col & 15)) << 2));
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float4 af[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = nxt[m];
+                if (kc * 16 + q + 1 < KC * 16) {
+                    const int kc2 = (kc * 16 + q + 1) / 16, q2 = (kc * 16 + q + 1) % 16;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        nxt[m] = ld4(at + (32 * m + col) * K + kc2 * 128 + (((16 * half + q2) ^ (col & 15)) << 2));
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float4 a0 = ld4(tile + col * kPitch + 64 * half + 4 * q);
-                    const float4 a1 = ld4(tile + (32 + col) * kPitch + 64 * half + 4 * q);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf[q].x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf[q].x, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf[q].y, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf[q].y, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf[q].z, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf[q].z, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf[q].w, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf[q].w, acc[1], 0, 0, 0);
-                }
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[kc][q].x, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[kc][q].y, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[kc][q].z, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[kc][q].w, acc[m], 0, 0, 0);
             }
-            // ---- epilogue for output chunk nc: this lane holds column n, 2 x 16 rows
-            const int n = 128 * nc + 32 * w + col;
-            const float bias = ep.bias ? ep.bias[n] : 0.f;
-            if (ep.gamma == nullptr) {
+        // the next tile's DMA had the whole MFMA phase to land; wait for it BEFORE issuing this
+        // tile's stores so the wait never covers them (vmcnt retires in order and counts stores)
+        wait_all_vmem();
+        if (!EXCH) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m) {
+                constexpr int MB = NG > 1 ? 8 : 16;   // mask loads batched per MB rows (register budget)
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int64_t row = r0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                        if (row < R) {
-                            float v = acc[m][reg] + bias;
-                            if (ep.relu) v = fmaxf(v, 0.f);
-                            if (ep.mask) v = ep.mask[row * N + n] > 0.f ? v : 0.f;
-                            if (ep.residual) v += ep.residual[row * N + n];
-                            y[row * N + n] = v;
+                for (int r8 = 0; r8 < 16; r8 += MB) {
+                    float mk[MB];
+                    if (ep.mask) {
+#pragma unroll
+                        for (int i = 0; i < MB; ++i) {
+                            const int reg = r8 + i;
+                            int64_t row = r0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            if (row >= R) row = R - 1;
+                            mk[i] = ep.mask[row * N + n];
                         }
                     }
-            } else {
-                // LayerNorm epilogue (N == 128): exchange through LDS, then whole rows per half-wave
-                __syncthreads();   // every wave finished reading A fragments from `tile`
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    for (int i = 0; i < MB; ++i) {
+                        const int reg = r8 + i;
+                        const int64_t row = r0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
                         float v = acc[m][reg] + bias;
                         if (ep.relu) v = fmaxf(v, 0.f);
-                        tile[rr * kPitch + 32 * w + col] = v;
-                    }
-                __syncthreads();
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int rr = w * 16 + it * 2 + half;       // wave w: rows 16w .. 16w+15
-                    const int64_t row = r0 + rr;
-                    const bool ok = row < R;
-                    float4 v = ld4(tile + rr * kPitch + col * 4);
-                    if (ep.residual && ok) v += ld4(ep.residual + row * N + col * 4);
-                    if (ep.pre && ok) st4(ep.pre + row * N + col * 4, v);
-                    const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
-                    const float4 d = v - f4(mu);
-                    const float var = half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
-                    const float rs = rsqrtf(var + ep.eps);
-                    if (ok) {
-                        st4(y + row * N + col * 4, fma4(rs * d, ld4(ep.gamma + col * 4), ld4(ep.beta + col * 4)));
-                        if (col == 0) {
-                            ep.mean[row] = mu;
-                            ep.rstd[row] = rs;
-                        }
+                        if (ep.mask) v = mk[i] > 0.f ? v : 0.f;
+                        if (row < R) y[row * N + n] = v;
                     }
                 }
             }
+            __syncthreads();   // every wave: DMA(t+1) landed, tile t fully read
+        } else {
+            float* ex = lds + buf * (TR * K);   // consumed A buffer becomes the [TR][128] exchange tile
+            __syncthreads();                    // all waves finished their fragment reads
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    float v = acc[m][reg] + bias;
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    ex[rr * 128 + 32 * wq + col] = v;
+                }
+            __syncthreads();
+            float4 res[TR / 8];
+            if (ep.residual) {
+#pragma unroll
+                for (int it = 0; it < TR / 8; ++it) {
+                    int64_t row = r0 + wq * (TR / 4) + it * 2 + half;
+                    if (row >= R) row = R - 1;
+                    res[it] = ld4(ep.residual + row * N + col * 4);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < TR / 8; ++it) {
+                const int rr = wq * (TR / 4) + it * 2 + half;
+                const int64_t row = r0 + rr;
+                const bool ok = row < R;
+                float4 v = ld4(ex + rr * 128 + col * 4);
+                if (ep.residual) v += res[it];
+                if (ep.gamma == nullptr) {
+                    if (ok) st4(y + row * N + col * 4, v);
+                    continue;
+                }
+                if (ep.pre && ok) st4(ep.pre + row * N + col * 4, v);
+                const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+                const float4 d = v - f4(mu);
+                const float var = half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+                const float rs = rsqrtf(var + ep.eps);
+                if (ok) {
+                    st4(y + row * N + col * 4, fma4(rs * d, ld4(ep.gamma + col * 4), ld4(ep.beta + col * 4)));
+                    if (col == 0) {
+                        ep.mean[row] = mu;
+                        ep.rstd[row] = rs;
+                    }
+                }
+            }
+            __syncthreads();   // exchange tile consumed before the next DMA overwrites it
         }
     }
 }
@@ -223,23 +272,37 @@ extern "C" int dg_row_gemm(const float* a, const float* a_mask, const float* pac
                            const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                            float eps, dg_stream_t stream_) {
     if (!a || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm: null pointer");
+    if (a_mask) return fail(DG_E_ARG, "dg_row_gemm: a_mask is not supported (mask in the producer's epilogue)");
     if (R < 0 || !((K == 128 && (N == 128 || N == 384)) || (K == 384 && N == 128)))
         return fail(DG_E_SHAPE, "dg_row_gemm: unsupported K=%d N=%d (supported: 128x128, 128x384, 384x128)", K, N);
-    if (gamma && (N != 128 || !beta || !mean || !rstd || out_mask))
-        return fail(DG_E_ARG, "dg_row_gemm: LayerNorm epilogue needs N == 128, beta, mean, rstd and no output mask");
+    if (gamma && (N != 128 || !beta || !mean || !rstd))
+        return fail(DG_E_ARG, "dg_row_gemm: LayerNorm epilogue needs N == 128, beta, mean and rstd");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Epilogue ep{bias, out_mask, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
-    const int64_t tiles = (R + kTR - 1) / kTR;
-    const int grid = static_cast<int>(tiles < 2048 ? tiles : 2048);
     ProfScope prof(DG_K_ROW_GEMM, stream);
-    const int kc = K / 128, nc = N / 128;
-#define LAUNCH(KC_, NC_)          \
-    if (kc == KC_ && nc == NC_)   \
-        hipLaunchKernelGGL((row_gemm_kernel<KC_, NC_>), dim3(grid), dim3(256), 0, stream, a, a_mask, packed, y, R, ep);
-    LAUNCH(1, 1)
-    LAUNCH(1, 3)
-    LAUNCH(3, 1)
+#define LAUNCH(KC_, NG_, TR_, LN_, PER_CU_)                                                                       \
+    {                                                                                                             \
+        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4;                                                        \
+        static const hipError_t attr =                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, TR_, LN_>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                           \
+        (void)attr;                                                                                               \
+        const int64_t tiles = (R + TR_ - 1) / TR_;                                                                \
+        const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                         \
+        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, TR_, LN_>), dim3(grid), dim3(NG_ * 256), lds_bytes, stream, \
+                           a, packed, y, R, ep);                                                                  \
+    }
+    const bool exch = gamma || residual;
+    if (exch && out_mask) return fail(DG_E_ARG, "dg_row_gemm: out_mask cannot be combined with residual / LayerNorm");
+    if (K == 128 && N == 128) {
+        if (exch) LAUNCH(1, 1, 64, true, 2) else LAUNCH(1, 1, 64, false, 2)
+    } else if (K == 128 && N == 384) {
+        if (exch) return fail(DG_E_ARG, "dg_row_gemm: residual / LayerNorm epilogues need N == 128");
+        LAUNCH(1, 3, 64, false, 1)
+    } else {
+        LAUNCH(3, 1, 32, true, 1)
+    }
 #undef LAUNCH
     return check_launch("dg_row_gemm");
 }

@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "inputs_only_backward",
+__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
@@ -419,10 +419,13 @@ def _double_backward_fallback(composite, inputs, grad_out):
     """Backward of a fused op when the caller asked for create_graph=True: rebuild the
     op from twice-differentiable pieces on the original (graph-attached) inputs."""
     with torch.enable_grad():
-        out = composite(*inputs)
-        need = [t for t in inputs if isinstance(t, torch.Tensor) and t.requires_grad]
+        # aliases: one input may be upstream of another (x feeds fc1 AND is the residual); the
+        # gradient must stop at each input, the outer engine continues from there
+        alias = [t.view_as(t) if isinstance(t, torch.Tensor) and t.requires_grad else t for t in inputs]
+        out = composite(*alias)
+        need = [t for t in alias if isinstance(t, torch.Tensor) and t.requires_grad]
         grads = iter(torch.autograd.grad(out, need, grad_out, create_graph=True, allow_unused=True))
-    return tuple(next(grads) if (isinstance(t, torch.Tensor) and t.requires_grad) else None for t in inputs)
+    return tuple(next(grads) if (isinstance(t, torch.Tensor) and t.requires_grad) else None for t in alias)
 
 
 def _fusable(x, w):
@@ -430,41 +433,80 @@ def _fusable(x, w):
     return x.is_cuda and x.dtype == torch.float32 and row_gemm_supported(K, N)
 
 
-def _composite_linear_relu(x, w, b):
-    return torch.relu(linear(x, w, b))
+def _ln_bwd_rows(pre, gamma, mean, rstd, dy2):
+    """LayerNorm backward over rows of the saved pre-LN sum -> (dz, dgamma, dbeta)."""
+    R, N = pre.shape
+    lib = _lib.load()
+    dz = torch.empty_like(pre)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    with _dev(pre):
+        ws, _ = _workspace(pre, R, N)
+        _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean), _lib.ptr(rstd),
+                                          _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                          ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
+                   "dg_ln_residual_bwd")
+    _account("ln_bwd", 4 * R * N * 3)
+    return dz, dgamma, dbeta
 
 
-class _LinearReLU(Function):
+def _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps):
+    return ln_residual(x, linear(torch.relu(linear(x, w1, b1)), w2, b2), gamma, beta, eps)
+
+
+class _FFNLN(Function):
+    """LN(x + fc2(relu(fc1 x))) -- MLP + residual + LayerNorm of Encoder_Block (reference
+    layers.py:50-53,191-192).  Forward: two row-GEMM launches (bias+ReLU epilogue; bias +
+    residual + LayerNorm epilogue).  Backward: LN backward, then the fc2 input gradient with the
+    ReLU mask applied in its epilogue, the fc1 input gradient with the residual gradient added in
+    its epilogue, and the two weight gradients on the split-K kernel."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
-        N, K = w.shape
-        x2 = _c(x).reshape(-1, K)
-        h = row_gemm(x2, packed_weight(w, 0), K, N, bias=b, relu=True)
-        ctx.save_for_backward(x, w, b, h)
-        return h.view(*x.shape[:-1], N)
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+        H, C = w1.shape
+        x2 = _c(x).reshape(-1, C)
+        h = row_gemm(x2, packed_weight(w1, 0), C, H, bias=b1, relu=True)
+        y, mean, rstd, pre = row_gemm(h, packed_weight(w2, 0), H, C, bias=b2, residual=x2,
+                                      ln=(_c(gamma), _c(beta), eps), want_pre=True)
+        ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre)
+        ctx.eps = eps
+        return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, b, h = ctx.saved_tensors
+        x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre = ctx.saved_tensors
         if torch.is_grad_enabled():
-            return _double_backward_fallback(_composite_linear_relu, (x, w, b), dy)
-        N, K = w.shape
-        dy2 = _c(dy).reshape(-1, N)
-        dx = dw = db = None
+            eps = ctx.eps
+            g = _double_backward_fallback(lambda *t: _composite_ffn_ln(*t, eps),
+                                          (x, w1, b1, w2, b2, gamma, beta), dy)
+            return g + (None,)
+        H, C = w1.shape
+        dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy).reshape(-1, C))
+        # dh = (dz @ W2) * (h > 0): ReLU backward in the epilogue
+        dh = row_gemm(dz, packed_weight(w2, 1), C, H, out_mask=h)
+        dx = None
         if ctx.needs_input_grad[0]:
-            # dx = (dy * (h > 0)) @ W : contraction over N, ReLU mask folded into the operand load
-            dx = row_gemm(dy2, packed_weight(w, 1), N, K, a_mask=h).view(x.shape)
+            dx = row_gemm(dh, packed_weight(w1, 1), H, C, residual=dz).view(x.shape)   # + residual path
+        dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
-            dw, db = _wgrad(dy2, _c(x).reshape(-1, K), b is not None, dy_mask=h)
-        return dx, dw, db
+            dw2, db2 = _wgrad(dz, h, True)
+            dw1, db1 = _wgrad(dh, _c(x).reshape(-1, C), True)
+        return dx, dw1, db1, dw2, db2, dgamma, dbeta, None
+
+
+def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(x + fc2(relu(fc1(x)))) with everything elementwise fused into the GEMM
+    epilogues (dim 128, hidden 384); other shapes / second-order graphs use the composite."""
+    H, C = w1.shape
+    ok = (x.is_cuda and x.dtype == torch.float32 and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
+          and b1 is not None and b2 is not None)
+    if not ok or in_second_order_forward():
+        return _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, float(eps))
+    return _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
 
 
 def linear_relu(x, weight, bias):
-    """relu(x W^T + b) -- MLP.fc1 + act (reference layers.py:50-51) in one kernel; the
-    backward folds the ReLU mask into the dgrad / wgrad operand loads."""
-    if not _fusable(x, weight) or in_second_order_forward():
-        return _composite_linear_relu(x, weight, bias)
-    return _LinearReLU.apply(x, weight, bias)
+    """relu(x W^T + b) (reference layers.py:50-51)."""
+    return torch.relu(linear(x, weight, bias))
 
 
 def _composite_linear_ln(x, w, b, residual, gamma, beta, eps):
@@ -492,21 +534,10 @@ class _LinearLN(Function):
                                           (x, w, b, residual, gamma, beta), dy)
             return g + (None,)
         N, K = w.shape
-        R = pre.shape[0]
-        lib = _lib.load()
-        dy2 = _c(dy).reshape(-1, N)
-        dz = torch.empty_like(pre)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        with _dev(pre):
-            ws, _ = _workspace(pre, R, N)
-            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean),
-                                              _lib.ptr(rstd), _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dgamma),
-                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
-                       "dg_ln_residual_bwd")
-        _account("ln_bwd", 4 * R * N * 3)
+        dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy).reshape(-1, N))
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = dz.matmul(w).view(x.shape)
+            dx = row_gemm(dz, packed_weight(w, 1), N, K).view(x.shape)
         if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
             dw, db = _wgrad(dz, _c(x).reshape(-1, K), b is not None)
         return dx, dw, db, dz.view(residual.shape), dgamma, dbeta, None
@@ -515,6 +546,6 @@ class _LinearLN(Function):
 def linear_ln(x, weight, bias, residual, gamma, beta, eps: float = 1e-5):
     """LayerNorm(residual + x W^T + b) * gamma + beta in one kernel: out_e + ln4 and
     mlp2.fc2 + ln6 (reference layers.py:127,188,190,192) and their node twins."""
-    if not _fusable(x, weight) or weight.shape[0] != 128 or in_second_order_forward():
+    if not _fusable(x, weight) or tuple(weight.shape) != (128, 128) or bias is None or in_second_order_forward():
         return _composite_linear_ln(x, weight, bias, residual, gamma, beta, float(eps))
     return _LinearLN.apply(x, weight, bias, residual, gamma, beta, float(eps))

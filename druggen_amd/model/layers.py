@@ -36,8 +36,8 @@ class MLP(nn.Module):
         residual add and the LayerNorm in one kernel when dropout is inactive."""
         if self.droprateout.p > 0.0 and self.training:
             return dgf.ln_residual(x, self.forward(x), ln.weight, ln.bias, ln.eps)
-        h = dgf.linear_relu(x, self.fc1.weight, self.fc1.bias)
-        return dgf.linear_ln(h, self.fc2.weight, self.fc2.bias, x, ln.weight, ln.bias, ln.eps)
+        return dgf.ffn_ln(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                          ln.weight, ln.bias, ln.eps)
 
 
 class MHA(nn.Module):

@@ -82,6 +82,9 @@ def gemm():
         t_lib = timeit(lambda: torch.nn.functional.linear(a, w, b))
         fl = 2.0 * R * N * K
         print(f"row_gemm fwd K={K} N={N}: mine {t_mine:8.1f} us ({fl / t_mine / 1e6:6.1f} TF) | F.linear {t_lib:8.1f} us ({fl / t_lib / 1e6:6.1f} TF)")
+        pwt = dgf.packed_weight(torch.randn(K, N, device="cuda") * 0.05, 1)
+        t_d = timeit(lambda: dgf.row_gemm(a, pwt, K, N))
+        print(f"   dgrad-mode (same shape): mine {t_d:8.1f} us ({fl / t_d / 1e6:6.1f} TF)")
         if N == 384:
             t_mine = timeit(lambda: dgf.row_gemm(a, pw, K, N, bias=b, relu=True))
             t_lib = timeit(lambda: torch.relu(torch.nn.functional.linear(a, w, b)))

@@ -249,25 +249,36 @@ def test_row_gemm_forward_and_dgrad_modes(R, K, N):
     assert _rel(y, a @ w2) < TOL
 
 
-@pytest.mark.parametrize("R", [5, 64, 1000])
-def test_row_gemm_fused_prologue_epilogues(R):
+@pytest.mark.parametrize("R", [5, 64, 1000, 2025 * 7])
+def test_row_gemm_fused_epilogues(R):
     from druggen_amd import functional as dgf
-    K, N = 384, 128
-    a, am = _gen((R, K), 1), _gen((R, K), 2)
-    w, b, res = _gen((N, K), 3) * 0.1, _gen((N,), 4), _gen((R, N), 5)
-    gamma, beta = 1 + 0.1 * _gen((N,), 6), _gen((N,), 7)
-    om = _gen((R, N), 8)
     f = lambda t: t.float().cuda()
+    # 384 -> 128 with bias + residual + LayerNorm (fc2 + ln6) and with residual only (fc1 dgrad)
+    K, N = 384, 128
+    a, w, b, res = _gen((R, K), 1), _gen((N, K), 3) * 0.1, _gen((N,), 4), _gen((R, N), 5)
+    gamma, beta = 1 + 0.1 * _gen((N,), 6), _gen((N,), 7)
     pw = dgf.packed_weight(f(w), 0)
-    want = (a * (am > 0)) @ w.t() + b
-    y = dgf.row_gemm(f(a), pw, K, N, bias=f(b), a_mask=f(am))
-    assert _rel(y, want) < TOL
-    y = dgf.row_gemm(f(a), pw, K, N, bias=f(b), a_mask=f(am), out_mask=f(om), residual=f(res))
-    assert _rel(y, want * (om > 0) + res) < TOL
-    y, mean, rstd = dgf.row_gemm(f(a), pw, K, N, bias=f(b), residual=f(res), ln=(f(gamma), f(beta), 1e-5))
+    y = dgf.row_gemm(f(a), pw, K, N, residual=f(res))
+    assert _rel(y, a @ w.t() + res) < TOL
+    y, mean, rstd, pre = dgf.row_gemm(f(a), pw, K, N, bias=f(b), residual=f(res), ln=(f(gamma), f(beta), 1e-5),
+                                      want_pre=True)
     z = a @ w.t() + b + res
     y_ref, mu_ref, rs_ref = km.ln_fwd(z, gamma, beta)
+    assert _rel(pre, z) < TOL
     assert _rel(y, y_ref) < TOL and _rel(mean, mu_ref.squeeze(-1)) < TOL and _rel(rstd, rs_ref.squeeze(-1)) < TOL
+    # 128 -> 384 with bias + ReLU (fc1) and with an output mask (fc2 dgrad + ReLU backward)
+    K, N = 128, 384
+    a, w, b, om = _gen((R, K), 11), _gen((N, K), 12) * 0.1, _gen((N,), 13), _gen((R, N), 14)
+    pw = dgf.packed_weight(f(w), 0)
+    assert _rel(dgf.row_gemm(f(a), pw, K, N, bias=f(b), relu=True), torch.relu(a @ w.t() + b)) < TOL
+    assert _rel(dgf.row_gemm(f(a), pw, K, N, out_mask=f(om)), (a @ w.t()) * (om > 0)) < TOL
+    # 128 -> 128 with bias + residual + LayerNorm (out_e + ln4)
+    K, N = 128, 128
+    a, w, b, res = _gen((R, K), 21), _gen((N, K), 22) * 0.1, _gen((N,), 23), _gen((R, N), 24)
+    y, mean, rstd = dgf.row_gemm(f(a), dgf.packed_weight(f(w), 0), K, N, bias=f(b), residual=f(res),
+                                 ln=(f(gamma), f(beta), 1e-5))
+    y_ref, _, _ = km.ln_fwd(a @ w.t() + b + res, gamma, beta)
+    assert _rel(y, y_ref) < TOL
 
 
 def test_packed_weight_cache_tracks_inplace_updates():
@@ -281,7 +292,7 @@ def test_packed_weight_cache_tracks_inplace_updates():
 
 
 @pytest.mark.parametrize("shape", [(2, 9, 9), (3, 50), (1, 45, 45)])
-def test_fused_linear_relu_and_linear_ln_match_composite_all_orders(shape):
+def test_fused_ffn_ln_matches_composite_all_orders(shape):
     """dgf.linear_relu / dgf.linear_ln (first-order fast path and the create_graph
     fallback) against plain torch ops."""
     import torch.nn.functional as F
@@ -297,7 +308,7 @@ def test_fused_linear_relu_and_linear_ln_match_composite_all_orders(shape):
     params = [x, w1, b1, w2, b2, gamma, beta]
 
     def fused():
-        return dgf.linear_ln(dgf.linear_relu(x, w1, b1), w2, b2, x, gamma, beta, 1e-5)
+        return dgf.ffn_ln(x, w1, b1, w2, b2, gamma, beta, 1e-5)
 
     def plain():
         return F.layer_norm(x + F.linear(torch.relu(F.linear(x, w1, b1)), w2, b2), (C,), gamma, beta, 1e-5)
@@ -322,3 +333,26 @@ def test_fused_linear_relu_and_linear_ln_match_composite_all_orders(shape):
     s_c = torch.autograd.grad((gx_c * tx).sum(), [w1, w2, gamma])
     for a, b in zip(s_c, s_p):
         assert _rel(a, b.double().cpu()) < 5 * TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 9), (7, 45)])
+def test_fused_linear_ln_matches_composite_all_orders(shape):
+    import torch.nn.functional as F
+    from druggen_amd import functional as dgf
+    C = 128
+    f = lambda t: t.float().cuda().requires_grad_(True)
+    x, res = f(_gen(shape + (C,), 1)), f(_gen(shape + (C,), 2))
+    w, b = f(_gen((C, C), 3) * 0.1), f(_gen((C,), 4))
+    gamma, beta = f(1 + 0.1 * _gen((C,), 6)), f(_gen((C,), 7))
+    dy, tx = _gen(shape + (C,), 8).float().cuda(), _gen(shape + (C,), 9).float().cuda()
+    params = [x, res, w, b, gamma, beta]
+    fused = lambda: dgf.linear_ln(x, w, b, res, gamma, beta, 1e-5)
+    plain = lambda: F.layer_norm(res + F.linear(x, w, b), (C,), gamma, beta, 1e-5)
+    assert _rel(fused(), plain().double().cpu()) < TOL
+    for a_, b_ in zip(torch.autograd.grad(fused(), params, dy), torch.autograd.grad(plain(), params, dy)):
+        assert _rel(a_, b_.double().cpu()) < 5 * TOL
+    gf = torch.autograd.grad(fused(), x, dy, create_graph=True)[0]
+    gp = torch.autograd.grad(plain(), x, dy, create_graph=True)[0]
+    for a_, b_ in zip(torch.autograd.grad((gf * tx).sum(), [w, gamma, res]),
+                      torch.autograd.grad((gp * tx).sum(), [w, gamma, res])):
+        assert _rel(a_, b_.double().cpu()) < 5 * TOL
