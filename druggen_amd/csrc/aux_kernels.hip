@@ -1,0 +1,138 @@
+// The steps either side of the GAN-step hot path:
+//   * batch densify  -- reference src/data/utils.py:128-137 (PyG to_dense_adj + label2onehot)
+//   * AdamW update   -- reference train.py:213-214,368,384 (torch.optim.AdamW defaults)
+//   * argmax decode  -- reference inference.py:197-198 (torch.max(.., -1)[1])
+// All HBM/latency-bound byte and elementwise work: one coalesced pass each.
+#include "common.h"
+
+namespace dg {
+namespace {
+
+// ---- densify --------------------------------------------------------------------------------
+// labels[b,i,j] += attr for every COO edge (u -> v), b = u / N, i = u % N, j = v % N: the reference
+// pads every graph to N = max_num_nodes nodes (utils.py:133), to_dense_adj scatter-ADDs duplicates.
+__global__ void densify_scatter_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                       const int64_t* __restrict__ attr, int64_t n_edges, int B, int N,
+                                       int* __restrict__ labels) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t u = src[e], v = dst[e];
+    const int64_t b = u / N;
+    if (b < 0 || b >= B || v / N != b) return;   // an edge never leaves its graph
+    atomicAdd(labels + (b * N + u % N) * N + v % N, static_cast<int>(attr[e]));
+}
+
+// one-hot expand: a[r, c] = (labels[r] == c); labels outside [0, E) give an all-zero row, which is
+// what scatter_ on an out-of-range index would refuse -- reported through `bad`.
+__global__ void onehot_kernel(const int* __restrict__ labels, int64_t rows, int E, float* __restrict__ a,
+                              int* __restrict__ bad) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= rows * E) return;
+    const int64_t r = idx / E;
+    const int c = static_cast<int>(idx - r * E);
+    const int lab = labels[r];
+    if (c == 0 && (lab < 0 || lab >= E)) atomicAdd(bad, 1);
+    a[idx] = lab == c ? 1.0f : 0.0f;
+}
+
+// ---- AdamW over a flat buffer ---------------------------------------------------------------
+// torch.optim.AdamW single-tensor formulas: p *= 1 - lr*wd;  m = b1 m + (1-b1) g;
+// v = b2 v + (1-b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float bc1, float bc2_sqrt) {
+    const int64_t i4 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const float step = lr / bc1;
+    if (i4 + 3 < n) {
+        float4 pp = ld4(p + i4), gg = ld4(g + i4), mm = ld4(m + i4), vv = ld4(v + i4);
+        float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pe[k] *= 1.0f - lr * weight_decay;
+            me[k] = beta1 * me[k] + (1.0f - beta1) * ge[k];
+            ve[k] = beta2 * ve[k] + (1.0f - beta2) * ge[k] * ge[k];
+            pe[k] -= step * me[k] / (sqrtf(ve[k]) / bc2_sqrt + eps);
+        }
+        st4(p + i4, pp);
+        st4(m + i4, mm);
+        st4(v + i4, vv);
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            float pp = p[i] * (1.0f - lr * weight_decay);
+            const float gg = g[i];
+            const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
+            const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+            pp -= step * mm / (sqrtf(vv) / bc2_sqrt + eps);
+            p[i] = pp;
+            m[i] = mm;
+            v[i] = vv;
+        }
+    }
+}
+
+// ---- argmax decode --------------------------------------------------------------------------
+// out[r] = index of the first maximum of logits[r, 0..E) (NaN counts as maximal, like torch.max)
+__global__ void argmax_kernel(const float* __restrict__ logits, int64_t rows, int E, unsigned char* __restrict__ out) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* x = logits + r * E;
+    float best = x[0];
+    int arg = 0;
+    for (int c = 1; c < E; ++c) {
+        const float v = x[c];
+        if (v > best || (v != v && best == best)) {
+            best = v;
+            arg = c;
+        }
+    }
+    out[r] = static_cast<unsigned char>(arg);
+}
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" int dg_densify(const int64_t* edge_src, const int64_t* edge_dst, const int64_t* edge_attr, int64_t n_edges,
+                          int B, int N, int E, int* labels, float* a, int* bad_count, dg_stream_t stream_) {
+    if ((n_edges > 0 && (!edge_src || !edge_dst || !edge_attr)) || !labels || !a || !bad_count)
+        return fail(DG_E_ARG, "dg_densify: null pointer");
+    if (B < 0 || N < 1 || E < 1 || n_edges < 0) return fail(DG_E_SHAPE, "dg_densify: bad sizes");
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t rows = static_cast<int64_t>(B) * N * N;
+    hipError_t err = hipMemsetAsync(labels, 0, rows * sizeof(int), stream);
+    if (err == hipSuccess) err = hipMemsetAsync(bad_count, 0, sizeof(int), stream);
+    if (err != hipSuccess) return fail(static_cast<int>(err), "dg_densify: %s", hipGetErrorString(err));
+    if (n_edges > 0)
+        hipLaunchKernelGGL(densify_scatter_kernel, dim3(static_cast<unsigned>((n_edges + 255) / 256)), dim3(256), 0,
+                           stream, edge_src, edge_dst, edge_attr, n_edges, B, N, labels);
+    hipLaunchKernelGGL(onehot_kernel, dim3(static_cast<unsigned>((rows * E + 255) / 256)), dim3(256), 0, stream, labels,
+                       rows, E, a, bad_count);
+    return check_launch("dg_densify");
+}
+
+extern "C" int dg_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             dg_stream_t stream_) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(DG_E_ARG, "dg_adamw_flat: null pointer");
+    if (n < 0 || step < 1) return fail(DG_E_ARG, "dg_adamw_flat: n >= 0 and step >= 1 required");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow(static_cast<double>(beta1), static_cast<double>(step));
+    const double bc2 = 1.0 - pow(static_cast<double>(beta2), static_cast<double>(step));
+    const int64_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(adamw_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, static_cast<float>(bc1), static_cast<float>(sqrt(bc2)));
+    return check_launch("dg_adamw_flat");
+}
+
+extern "C" int dg_argmax_decode(const float* logits, int64_t rows, int E, unsigned char* out, dg_stream_t stream_) {
+    if (!logits || !out) return fail(DG_E_ARG, "dg_argmax_decode: null pointer");
+    if (rows < 0 || E < 1 || E > 255) return fail(DG_E_SHAPE, "dg_argmax_decode: need 1 <= classes <= 255");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(argmax_kernel, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), logits, rows, E, out);
+    return check_launch("dg_argmax_decode");
+}

@@ -1,0 +1,56 @@
+"""Batch densify on the GPU -- the step that feeds the hot path.
+
+Mirror of the reference's ``load_molecules`` / ``label2onehot``
+(``src/data/utils.py:15-23,128-142``): COO edges + bond labels of a padded PyG
+batch become ``a_tensor [B,N,N,b_dim]`` one-hot float32; node features are
+reshaped to ``x_tensor [B,N,m_dim]``.  PyG itself is not needed: any object with
+``edge_index [2,E]``, ``edge_attr [E]``, ``x [B*N, m_dim]`` and ``batch [B*N]``
+attributes works (``torch_geometric.data.Batch`` has exactly these).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .functional import _dev
+
+__all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot"]
+
+
+def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check: bool = False):
+    """``label2onehot(to_dense_adj(edge_index, batch, edge_attr, max_num_nodes=N), b_dim)`` for a
+    batch whose graphs are all padded to ``vertexes`` nodes (utils.py:130-137)."""
+    if not edge_index.is_cuda:
+        raise RuntimeError("druggen_amd.data runs on the GPU (no CPU fallback)")
+    lib = _lib.load()
+    dev = edge_index.device
+    src = edge_index[0].contiguous().long()
+    dst = edge_index[1].contiguous().long()
+    attr = edge_attr.reshape(-1).contiguous().long()
+    labels = torch.empty(batch_size, vertexes, vertexes, dtype=torch.int32, device=dev)
+    a = torch.empty(batch_size, vertexes, vertexes, b_dim, dtype=torch.float32, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    with _dev(a):
+        _lib.check(lib.dg_densify(src.data_ptr(), dst.data_ptr(), attr.data_ptr(), src.numel(), batch_size, vertexes,
+                                  b_dim, labels.data_ptr(), a.data_ptr(), bad.data_ptr(), _lib.stream_of(a)),
+                   "dg_densify")
+    if check and int(bad.item()):
+        raise RuntimeError(f"{int(bad.item())} adjacency entries have a bond label outside [0, {b_dim})")
+    return a
+
+
+def label2onehot(labels, dim, device=None):
+    """Reference utils.py:15-23 for label tensors already on the GPU."""
+    out = torch.zeros(list(labels.size()) + [dim], device=labels.device if device is None else device)
+    out.scatter_(len(out.size()) - 1, labels.unsqueeze(-1), 1.)
+    return out.float()
+
+
+def load_molecules(data=None, b_dim=32, m_dim=32, device=None, batch_size=32):
+    """Reference utils.py:128-142 -> (real_graphs, a_tensor, x_tensor)."""
+    data = data.to(device) if hasattr(data, "to") and device is not None else data
+    vertexes = int(data.batch.shape[0] / batch_size)
+    a_tensor = dense_one_hot_adjacency(data.edge_index, data.edge_attr, batch_size, vertexes, b_dim)
+    x_tensor = data.x.view(batch_size, vertexes, -1)
+    real_graphs = torch.concat((x_tensor.reshape(batch_size, -1), a_tensor.reshape(batch_size, -1)), dim=-1)
+    return real_graphs, a_tensor, x_tensor

@@ -339,6 +339,14 @@ def linear(x, weight, bias=None):
 # fp32-MFMA row GEMM with fused prologue / epilogue (dg_row_gemm)
 # --------------------------------------------------------------------------
 _pack_cache = {}
+_weights_epoch = 0
+
+
+def bump_weights_epoch() -> None:
+    """Called by optimizers that update parameters behind autograd's back (raw kernels on a
+    flat buffer do not bump ``tensor._version``): invalidates every packed weight."""
+    global _weights_epoch
+    _weights_epoch += 1
 
 
 def packed_weight(w, mode: int):
@@ -346,7 +354,8 @@ def packed_weight(w, mode: int):
     gradient), cached per (storage, version): re-packed only after an optimizer step."""
     key = (id(w), mode)
     hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[3] == w.data_ptr():
+    if (hit is not None and hit[0]() is w and hit[1] == w._version and hit[3] == w.data_ptr()
+            and hit[4] == _weights_epoch):
         return hit[2]
     if len(_pack_cache) > 4096:       # entries of dead tensors (e.g. DataParallel replicas)
         for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
@@ -359,7 +368,7 @@ def packed_weight(w, mode: int):
     with _dev(w):
         _lib.check(lib.dg_row_gemm_pack(_lib.ptr(wd), _lib.ptr(packed), rows, cols, mode, _lib.stream_of(w)),
                    "dg_row_gemm_pack")
-    _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr())
+    _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr(), _weights_epoch)
     return packed
 
 

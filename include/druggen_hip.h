@@ -134,6 +134,25 @@ int dg_row_gemm(const float* a, const float* a_mask, const float* packed, float*
                 const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                 float eps, dg_stream_t stream);
 
+/* ---- the steps either side of the path -------------------
+ * dg_densify: reference src/data/utils.py:128-137 -- PyG to_dense_adj (scatter-ADD
+ * of edge_attr at [b = u/N, u%N, v%N]; every graph is padded to N nodes) followed by
+ * label2onehot (utils.py:15-23).  COO arrays are int64 device pointers; `labels`
+ * [B,N,N] int32 scratch, `a` [B,N,N,E] float32 out, `bad_count` (int32, device)
+ * receives the number of entries whose summed label fell outside [0,E).            */
+int dg_densify(const int64_t* edge_src, const int64_t* edge_dst, const int64_t* edge_attr, int64_t n_edges,
+               int B, int N, int E, int* labels, float* a, int* bad_count, dg_stream_t stream);
+
+/* dg_adamw_flat: one torch.optim.AdamW update (reference train.py:213-214,368,384;
+ * decoupled weight decay, no amsgrad) over flat float32 buffers; `step` >= 1.       */
+int dg_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  dg_stream_t stream);
+
+/* dg_argmax_decode: reference inference.py:197-198 `torch.max(x, -1)[1]` on logits
+ * [rows, E] -> uint8 labels [rows] (first maximum), so only bytes cross PCIe.      */
+int dg_argmax_decode(const float* logits, int64_t rows, int E, unsigned char* out, dg_stream_t stream);
+
 /* ---- opt-in kernel timing with HIP events (bench.py roofline) ----------------
  * When enabled, every launch of a profiled kernel is bracketed by two events on
  * the caller's stream.  dg_prof_read() synchronises the recorded events and

@@ -1,0 +1,123 @@
+"""GPU parity of the kernels either side of the hot path (densify, AdamW, argmax
+decode) and of the reference-format checkpoint helpers."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aux_oracle as aux
+
+pytestmark = pytest.mark.gpu
+
+
+def _coo_batch(B, N, E, seed):
+    """Padded PyG-style batch from the synthetic molecule generator."""
+    from druggen_amd import synth
+    a, x, bonds, atoms = synth.molecule_batch(B, N, E, 7, seed=seed)
+    src, dst, attr = [], [], []
+    for b in range(B):
+        i, j = np.nonzero(bonds[b])
+        src.append(b * N + i); dst.append(b * N + j); attr.append(bonds[b][i, j])
+    edge_index = np.stack([np.concatenate(src), np.concatenate(dst)])
+    return edge_index, np.concatenate(attr), x.reshape(B * N, -1), np.repeat(np.arange(B), N), a, x
+
+
+@pytest.mark.parametrize("B,N,E", [(3, 6, 4), (32, 9, 5), (256, 45, 5), (1, 90, 10)])
+def test_densify_matches_to_dense_adj_plus_onehot(B, N, E):
+    from druggen_amd import data
+
+    class Batch:      # the four attributes load_molecules touches on a PyG Batch
+        pass
+    ei, ea, x, batch, a_want, x_want = _coo_batch(B, N, E, seed=B + N)
+    d = Batch()
+    d.edge_index, d.edge_attr = torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()
+    d.x, d.batch = torch.from_numpy(x).cuda(), torch.from_numpy(batch).cuda()
+    graphs, a, xt = data.load_molecules(data=d, b_dim=E, m_dim=7, device=None, batch_size=B)
+    g_ref, a_ref, x_ref = aux.load_molecules(ei, ea, x, batch, B, E)
+    assert np.array_equal(a_ref, a_want)                       # the oracle reproduces the generator's graphs
+    assert np.array_equal(a.cpu().numpy(), a_ref)              # bit-exact one-hot
+    assert np.array_equal(xt.cpu().numpy(), x_ref) and np.array_equal(graphs.cpu().numpy(), g_ref)
+
+
+def test_densify_edge_cases():
+    from druggen_amd import data
+    # no edges at all -> every entry is class 0
+    ei = torch.zeros(2, 0, dtype=torch.long, device="cuda")
+    ea = torch.zeros(0, dtype=torch.long, device="cuda")
+    a = data.dense_one_hot_adjacency(ei, ea, 2, 4, 3)
+    assert a.shape == (2, 4, 4, 3) and bool((a[..., 0] == 1).all()) and float(a.sum()) == 2 * 16
+    # duplicate edges are ADDED by to_dense_adj (1 + 1 = label 2); out-of-range sums are reported
+    ei = torch.tensor([[0, 0, 5], [1, 1, 6]], device="cuda")
+    ea = torch.tensor([1, 1, 2], device="cuda")
+    a = data.dense_one_hot_adjacency(ei, ea, 2, 4, 3)
+    ref = aux.label2onehot(aux.to_dense_adj(ei.cpu().numpy(), np.repeat(np.arange(2), 4), ea.cpu().numpy(), 4), 3)
+    assert np.array_equal(a.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError, match="outside"):
+        data.dense_one_hot_adjacency(ei, torch.tensor([2, 2, 2], device="cuda"), 2, 4, 3, check=True)
+
+
+def test_flat_adamw_matches_torch_and_oracle_and_skips_dead_parameters():
+    from druggen_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(128, 128), (128,), (384, 128), (5,), (7, 3)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    dead = torch.nn.Parameter(torch.randn(9, device="cuda"))
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    dead0 = dead.detach().clone()
+    mine = FlatAdamW(ps + [dead], lr=1e-3)
+    theirs = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.999))
+    p_np = [p.detach().double().cpu().numpy() for p in ps]
+    m_np = [np.zeros_like(v) for v in p_np]
+    v_np = [np.zeros_like(v) for v in p_np]
+    for step in range(1, 4):
+        grads = [torch.randn_like(p) for p in ps]
+        for p, r, g in zip(ps, ref, grads):
+            p.grad, r.grad = g.clone(), g.clone()
+        mine.step()
+        theirs.step()
+        for k, g in enumerate(grads):
+            p_np[k], m_np[k], v_np[k] = aux.adamw_step(p_np[k], g.double().cpu().numpy(), m_np[k], v_np[k], step, 1e-3)
+        for p, r, q in zip(ps, ref, p_np):
+            assert torch.allclose(p, r, rtol=1e-6, atol=1e-7)
+            assert np.allclose(p.detach().cpu().numpy(), q, rtol=1e-5, atol=1e-6)
+    assert torch.equal(dead, dead0) and dead.grad is None       # never touched, not even weight decay
+    assert all(p.data_ptr() >= mine.flat_param.data_ptr() for p in ps)
+
+
+def test_argmax_decode_matches_torch_max():
+    from druggen_amd import decode
+    g = torch.Generator(device="cuda").manual_seed(0)
+    node = torch.randn(64, 45, 13, device="cuda", generator=g)
+    edge = torch.randn(64, 45, 45, 5, device="cuda", generator=g)
+    edge[0, 0, 0] = 1.0                                          # ties -> first maximum
+    n_lab, e_lab = decode.decode_molecule_labels(node, edge)
+    assert n_lab.dtype == torch.uint8 and e_lab.shape == (64, 45, 45)
+    assert np.array_equal(n_lab.cpu().numpy(), aux.argmax_last(node.cpu().numpy()))
+    assert np.array_equal(e_lab.cpu().numpy(), aux.argmax_last(edge.cpu().numpy()))
+    assert torch.equal(e_lab.long(), torch.max(edge, -1)[1])
+
+
+def test_trainer_with_flat_adamw_matches_torch_adamw():
+    """GANStep(optimizer='flat') == GANStep(optimizer='torch') after two iterations."""
+    import cases
+    import harness
+    from druggen_amd.model import Discriminator, Generator
+    from druggen_amd.trainer import GANStep
+    case = cases.CASES["tiny_relu"]
+    cfg = cases.net_config(case)
+    gp, dp = cases.build_params(case)
+    inp = harness.torch_inputs(case, torch.float32, "cuda")
+    results = []
+    for kind in ("flat", "torch"):
+        args = (cfg.act, cfg.vertexes, cfg.edges, cfg.nodes, cfg.dropout)
+        kw = dict(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, mlp_ratio=cfg.mlp_ratio)
+        G, D = Generator(*args, **kw), Discriminator(*args, **kw)
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in gp.items()})
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+        G, D = G.cuda(), D.cuda()
+        st = GANStep(G, D, lambda_gp=case["lambda_gp"], optimizer=kind)
+        for _ in range(2):
+            st.step(inp["disc_edge"], inp["disc_node"], inp["gen_edge"], inp["gen_node"],
+                    eps=(inp["eps_edge"], inp["eps_node"]))
+        results.append([p.detach().clone() for p in list(G.parameters()) + list(D.parameters())])
+    for a, b in zip(*results):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
