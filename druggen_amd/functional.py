@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "inputs_only_backward",
+__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
@@ -558,3 +558,120 @@ def linear_ln(x, weight, bias, residual, gamma, beta, eps: float = 1e-5):
     if not _fusable(x, weight) or tuple(weight.shape) != (128, 128) or bias is None or in_second_order_forward():
         return _composite_linear_ln(x, weight, bias, residual, gamma, beta, float(eps))
     return _LinearLN.apply(x, weight, bias, residual, gamma, beta, float(eps))
+
+
+# --------------------------------------------------------------------------
+# whole attention half of an Encoder_Block as one autograd node
+# --------------------------------------------------------------------------
+def _composite_attn_block(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4, alpha, eps3,
+                          eps4, need_edge):
+    q, k, v = linear(x1, wq, bq), linear(x1, wk, bk), linear(x1, wv, bv)
+    e = linear(y, we, be)
+    s, o = attn_core(q, k, v, e, alpha, need_s=need_edge)
+    x2 = linear_ln(o, won, bon, x1, g3, b3, eps3)
+    if not need_edge:
+        return x2
+    return x2, linear_ln(s, woe, boe, y, g4, b4, eps4)
+
+
+class _AttnBlock(Function):
+    """x2 = LN3(x1 + out_n(o)), y2 = LN4(y + out_e(s)) with (s, o) = attention(q(x1), k(x1), v(x1), e(y))
+    -- reference layers.py:111-135 + 186-190 -- as ONE autograd node: every projection is a row-GEMM
+    launch with its bias / residual / LayerNorm epilogue, and in the backward every gradient
+    accumulation (y feeds e-proj and the ln4 residual; x1 feeds q, k, v and the ln3 residual) is the
+    residual operand of the next GEMM's epilogue instead of a separate elementwise add."""
+
+    @staticmethod
+    def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4, alpha, eps3, eps4,
+                need_edge):
+        B, N, C = x1.shape
+        x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
+        pw = packed_weight
+        q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
+        k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
+        v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
+        e = row_gemm(yf, pw(we, 0), C, C, bias=be)
+        lib = _lib.load()
+        s = torch.empty_like(e) if need_edge else None
+        o = torch.empty_like(q)
+        with _dev(q):
+            _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
+                                            _lib.ptr(o), B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_fwd")
+        _account("attn_fwd", 4 * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
+        x2, mean3, rstd3, pre3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3),
+                                          want_pre=True)
+        outs = [x2.view(B, N, C)]
+        saved = [x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3]
+        if need_edge:
+            y2, mean4, rstd4, pre4 = row_gemm(s, pw(woe, 0), C, C, bias=boe, residual=yf,
+                                              ln=(_c(g4), _c(b4), eps4), want_pre=True)
+            outs.append(y2.view(B, N, N, C))
+            saved += [mean4, rstd4, pre4]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (alpha, eps3, eps4, need_edge, (B, N, C))
+        ctx.extra = (bq, bk, bv, be, boe, bon, b3, b4)     # only needed by the create_graph fallback
+        return tuple(outs) if need_edge else outs[0]
+
+    @staticmethod
+    def backward(ctx, dx2, dy2=None):
+        alpha, eps3, eps4, need_edge, (B, N, C) = ctx.cfg
+        sv = ctx.saved_tensors
+        x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3 = sv[:19]
+        if torch.is_grad_enabled():
+            bq, bk, bv, be, boe, bon, b3, b4 = ctx.extra
+            ins = (x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4)
+            fn = lambda *t: _composite_attn_block(*t, alpha, eps3, eps4, need_edge)
+            gout = (dx2, dy2) if need_edge else dx2
+            return _double_backward_fallback(fn, ins, gout) + (None, None, None, None)
+        pw = packed_weight
+        wants_w = ctx.needs_input_grad[2] and not getattr(_tls, "inputs_only", False)
+        x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(dx2).reshape(-1, C))
+        do = row_gemm(dz3, pw(won, 1), C, C)
+        ds = dz4 = dg4 = db4 = None
+        if need_edge:
+            mean4, rstd4, pre4 = sv[19:22]
+            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, _c(dy2).reshape(-1, C))
+            ds = row_gemm(dz4, pw(woe, 1), C, C)
+        lib = _lib.load()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        de = torch.empty_like(e)
+        with _dev(q):
+            _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ds),
+                                            _lib.ptr(do), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de),
+                                            B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd")
+        _account("attn_bwd", 4 * B * ((3 if ds is not None else 2) * N * N * C + 7 * N * C))
+        dy = dx1 = None
+        if ctx.needs_input_grad[1]:
+            dy = row_gemm(de, pw(we, 1), C, C, residual=dz4).view(y.shape)        # + ln4 residual path
+        if ctx.needs_input_grad[0]:
+            t = row_gemm(dq, pw(wq, 1), C, C, residual=dz3)                       # + ln3 residual path
+            t = row_gemm(dk, pw(wk, 1), C, C, residual=t)
+            dx1 = row_gemm(dv, pw(wv, 1), C, C, residual=t).view(x1.shape)
+        gw = [None] * 12
+        if wants_w:
+            gw[0], gw[1] = _wgrad(dq, x1f, True)
+            gw[2], gw[3] = _wgrad(dk, x1f, True)
+            gw[4], gw[5] = _wgrad(dv, x1f, True)
+            gw[6], gw[7] = _wgrad(de, yf, True)
+            if need_edge:
+                gw[8], gw[9] = _wgrad(dz4, s, True)
+            gw[10], gw[11] = _wgrad(dz3, o, True)
+        return (dx1, dy, *gw, dg3, db3, dg4, db4, None, None, None, None)
+
+
+def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
+    """Attention half of an encoder block for ``attn`` (an MHA module): returns
+    (LN3(x1 + out_n(o)), LN4(y + out_e(s)) or None)."""
+    C = x1.shape[-1]
+    alpha = 1.0 / (attn.d_k ** 0.5)
+    args = (x1, y, attn.q.weight, attn.q.bias, attn.k.weight, attn.k.bias, attn.v.weight, attn.v.bias,
+            attn.e.weight, attn.e.bias, attn.out_e.weight, attn.out_e.bias, attn.out_n.weight, attn.out_n.bias,
+            ln3.weight, ln3.bias, ln4.weight, ln4.bias)
+    fused = (x1.is_cuda and x1.dtype == torch.float32 and C == 128 and x1.dim() == 3
+             and all(t is not None for t in args) and not in_second_order_forward())
+    if not fused:
+        out = _composite_attn_block(*args, alpha, ln3.eps, ln4.eps, need_edge)
+    else:
+        out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
+    return out if need_edge else (out, None)

@@ -97,15 +97,12 @@ class Encoder_Block(nn.Module):
         return dgf.ln_residual(a, r, ln.weight, ln.bias, ln.eps)
 
     def forward(self, x, y, need_edge=True):
-        a = self.attn
         x1 = self._ln(self.ln1, x)
-        o, s = a(x1, y, need_edge, raw=True)
-        # out_n / out_e projections fused with the residual add and ln3 / ln4
-        x2 = dgf.linear_ln(o, a.out_n.weight, a.out_n.bias, x1, self.ln3.weight, self.ln3.bias, self.ln3.eps)
+        # q/k/v/e projections, attention core, out_n/out_e + residual + ln3/ln4: one autograd node
+        x2, y2 = dgf.attn_block(x1, y, self.attn, self.ln3, self.ln4, need_edge)
         x = self.mlp.forward_residual_ln(x2, self.ln5)
         if not need_edge:
             return x, None
-        y2 = dgf.linear_ln(s, a.out_e.weight, a.out_e.bias, y, self.ln4.weight, self.ln4.bias, self.ln4.eps)
         y = self.mlp2.forward_residual_ln(y2, self.ln6)
         return x, y
 
