@@ -27,21 +27,27 @@ def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, 
 
 
 def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, mol_annot, batch_size, device,
-                       lambda_gp, *, eps=None):
+                       lambda_gp, *, eps=None, generator_outputs=None):
     """Reference loss.py:52-72 -> (node, edge, d_loss).
 
     The generator output only enters detached, so its forward runs without
-    recording a graph (the reference records one it never uses)."""
+    recording a graph (the reference records one it never uses).  ``generator_outputs``
+    may carry the 4-tuple of an earlier ``generator(mol_adj, mol_annot)`` call to reuse."""
     prediction_real = -torch.mean(discriminator(drug_adj, drug_annot))
-    with torch.no_grad():
-        node, edge, node_sample, edge_sample = generator(mol_adj, mol_annot)
+    if generator_outputs is None:
+        with torch.no_grad():
+            generator_outputs = generator(mol_adj, mol_annot)
+    node, edge, node_sample, edge_sample = generator_outputs
+    node_sample, edge_sample = node_sample.detach(), edge_sample.detach()
     prediction_fake = torch.mean(discriminator(edge_sample, node_sample))
     gp = gradient_penalty(discriminator, drug_annot, drug_adj, node_sample, edge_sample, batch_size, device, eps=eps)
     return node, edge, prediction_fake + prediction_real + lambda_gp * gp
 
 
-def generator_loss(generator, discriminator, mol_adj, mol_annot, batch_size):
+def generator_loss(generator, discriminator, mol_adj, mol_annot, batch_size, *, generator_outputs=None):
     """Reference loss.py:75-84 -> (g_loss, node, edge, node_sample, edge_sample)."""
-    node, edge, node_sample, edge_sample = generator(mol_adj, mol_annot)
+    if generator_outputs is None:
+        generator_outputs = generator(mol_adj, mol_annot)
+    node, edge, node_sample, edge_sample = generator_outputs
     g_loss = -torch.mean(discriminator(edge_sample, node_sample))
     return g_loss, node, edge, node_sample, edge_sample

@@ -15,7 +15,7 @@ from typing import Iterable, List, Optional
 import torch
 
 from . import _lib
-from .functional import _dev, bump_weights_epoch
+from .functional import _dev
 
 __all__ = ["FlatAdamW"]
 
@@ -92,4 +92,6 @@ class FlatAdamW:
                                          self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                          self.weight_decay, self.step_count, _lib.stream_of(self.flat_param)),
                        "dg_adamw_flat")
-        bump_weights_epoch()    # parameters changed without touching tensor._version
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that
+        # version-keyed caches (packed GEMM weights) notice, exactly as an in-place torch op would
+        torch.autograd.graph.increment_version([self.params[i] for i in self._live])

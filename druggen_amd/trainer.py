@@ -95,7 +95,7 @@ class GANStep:
     def __init__(self, G: torch.nn.Module, D: torch.nn.Module, *, g_lr: float = 1e-5, d_lr: float = 1e-5,
                  betas: Sequence[float] = (0.9, 0.999), lambda_gp: float = 10.0, group=None,
                  skip_d_wgrad_in_g_step: bool = True, d_loss_fn=discriminator_loss, g_loss_fn=generator_loss,
-                 optimizer: str = "auto"):
+                 optimizer: str = "auto", share_generator_forward: bool = True):
         self.G, self.D = G, D
         self.lambda_gp = lambda_gp
         self.group = group
@@ -112,6 +112,11 @@ class GANStep:
         # them away at the next reset_grad (train.py:352); skipping them changes nothing
         # observable and saves ~2.2e9 FLOP per molecule.
         self.skip_d_wgrad_in_g_step = skip_d_wgrad_in_g_step
+        # The reference runs G(mol) twice per iteration -- loss.py:60 for the D step (detached) and
+        # loss.py:77 for the G step -- with the SAME generator weights and inputs (G is only updated
+        # at the end of the iteration, train.py:384).  Without active dropout the two forwards are
+        # identical, so one forward with its graph serves both.
+        self.share_generator_forward = share_generator_forward
         self._d_loss_fn, self._g_loss_fn = d_loss_fn, g_loss_fn
 
     def _update(self, opt, bucket: GradBucket) -> None:
@@ -142,6 +147,12 @@ class GANStep:
         B, dev = gen_node.shape[0], gen_node.device
         self.reset_grad()
         kw = {} if eps is None else {"eps": eps}
+        shared = None
+        if (self.share_generator_forward and self._d_loss_fn is discriminator_loss
+                and self._g_loss_fn is generator_loss
+                and not (self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0)):
+            shared = self.G(gen_edge, gen_node)
+            kw["generator_outputs"] = shared
         _, _, d_loss = self._d_loss_fn(self.G, self.D, disc_edge, disc_node, gen_edge, gen_node, B, dev,
                                        self.lambda_gp, **kw)
         d_loss.backward()
@@ -151,7 +162,8 @@ class GANStep:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            g_loss = self._g_loss_fn(self.G, self.D, gen_edge, gen_node, B)[0]
+            gkw = {} if shared is None else {"generator_outputs": shared}
+            g_loss = self._g_loss_fn(self.G, self.D, gen_edge, gen_node, B, **gkw)[0]
             g_loss.backward()
         finally:
             for p in d_params:

@@ -121,3 +121,31 @@ def test_trainer_with_flat_adamw_matches_torch_adamw():
         results.append([p.detach().clone() for p in list(G.parameters()) + list(D.parameters())])
     for a, b in zip(*results):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_shared_generator_forward_is_exact():
+    """One G forward serving both the D step and the G step (possible because G is only updated at
+    the end of the iteration) gives bit-identical parameters to running it twice like the reference."""
+    import cases
+    import harness
+    from druggen_amd.model import Discriminator, Generator
+    from druggen_amd.trainer import GANStep
+    case = cases.CASES["tiny_leaky"]
+    cfg = cases.net_config(case)
+    gp, dp = cases.build_params(case)
+    inp = harness.torch_inputs(case, torch.float32, "cuda")
+    results = []
+    for share in (True, False):
+        args = (cfg.act, cfg.vertexes, cfg.edges, cfg.nodes, cfg.dropout)
+        kw = dict(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, mlp_ratio=cfg.mlp_ratio)
+        G, D = Generator(*args, **kw), Discriminator(*args, **kw)
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in gp.items()})
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+        G, D = G.cuda(), D.cuda()
+        st = GANStep(G, D, lambda_gp=case["lambda_gp"], share_generator_forward=share)
+        for _ in range(2):
+            losses = st.step(inp["disc_edge"], inp["disc_node"], inp["gen_edge"], inp["gen_node"],
+                             eps=(inp["eps_edge"], inp["eps_node"]))
+        results.append([p.detach().clone() for p in list(G.parameters()) + list(D.parameters())] + list(losses))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
