@@ -166,6 +166,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---- skinny outputs: N <= 16 rows of dW (readout_e / readout_n, reference models.py:67-68) -----
+// dW[n][k] = sum_r dy[r][n] x[r][k] with N = 5 / 13: no MFMA tile to fill, the kernel is a coalesced
+// stream over x (512 B rows) with N float4 accumulators per lane; dy[r][.] is a broadcast load.
+// Thread = (row phase, k quad); row phases are combined through LDS in a fixed order.
+template <int NMAX>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         float* __restrict__ part_w, float* __restrict__ part_b,
+                                                         int64_t R, int N, int K, int64_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* red = reinterpret_cast<float4*>(smem_raw);   // [phases][NMAX][KQ]
+    const int KQ = K / 4;
+    const int phases = 256 / KQ;
+    const int kq = threadIdx.x % KQ, rp = threadIdx.x / KQ;
+    const int64_t r_lo = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+    int64_t r_hi = r_lo + rows_per_block;
+    if (r_hi > R) r_hi = R;
+    float4 acc[NMAX];
+    float bsum[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+        acc[n] = f4(0.f);
+        bsum[n] = 0.f;
+    }
+    if (rp < phases) {
+        for (int64_t r = r_lo + rp; r < r_hi; r += phases) {
+            const float4 xv = ld4(x + r * K + kq * 4);
+            const float* dr = dy + r * N;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                const float d = n < N ? dr[n] : 0.f;
+                acc[n] = fma4(f4(d), xv, acc[n]);
+                bsum[n] += d;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) red[(rp * NMAX + n) * KQ + kq] = acc[n];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < N * KQ; idx += 256) {
+        const int n = idx / KQ, q = idx % KQ;
+        float4 t = f4(0.f);
+        for (int p = 0; p < phases; ++p) t += red[(p * NMAX + n) * KQ + q];
+        st4(part_w + (static_cast<size_t>(blockIdx.x) * N * K) + static_cast<size_t>(n) * K + q * 4, t);
+    }
+    if (part_b) {
+        __syncthreads();
+        float* rb = reinterpret_cast<float*>(smem_raw);   // [phases][NMAX]
+        if (rp < phases && kq == 0)
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) rb[rp * NMAX + n] = bsum[n];
+        __syncthreads();
+        if (threadIdx.x < N) {
+            float t = 0.f;
+            for (int p = 0; p < phases; ++p) t += rb[p * NMAX + threadIdx.x];
+            part_b[static_cast<size_t>(blockIdx.x) * N + threadIdx.x] = t;
+        }
+    }
+}
+
+// generic fixed-order reduce for the skinny path (element granularity, any count)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t n,
+                                                            float* __restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < S; ++p) s += part[static_cast<size_t>(p) * n + i];
+    out[i] = s;
+}
+
+constexpr int kSkinnyBlocks = 512;
+
+bool skinny_ok(int N, int K) { return N >= 1 && N <= 16 && K >= 4 && K % 4 == 0 && K <= 1024 && 256 % (K / 4) == 0; }
+
 struct WgradPlan {
     int nt, kt, wn, wk, tr, threads, lds, lds_mask;
 };
@@ -219,6 +293,7 @@ using namespace dg;
 
 extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     WgradPlan p;
+    if (R >= 1 && skinny_ok(N, K)) return static_cast<size_t>(kSkinnyBlocks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
     if (R < 1 || !wgrad_plan(N, K, &p)) return 0;
     int tpb;
     const int S = wgrad_blocks(R, p, &tpb);
@@ -228,6 +303,31 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
 extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db, void* workspace,
                                size_t workspace_bytes, int64_t R, int N, int K, dg_stream_t stream_) {
     if (!dy || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
+    if (R >= 1 && skinny_ok(N, K)) {
+        if (dy_mask) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask is not supported for N <= 16");
+        if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
+            return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        int S = kSkinnyBlocks;
+        int64_t rpb = (R + S - 1) / S;
+        if (rpb < 64) rpb = 64;
+        S = static_cast<int>((R + rpb - 1) / rpb);
+        float* part_w = static_cast<float*>(workspace);
+        float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
+        const int KQ = K / 4, phases = 256 / KQ;
+        ProfScope prof(DG_K_LINEAR_WGRAD, stream);
+        if (N <= 8)
+            hipLaunchKernelGGL((skinny_wgrad_kernel<8>), dim3(S), dim3(256), phases * 8 * KQ * 16, stream, dy, x, part_w,
+                               part_b, R, N, K, rpb);
+        else
+            hipLaunchKernelGGL((skinny_wgrad_kernel<16>), dim3(S), dim3(256), phases * 16 * KQ * 16, stream, dy, x,
+                               part_w, part_b, R, N, K, rpb);
+        const int64_t nw = static_cast<int64_t>(N) * K;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + 255) / 256)), dim3(256), 0, stream,
+                           part_w, S, nw, dw);
+        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part_b, S, static_cast<int64_t>(N), db);
+        return check_launch("dg_linear_wgrad(skinny)");
+    }
     WgradPlan p;
     if (R < 1 || !wgrad_plan(N, K, &p))
         return fail(DG_E_SHAPE, "dg_linear_wgrad: unsupported shape R=%lld N=%d K=%d", (long long)R, N, K);

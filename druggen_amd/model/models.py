@@ -61,7 +61,9 @@ class Generator(_Trunk):
 
     def forward(self, z_e, z_n):
         node, edge = self._encode(z_e, z_n, True)
-        return node, edge, self.readout_n(node), self.readout_e(edge)
+        node_sample = dgf.linear(node, self.readout_n.weight, self.readout_n.bias)
+        edge_sample = dgf.linear(edge, self.readout_e.weight, self.readout_e.bias)
+        return node, edge, node_sample, edge_sample
 
 
 class Discriminator(_Trunk):

@@ -108,7 +108,8 @@ int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
  * dy_mask (nullable, [R,N]): use dy * (dy_mask > 0), i.e. the ReLU backward of
  * MLP.fc1 (layers.py:51) folded into the operand load.
  * Supported (N,K): multiples of 32 from the table in csrc/linear_wgrad.hip
- * (128x128, 384x128, 128x384, 128x64, ...); others return DG_E_SHAPE.             */
+ * (128x128, 384x128, 128x384, 128x64, ...), plus N <= 16 with K % 4 == 0 (readout
+ * layers, models.py:67-68: a streaming VALU kernel); others return DG_E_SHAPE.   */
 size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K);
 int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db,
                     void* workspace, size_t workspace_bytes,

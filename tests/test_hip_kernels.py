@@ -177,7 +177,7 @@ def test_ln_matches_torch_layer_norm_at_edge_tensor_size():
     assert (y - want).abs().max().item() < 2e-5
 
 
-WGRAD_SHAPES = [(5, 32, 32), (50, 32, 64), (77, 128, 64), (1000, 128, 128), (4097, 384, 128), (333, 128, 384),
+WGRAD_SHAPES = [(1000, 5, 128), (2025 * 3, 13, 128), (70, 10, 128), (33, 1, 64), (513, 16, 32), (5, 32, 32), (50, 32, 64), (77, 128, 64), (1000, 128, 128), (4097, 384, 128), (333, 128, 384),
                 (2025 * 3, 128, 128), (64, 64, 64), (129, 96, 32), (31, 32, 96), (40, 64, 32)]
 
 
