@@ -267,6 +267,11 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None):
     K = x2.shape[1]
     lib = _lib.load()
     need = int(lib.dg_linear_wgrad_workspace_bytes(R, N, K)) if dy2.is_cuda else 0
+    if need == 0 and dy2.is_cuda and dy_mask is None and K <= 16 and int(lib.dg_linear_wgrad_workspace_bytes(R, K, N)):
+        # few INPUT features (embedding layer 1, Linear(5 -> 64), reference models.py:57): the same
+        # streaming kernel with the operands swapped gives dW^T
+        dwt, _ = _wgrad(x2, dy2, False)
+        return dwt.t().contiguous(), (dy2.sum(0) if want_bias else None)
     if need == 0:      # shape outside the kernel's table: library GEMM on the same device
         if dy_mask is not None:
             dy2 = dy2 * (dy_mask > 0)
