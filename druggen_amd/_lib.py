@@ -34,7 +34,8 @@ SIGNATURES = {
     "dg_linear_wgrad": (c_int, [_P] * 5 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
     "dg_row_gemm_packed_floats": (c_size_t, [c_int, c_int]),
     "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "dg_row_gemm": (c_int, [_P] * 4 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
+    "dg_row_gemm_mask_words": (c_size_t, [c_int64, c_int, c_int]),
+    "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
     "dg_densify": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dg_adamw_flat": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "dg_argmax_decode": (c_int, [_P, c_int64, c_int, _P, _P]),

@@ -59,7 +59,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 struct Epilogue {
     const float* bias;      // [N] or null
-    const float* mask;      // [R,N] or null: y *= (mask > 0)
+    const unsigned* mask_bits;  // per (tile, wave, lane) bit mask written by a ReLU forward of the SAME geometry
+    unsigned* relu_bits;        // optional output of the ReLU epilogue: bit (16*m + reg) = (v > 0)
     const float* residual;  // [R,N] or null
     const float* gamma;     // LayerNorm (needs N == 128) or null
     const float* beta;
@@ -80,27 +81,33 @@ __device__ __forceinline__ float half_sum(float x) {
 // Persistent row-GEMM workgroup.
 //   KC  = K/128 contraction chunks (B fragments for all of them stay in VGPRs for the whole kernel)
 //   NG  = N/128 output chunks, one 4-wave group each (all groups share the A tile)
-//   TR  = rows per tile (32 or 64)
+//   MG  = row groups of waves: the TR-row tile is split into MG slabs of MT = TR/32/MG 32-row blocks
+//   TR  = rows per tile
 //   EXCH = epilogue through an LDS exchange tile (row-wise float4 residual loads / stores,
-//          optional LayerNorm; NG == 1); otherwise direct stores from the accumulator layout
+//          optional LayerNorm; NG == MG == 1); otherwise direct stores from the accumulator layout,
+//          software-pipelined: the stores of tile t-1 are issued inside the MFMA phase of tile t.
 // A tiles arrive by LDS-DMA into a double buffer; the LDS image is the global image with the
 // 16-byte chunk index XOR-ed by (row & 15) inside every 512-byte segment (applied on the per-lane
 // SOURCE address, the DMA destination is lane-linear), which makes the ds_read_b128 fragment
 // reads bank-conflict free without padding.
-template <int KC, int NG, int TR, bool EXCH>
-__global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restrict__ a,
-                                                           const float* __restrict__ packed,
-                                                           float* __restrict__ y, int64_t R, Epilogue ep) {
-    constexpr int K = KC * 128, N = NG * 128, MT = TR / 32, WAVES = NG * 4;
+template <int KC, int NG, int MG, int TR, bool EXCH, bool PIPE, int MINW>
+__global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const float* __restrict__ a,
+                                                                const float* __restrict__ packed,
+                                                                float* __restrict__ y, int64_t R, Epilogue ep) {
+    constexpr int K = KC * 128, N = NG * 128, MT = TR / 32 / MG, WAVES = NG * MG * 4;
     constexpr int SLOTS = TR * K / 4;            // 16-byte slots per tile
-    static_assert(!EXCH || NG == 1, "exchange epilogue needs the whole row in one group");
+    constexpr int STEPS = KC * 16;               // MFMA steps (4 MFMAs per 32-row block each)
+    static_assert(!EXCH || (NG == 1 && MG == 1), "exchange epilogue needs the whole tile in one group");
+    static_assert(TR % (32 * MG) == 0, "tile rows must split evenly over the row groups");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);   // [2][TR*K]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = w >> 2, wq = w & 3;
+    const int wq = w & 3, g = (w >> 2) % NG, mg = (w >> 2) / NG;
     const int half = lane >> 5, col = lane & 31;
     const int64_t tiles = (R + TR - 1) / TR;
+    const int n = 128 * g + 32 * wq + col;
+    const int row_base = 32 * MT * mg;           // first tile row of this wave's slab
 
     float4 bf[KC][16];
 #pragma unroll
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             bf[kc][q] = ld4(packed + (static_cast<size_t>((4 * g + wq) * KC + kc) * 16 + q) * 256 + lane * 4);
+    const float bias = ep.bias ? ep.bias[n] : 0.f;
 
     auto dma_tile = [&](int64_t tile, int buf) {
         const int64_t r0 = tile * TR;
@@ -119,17 +127,33 @@ __global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restr
             if (r0 + row < R) dma16_async(a + (r0 + row) * K + src * 4, dst + ii * 1024);
         }
     };
+    // direct epilogue of one accumulator register (tile rows r0.., this lane's column n)
+    auto store_reg = [&](const f32x16 (&acc)[MT], int64_t r0, unsigned bits, int m, int reg, unsigned& newbits) {
+        const int64_t row = r0 + row_base + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        float v = acc[m][reg] + bias;
+        if (ep.relu) {
+            newbits |= (v > 0.f ? 1u : 0u) << (16 * m + reg);
+            v = fmaxf(v, 0.f);
+        }
+        if (ep.mask_bits) v = (bits >> (16 * m + reg)) & 1u ? v : 0.f;
+        if (row < R) y[row * N + n] = v;
+    };
 
-    int64_t tix = blockIdx.x;
-    const int n = 128 * g + 32 * wq + col;
-    const float bias = ep.bias ? ep.bias[n] : 0.f;
     wait_all_vmem_visible();   // B fragments and bias are in registers (and the compiler knows it)
+    int64_t tix = blockIdx.x;
     if (tix < tiles) dma_tile(tix, 0);
     wait_all_vmem();
     __syncthreads();
     int buf = 0;
+    f32x16 accP[MT];            // accumulators of the previous tile, stored during this tile's MFMA phase
+    int64_t r0P = 0, tixP = -1;
     for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
         const int64_t r0 = tix * TR;
+        unsigned bitsP = 0, newbits = 0;
+        if (!EXCH && PIPE && tixP >= 0 && ep.mask_bits) {
+            bitsP = ep.mask_bits[(tixP * WAVES + w) * 64 + lane];
+            wait_all_vmem_visible();      // issued before this tile's DMA: does not wait for it
+        }
         if (tix + gridDim.x < tiles) dma_tile(tix + gridDim.x, buf ^ 1);
         const float* at = lds + buf * (TR * K);
         f32x16 acc[MT];
@@ -137,63 +161,63 @@ __global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restr
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-        // A fragments are software-pipelined one step ahead of the MFMAs that consume them
+        // A fragments are read one step ahead of the MFMAs that consume them
         float4 nxt[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) nxt[m] = ld4(at + (32 * m + col) * K + (((16 * half) ^ (col & 15)) << 2));
+        for (int m = 0; m < MT; ++m)
+            nxt[m] = ld4(at + (row_base + 32 * m + col) * K + (((16 * half) ^ (col & 15)) << 2));
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
+        for (int st = 0; st < STEPS; ++st) {
+            const int kc = st / 16, q = st % 16;
+            float4 af[MT];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float4 af[MT];
+            for (int m = 0; m < MT; ++m) af[m] = nxt[m];
+            if (st + 1 < STEPS) {
+                const int kc2 = (st + 1) / 16, q2 = (st + 1) % 16;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = nxt[m];
-                if (kc * 16 + q + 1 < KC * 16) {
-                    const int kc2 = (kc * 16 + q + 1) / 16, q2 = (kc * 16 + q + 1) % 16;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        nxt[m] = ld4(at + (32 * m + col) * K + kc2 * 128 + (((16 * half + q2) ^ (col & 15)) << 2));
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[kc][q].x, acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[kc][q].y, acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[kc][q].z, acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[kc][q].w, acc[m], 0, 0, 0);
+                for (int m = 0; m < MT; ++m)
+                    nxt[m] = ld4(at + (row_base + 32 * m + col) * K + kc2 * 128 + (((16 * half + q2) ^ (col & 15)) << 2));
             }
-        // the next tile's DMA had the whole MFMA phase to land; wait for it BEFORE issuing this
-        // tile's stores so the wait never covers them (vmcnt retires in order and counts stores)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[kc][q].x, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[kc][q].y, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[kc][q].z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[kc][q].w, acc[m], 0, 0, 0);
+            if (!EXCH && PIPE) {
+                // previous tile's stores ride in the shadow of this tile's MFMAs (first steps only, so
+                // they have drained by the time the DMA wait below needs vmcnt == 0)
+                constexpr int PER = (16 * MT + 7) / 8;          // registers stored per step, 8 steps
+                if (st < 8 && tixP >= 0) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int r = st * PER + i;
+                        if (r < 16 * MT) store_reg(accP, r0P, bitsP, r / 16, r % 16, newbits);
+                    }
+                }
+            }
+        }
+        // the next tile's DMA had the whole MFMA phase to land; the stores above were issued early
         wait_all_vmem();
-        if (!EXCH) {
+        if (!EXCH && PIPE) {
+            if (ep.relu_bits && tixP >= 0) ep.relu_bits[(tixP * WAVES + w) * 64 + lane] = newbits;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                constexpr int MB = NG > 1 ? 8 : 16;   // mask loads batched per MB rows (register budget)
-#pragma unroll
-                for (int r8 = 0; r8 < 16; r8 += MB) {
-                    float mk[MB];
-                    if (ep.mask) {
-#pragma unroll
-                        for (int i = 0; i < MB; ++i) {
-                            const int reg = r8 + i;
-                            int64_t row = r0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                            if (row >= R) row = R - 1;
-                            mk[i] = ep.mask[row * N + n];
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < MB; ++i) {
-                        const int reg = r8 + i;
-                        const int64_t row = r0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                        float v = acc[m][reg] + bias;
-                        if (ep.relu) v = fmaxf(v, 0.f);
-                        if (ep.mask) v = mk[i] > 0.f ? v : 0.f;
-                        if (row < R) y[row * N + n] = v;
-                    }
-                }
-            }
+            for (int m = 0; m < MT; ++m) accP[m] = acc[m];
+            r0P = r0;
+            tixP = tix;
             __syncthreads();   // every wave: DMA(t+1) landed, tile t fully read
+        } else if (!EXCH) {
+            // many waves per SIMD: the other waves' MFMA phases hide this epilogue
+            const unsigned bits = ep.mask_bits ? ep.mask_bits[(tix * WAVES + w) * 64 + lane] : 0u;
+            unsigned nb = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) store_reg(acc, r0, bits, m, reg, nb);
+            if (ep.relu_bits) ep.relu_bits[(tix * WAVES + w) * 64 + lane] = nb;
+            __syncthreads();
         } else {
             float* ex = lds + buf * (TR * K);   // consumed A buffer becomes the [TR][128] exchange tile
             __syncthreads();                    // all waves finished their fragment reads
@@ -243,6 +267,14 @@ __global__ __launch_bounds__(NG * 256) void row_gemm_kernel(const float* __restr
             __syncthreads();   // exchange tile consumed before the next DMA overwrites it
         }
     }
+    if (!EXCH && PIPE && tixP >= 0) {   // drain: epilogue of the last tile
+        unsigned bitsP = ep.mask_bits ? ep.mask_bits[(tixP * WAVES + w) * 64 + lane] : 0u, newbits = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) store_reg(accP, r0P, bitsP, m, reg, newbits);
+        if (ep.relu_bits) ep.relu_bits[(tixP * WAVES + w) * 64 + lane] = newbits;
+    }
 }
 
 }  // namespace
@@ -267,41 +299,53 @@ extern "C" int dg_row_gemm_pack(const float* w, float* packed, int rows, int col
     return check_launch("dg_row_gemm_pack");
 }
 
-extern "C" int dg_row_gemm(const float* a, const float* a_mask, const float* packed, float* y, int64_t R, int K, int N,
-                           const float* bias, int relu, const float* out_mask, const float* residual,
+extern "C" size_t dg_row_gemm_mask_words(int64_t R, int K, int N) {
+    // geometry of the direct-epilogue kernels (see the launch table in dg_row_gemm)
+    if (K == 128 && N == 384) return static_cast<size_t>((R + 31) / 32) * 12 * 64;
+    if (K == 128 && N == 128) return static_cast<size_t>((R + 63) / 64) * 8 * 64;   // upper bound over variants
+    return 0;
+}
+
+extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias,
+                           int relu, unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual,
                            const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                            float eps, dg_stream_t stream_) {
     if (!a || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm: null pointer");
-    if (a_mask) return fail(DG_E_ARG, "dg_row_gemm: a_mask is not supported (mask in the producer's epilogue)");
     if (R < 0 || !((K == 128 && (N == 128 || N == 384)) || (K == 384 && N == 128)))
         return fail(DG_E_SHAPE, "dg_row_gemm: unsupported K=%d N=%d (supported: 128x128, 128x384, 384x128)", K, N);
     if (gamma && (N != 128 || !beta || !mean || !rstd))
         return fail(DG_E_ARG, "dg_row_gemm: LayerNorm epilogue needs N == 128, beta, mean and rstd");
+    const bool exch = gamma || residual;
+    if (exch && (mask_bits || relu_bits_out))
+        return fail(DG_E_ARG, "dg_row_gemm: bit masks cannot be combined with residual / LayerNorm epilogues");
+    if ((mask_bits || relu_bits_out) && K != 128)
+        return fail(DG_E_ARG, "dg_row_gemm: bit masks need K == 128");
+    if (exch && N != 128) return fail(DG_E_ARG, "dg_row_gemm: residual / LayerNorm epilogues need N == 128");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    Epilogue ep{bias, out_mask, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
+    Epilogue ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
     ProfScope prof(DG_K_ROW_GEMM, stream);
-#define LAUNCH(KC_, NG_, TR_, LN_, PER_CU_)                                                                       \
-    {                                                                                                             \
-        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4;                                                        \
-        static const hipError_t attr =                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, TR_, LN_>),              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                           \
-        (void)attr;                                                                                               \
-        const int64_t tiles = (R + TR_ - 1) / TR_;                                                                \
-        const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                         \
-        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, TR_, LN_>), dim3(grid), dim3(NG_ * 256), lds_bytes, stream, \
-                           a, packed, y, R, ep);                                                                  \
+#define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_)                                                     \
+    {                                                                                                              \
+        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4;                                                         \
+        static const hipError_t attr = hipFuncSetAttribute(                                                        \
+            reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_>),                \
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                                \
+        (void)attr;                                                                                                \
+        const int64_t tiles = (R + TR_ - 1) / TR_;                                                                 \
+        const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                          \
+        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_>), dim3(grid),                   \
+                           dim3(NG_ * MG_ * 256), lds_bytes, stream, a, packed, y, R, ep);                         \
     }
-    const bool exch = gamma || residual;
-    if (exch && out_mask) return fail(DG_E_ARG, "dg_row_gemm: out_mask cannot be combined with residual / LayerNorm");
+    static const int variant = getenv("DG_GEMM_VARIANT") ? atoi(getenv("DG_GEMM_VARIANT")) : 0;
     if (K == 128 && N == 128) {
-        if (exch) LAUNCH(1, 1, 64, true, 2) else LAUNCH(1, 1, 64, false, 2)
+        if (exch) LAUNCH(1, 1, 1, 64, true, false, 1, 2)
+        else if (variant == 1) LAUNCH(1, 1, 2, 64, false, false, 4, 2)   /* 8 waves, 4 waves/SIMD */
+        else LAUNCH(1, 1, 1, 64, false, true, 1, 2)
     } else if (K == 128 && N == 384) {
-        if (exch) return fail(DG_E_ARG, "dg_row_gemm: residual / LayerNorm epilogues need N == 128");
-        LAUNCH(1, 3, 64, false, 1)
+        LAUNCH(1, 3, 1, 32, false, true, 1, 1)
     } else {
-        LAUNCH(3, 1, 32, true, 1)
+        LAUNCH(3, 1, 1, 32, true, false, 1, 1)
     }
 #undef LAUNCH
     return check_launch("dg_row_gemm");

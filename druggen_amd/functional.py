@@ -381,14 +381,15 @@ def row_gemm_supported(K: int, N: int) -> bool:
     return (K == 128 and N in (128, 384)) or (K == 384 and N == 128)
 
 
-def row_gemm(a2, packed, K, N, bias=None, relu=False, a_mask=None, out_mask=None, residual=None, ln=None,
+def row_gemm(a2, packed, K, N, bias=None, relu=False, want_relu_bits=False, mask_bits=None, residual=None, ln=None,
              want_pre=False):
-    """y = epi(pro(a2) @ B): see include/druggen_hip.h.  ``ln=(gamma, beta, eps)`` selects the
-    LayerNorm epilogue and returns (y, mean, rstd); otherwise returns y."""
+    """y = epi(a2 @ B): see include/druggen_hip.h.  ``ln=(gamma, beta, eps)`` selects the LayerNorm
+    epilogue and returns (y, mean, rstd[, pre]); ``want_relu_bits`` additionally returns the packed
+    ReLU mask (y, bits) that a later input-gradient launch of the same geometry takes as ``mask_bits``."""
     R = a2.shape[0]
     lib = _lib.load()
     y = torch.empty(R, N, dtype=torch.float32, device=a2.device)
-    mean = rstd = gamma = beta = pre = None
+    mean = rstd = gamma = beta = pre = bits = None
     eps = 0.0
     if ln is not None and want_pre:
         pre = torch.empty(R, N, dtype=torch.float32, device=a2.device)
@@ -396,16 +397,18 @@ def row_gemm(a2, packed, K, N, bias=None, relu=False, a_mask=None, out_mask=None
         gamma, beta, eps = ln
         mean = torch.empty(R, dtype=torch.float32, device=a2.device)
         rstd = torch.empty(R, dtype=torch.float32, device=a2.device)
+    if want_relu_bits:
+        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, K, N)), dtype=torch.int32, device=a2.device)
     with _dev(a2):
-        _lib.check(lib.dg_row_gemm(_lib.ptr(a2), _lib.ptr(a_mask), _lib.ptr(packed), _lib.ptr(y), R, K, N,
-                                   _lib.ptr(bias), 1 if relu else 0, _lib.ptr(out_mask), _lib.ptr(residual),
-                                   _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre), float(eps),
-                                   _lib.stream_of(a2)), "dg_row_gemm")
-    nb = 4 * R * (K * (2 if a_mask is not None else 1) + N * (1 + (out_mask is not None) + (residual is not None)))
-    _account("row_gemm", nb)
-    if ln is None:
-        return y
-    return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
+        _lib.check(lib.dg_row_gemm(_lib.ptr(a2), _lib.ptr(packed), _lib.ptr(y), R, K, N, _lib.ptr(bias),
+                                   1 if relu else 0, None if bits is None else bits.data_ptr(),
+                                   None if mask_bits is None else mask_bits.data_ptr(), _lib.ptr(residual),
+                                   _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
+                                   float(eps), _lib.stream_of(a2)), "dg_row_gemm")
+    _account("row_gemm", 4 * R * (K + N * (1 + (residual is not None))))
+    if ln is not None:
+        return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
+    return (y, bits) if want_relu_bits else y
 
 
 # --------------------------------------------------------------------------
@@ -478,16 +481,16 @@ class _FFNLN(Function):
     def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
         H, C = w1.shape
         x2 = _c(x).reshape(-1, C)
-        h = row_gemm(x2, packed_weight(w1, 0), C, H, bias=b1, relu=True)
+        h, bits = row_gemm(x2, packed_weight(w1, 0), C, H, bias=b1, relu=True, want_relu_bits=True)
         y, mean, rstd, pre = row_gemm(h, packed_weight(w2, 0), H, C, bias=b2, residual=x2,
                                       ln=(_c(gamma), _c(beta), eps), want_pre=True)
-        ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre)
+        ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre = ctx.saved_tensors
+        x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = ctx.saved_tensors
         if torch.is_grad_enabled():
             eps = ctx.eps
             g = _double_backward_fallback(lambda *t: _composite_ffn_ln(*t, eps),
@@ -496,7 +499,7 @@ class _FFNLN(Function):
         H, C = w1.shape
         dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy).reshape(-1, C))
         # dh = (dz @ W2) * (h > 0): ReLU backward in the epilogue
-        dh = row_gemm(dz, packed_weight(w2, 1), C, H, out_mask=h)
+        dh = row_gemm(dz, packed_weight(w2, 1), C, H, mask_bits=bits)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = row_gemm(dh, packed_weight(w1, 1), H, C, residual=dz).view(x.shape)   # + residual path

@@ -115,23 +115,29 @@ int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float
                     void* workspace, size_t workspace_bytes,
                     int64_t R, int N, int K, dg_stream_t stream);
 
-/* ---- fp32-MFMA row GEMM with fused prologue / epilogue -------------------------
+/* ---- fp32-MFMA row GEMM with fused epilogues ------------------------------------
  * The dense layers applied to every edge / node row: MHA projections
  * (src/model/layers.py:111-116,127,135) and MLP.fc1/fc2 (:50-53), forward and
  * input-gradient, with the elementwise ops around them folded in:
- *   y[R,N] = epi( pro(a)[R,K] . B ),  pro(a) = a or a*(a_mask>0),
- *   epi(v) = LN?( relu?(v + bias) * (out_mask>0)? + residual? )
+ *   y[R,N] = epi( a[R,K] . B ),
+ *   epi(v) = LN?( relu?(v + bias) * relu_mask? + residual? )
  * `packed` is the weight in MFMA fragment order made by dg_row_gemm_pack from the
  * nn.Linear weight w[rows,cols]: mode 0 -> B[k][n] = w[n][k] (forward, N=rows,
  * K=cols); mode 1 -> B[k][n] = w[k][n] (input gradient dx = dy.w, N=cols, K=rows).
- * (K,N) in {(128,128), (128,384), (384,128)}; others DG_E_SHAPE.  LayerNorm epilogue
- * (gamma != NULL; layers.py:187-192) needs N == 128, writes mean/rstd [R] and,
- * if pre_ln != NULL, the pre-LayerNorm sum [R,N] that its backward needs.         */
+ * (K,N) in {(128,128), (128,384), (384,128)}; others DG_E_SHAPE.
+ * ReLU backward without a pass over the activations: a forward launch with
+ * relu != 0 can write one bit per output element into relu_bits_out
+ * (dg_row_gemm_mask_words(R,K,N) uint32 words, laid out per tile/wave/lane); the
+ * input-gradient launch of the NEXT layer (same R, K, N geometry) takes it as
+ * mask_bits and zeroes the masked outputs (reference: threshold_backward of
+ * layers.py:51).  LayerNorm epilogue (gamma != NULL; layers.py:187-192) needs
+ * N == 128, writes mean/rstd [R] and, if pre_ln != NULL, the pre-LayerNorm sum.   */
 size_t dg_row_gemm_packed_floats(int n_out, int k_contract);
 int dg_row_gemm_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
-int dg_row_gemm(const float* a, const float* a_mask, const float* packed, float* y,
-                int64_t R, int K, int N,
-                const float* bias, int relu, const float* out_mask, const float* residual,
+size_t dg_row_gemm_mask_words(int64_t R, int K, int N);
+int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K, int N,
+                const float* bias, int relu, unsigned* relu_bits_out, const unsigned* mask_bits,
+                const float* residual,
                 const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                 float eps, dg_stream_t stream);
 

@@ -270,8 +270,13 @@ def test_row_gemm_fused_epilogues(R):
     K, N = 128, 384
     a, w, b, om = _gen((R, K), 11), _gen((N, K), 12) * 0.1, _gen((N,), 13), _gen((R, N), 14)
     pw = dgf.packed_weight(f(w), 0)
-    assert _rel(dgf.row_gemm(f(a), pw, K, N, bias=f(b), relu=True), torch.relu(a @ w.t() + b)) < TOL
-    assert _rel(dgf.row_gemm(f(a), pw, K, N, out_mask=f(om)), (a @ w.t()) * (om > 0)) < TOL
+    h, bits = dgf.row_gemm(f(a), pw, K, N, bias=f(b), relu=True, want_relu_bits=True)
+    h_ref = torch.relu(a @ w.t() + b)
+    assert _rel(h, h_ref) < TOL
+    # the packed ReLU mask of that launch gates a later launch of the same geometry
+    w3 = _gen((N, K), 15) * 0.1
+    masked = dgf.row_gemm(f(a), dgf.packed_weight(f(w3), 0), K, N, mask_bits=bits)
+    assert _rel(masked, (a @ w3.t()) * (h.double().cpu() > 0)) < TOL
     # 128 -> 128 with bias + residual + LayerNorm (out_e + ln4)
     K, N = 128, 128
     a, w, b, res = _gen((R, K), 21), _gen((N, K), 22) * 0.1, _gen((N,), 23), _gen((R, N), 24)
