@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 WORKLOAD = dict(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
 
 
@@ -157,6 +158,13 @@ def main():
                 kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algorithmic_MB_per_launch": nbytes / n / 1e6,
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                                  "share_of_step": ms * 1e-3 / elapsed}
+                fl = dgf.traffic_flops(name)
+                if fl:          # MFMA-bound kernels: fp32 matrix-core roofline
+                    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                    kernels[name].update({"bound": "mfma", "achieved_TFLOPs": tf,
+                                          "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TFLOPS})
+                else:
+                    kernels[name]["bound"] = "hbm"
         dom = kernels.get("attn_fwd", {})
         traffic = None
         side = os.path.join(ROOT, "profiles", "traffic.json")     # PMC pass (rocprofv3 --pmc), per launch, bytes

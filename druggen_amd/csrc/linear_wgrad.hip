@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
         const float* ldy = lds + buf * BUF;
         const float* lx = ldy + TR * N;
         const int half = lane >> 5, col = lane & 31;
-#pragma unroll 4
+#pragma unroll
         for (int ks = 0; ks < TR / 2; ++ks) {
             float a[TN], b[TK];
 #pragma unroll
@@ -251,10 +251,11 @@ bool wgrad_plan(int N, int K, WgradPlan* p) {
     struct Row {
         int nt, kt, wn, wk, tr;
     };
+    static const bool big = getenv("DG_WGRAD_BIG_TILES") && atoi(getenv("DG_WGRAD_BIG_TILES"));
     static const Row table[] = {
-        {4, 4, 2, 2, 32},   // 128 x 128   (q,k,v,e,out_e,out_n)
-        {12, 4, 4, 2, 16},  // 384 x 128   (fc1: dW[3C, C])
-        {4, 12, 2, 4, 16},  // 128 x 384   (fc2: dW[C, 3C])
+        {4, 4, 2, 2, big ? 64 : 32},   // 128 x 128   (q,k,v,e,out_e,out_n)
+        {12, 4, 4, 2, big ? 32 : 16},  // 384 x 128   (fc1: dW[3C, C])
+        {4, 12, 2, 4, big ? 32 : 16},  // 128 x 384   (fc2: dW[C, 3C])
         {4, 2, 2, 2, 32},   // 128 x 64    (embedding layer 2: Linear(64, C))
         {2, 2, 2, 2, 32},   // 64 x 64
         {1, 1, 1, 1, 32},   // 32 x 32     (tiny test models)
@@ -338,6 +339,7 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
     const int S = wgrad_blocks(R, p, &tpb);
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
+    const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(DG_K_LINEAR_WGRAD, stream);
 #define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                                                     \
     {                                                                                                            \
@@ -354,9 +356,15 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
         if (dy_mask) LAUNCH_M(NT_, KT_, WN_, WK_, TR_, true)              \
         else LAUNCH_M(NT_, KT_, WN_, WK_, TR_, false)                     \
     }
-    LAUNCH(4, 4, 2, 2, 32)
-    LAUNCH(12, 4, 4, 2, 16)
-    LAUNCH(4, 12, 2, 4, 16)
+    if (big_tiles) {
+        LAUNCH(4, 4, 2, 2, 64)
+        LAUNCH(12, 4, 4, 2, 32)
+        LAUNCH(4, 12, 2, 4, 32)
+    } else {
+        LAUNCH(4, 4, 2, 2, 32)
+        LAUNCH(12, 4, 4, 2, 16)
+        LAUNCH(4, 12, 2, 4, 16)
+    }
     LAUNCH(4, 2, 2, 2, 32)
     LAUNCH(2, 2, 2, 2, 32)
     LAUNCH(1, 1, 1, 1, 32)

@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 __all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "inputs_only_backward",
-           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes"]
+           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -35,8 +35,14 @@ def traffic_bytes(kernel: str) -> int:
     return _traffic.get(kernel, 0)
 
 
-def _account(kernel: str, nbytes: int) -> None:
+def _account(kernel: str, nbytes: int, flops: int = 0) -> None:
     _traffic[kernel] = _traffic.get(kernel, 0) + nbytes
+    if flops:
+        _traffic[kernel + ":flops"] = _traffic.get(kernel + ":flops", 0) + flops
+
+
+def traffic_flops(kernel: str) -> int:
+    return _traffic.get(kernel + ":flops", 0)
 
 
 def _dev(t):
@@ -282,8 +288,21 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None):
         ws = _scratch(dy2, need, "wgrad")
         _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
                                        ws.numel(), R, N, K, _lib.stream_of(dy2)), "dg_linear_wgrad")
-    _account("linear_wgrad", 4 * R * (N * (2 if dy_mask is not None else 1) + K))
+    _account("linear_wgrad", 4 * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
     return dw, db
+
+
+def _mm_rows(a, w, mode, bias=None):
+    """a @ w^T (mode 0) or a @ w (mode 1) over the rows of ``a`` on dg_row_gemm when the shape is one
+    of its three, else on the ROCm BLAS (tiny / odd layers: embedding, readout, discriminator head)."""
+    rows, cols = w.shape
+    K, N = (cols, rows) if mode == 0 else (rows, cols)
+    if a.is_cuda and a.dtype == torch.float32 and row_gemm_supported(K, N):
+        out = row_gemm(_c(a).reshape(-1, K), packed_weight(w, mode), K, N, bias=bias)
+        return out.view(*a.shape[:-1], N)
+    if mode == 0:
+        return torch.nn.functional.linear(a, w, bias)
+    return a.matmul(w)
 
 
 class _Linear(Function):
@@ -291,7 +310,7 @@ class _Linear(Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+        return _mm_rows(x, w, 0, b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -306,7 +325,7 @@ class _LinearBwd(Function):
     def forward(ctx, x, w, dy, want_bias, need_x, need_w):
         dy = _c(dy)
         N, K = w.shape
-        dx = dy.matmul(w) if need_x else None
+        dx = _mm_rows(dy, w, 1) if need_x else None
         dw = db = None
         if need_w:
             dw, db = _wgrad(dy.reshape(-1, N), _c(x).reshape(-1, K), want_bias)
@@ -322,7 +341,7 @@ class _LinearBwd(Function):
         g_x = g_w = g_dy = None
         if tdx is not None:
             tdx = _c(tdx)
-            g_dy = torch.nn.functional.linear(tdx, w)
+            g_dy = _mm_rows(tdx, w, 0)
             if not getattr(_tls, "inputs_only", False):
                 g_w, _ = _wgrad(dy.reshape(-1, N), tdx.reshape(-1, K), False)
         if tdw is not None:
@@ -405,7 +424,7 @@ def row_gemm(a2, packed, K, N, bias=None, relu=False, want_relu_bits=False, mask
                                    None if mask_bits is None else mask_bits.data_ptr(), _lib.ptr(residual),
                                    _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
                                    float(eps), _lib.stream_of(a2)), "dg_row_gemm")
-    _account("row_gemm", 4 * R * (K + N * (1 + (residual is not None))))
+    _account("row_gemm", 4 * R * (K + N * (1 + (residual is not None))), 2 * R * K * N)
     if ln is not None:
         return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
     return (y, bits) if want_relu_bits else y
