@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (single GPU)")
+    ap.add_argument("--vertexes", type=int, default=0, help="override N (parity-case shapes; not the headline)")
+    ap.add_argument("--depth", type=int, default=0, help="override L")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(32, logical cores)")
     return ap.parse_args()
@@ -106,9 +109,13 @@ def main():
 
     from druggen_amd import _lib, functional as dgf, synth
     from druggen_amd.model import Discriminator, Generator
-    from druggen_amd.trainer import GANStep, broadcast_parameters
+    from druggen_amd.trainer import GANStep, GraphedGANStep, broadcast_parameters
 
-    w = WORKLOAD
+    w = dict(WORKLOAD)
+    if args.vertexes:
+        w["vertexes"] = args.vertexes
+    if args.depth:
+        w["depth"] = args.depth
     ctor = (w["act"], w["vertexes"], w["edges"], w["nodes"], w["dropout"])
     kw = dict(dim=w["dim"], depth=w["depth"], heads=w["heads"], mlp_ratio=w["mlp_ratio"])
     torch.manual_seed(0)                       # PyTorch default init, on CPU, then moved
@@ -130,15 +137,35 @@ def main():
     losses = None
     for _ in range(args.warmup):
         losses = stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+    run = lambda: stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+    if args.graph and world == 1:
+        graphed = GraphedGANStep(stepper, disc_edge, disc_node, gen_edge, gen_node, warmup=1)
+        run = graphed.step
     _lib.prof_reset()
     dgf.traffic_reset()
-    _lib.prof_enable(True)
+    # timed region: HIP events only around the attention-core launches (the roofline kernel; ~70 per
+    # step) so that the timing of the other ~2 k launches is not perturbed
+    attn_kernels = ("attn_fwd", "attn_bwd", "attn_bwd2")
+    if not args.graph:
+        _lib.prof_enable(kernels=attn_kernels)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+        losses = run()
     sync()
     elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    attn_stats = {k: (_lib.prof_read(k), dgf.traffic_bytes(k)) for k in attn_kernels}
+    # per-kernel table of every HIP kernel: two extra, untimed, fully instrumented steps
+    _lib.prof_reset()
+    dgf.traffic_reset()
+    _lib.prof_enable(True)
+    detail_steps = 2
+    t1 = time.perf_counter()
+    for _ in range(detail_steps):
+        stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+    sync()
+    detail_elapsed = time.perf_counter() - t1
     _lib.prof_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -155,9 +182,10 @@ def main():
             nbytes = dgf.traffic_bytes(name)
             if n:
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                kernels[name] = {"launches": n, "avg_us": 1e3 * ms / n, "algorithmic_MB_per_launch": nbytes / n / 1e6,
+                kernels[name] = {"launches_per_step": n / detail_steps, "avg_us": 1e3 * ms / n,
+                                 "algorithmic_MB_per_launch": nbytes / n / 1e6,
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-                                 "share_of_step": ms * 1e-3 / elapsed}
+                                 "share_of_step": ms * 1e-3 / detail_elapsed}
                 fl = dgf.traffic_flops(name)
                 if fl:          # MFMA-bound kernels: fp32 matrix-core roofline
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -165,7 +193,14 @@ def main():
                                           "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TFLOPS})
                 else:
                     kernels[name]["bound"] = "hbm"
-        dom = kernels.get("attn_fwd", {})
+        (n_f, ms_f), bytes_f = attn_stats["attn_fwd"]
+        dom = {}
+        if n_f and ms_f > 0:        # measured inside the timed region
+            gbs = bytes_f / (ms_f * 1e-3) / 1e9
+            dom = {"achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "launches": n_f,
+                   "avg_us": 1e3 * ms_f / n_f, "algorithmic_MB_per_launch": bytes_f / n_f / 1e6}
+        elif "attn_fwd" in kernels:  # --graph: events cannot sit inside a replayed graph
+            dom = dict(kernels["attn_fwd"])
         traffic = None
         side = os.path.join(ROOT, "profiles", "traffic.json")     # PMC pass (rocprofv3 --pmc), per launch, bytes
         if os.path.exists(side):
@@ -183,10 +218,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DrugGEN default 4-layer/8-head dim128 mlp_ratio3, N=45, E=5, "
                                    "M=13, fp32, full WGAN-GP step (train.py:351-384) incl. gradient penalty + 2x AdamW",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "vertexes": w["vertexes"], "depth": w["depth"], "hip_graph_replay": bool(args.graph and world == 1)},
             "roofline": {"kernel": "attn_core_fwd", "bound": "hbm", "achieved": dom.get("achieved_GBps"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic},
+                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic,
+                         "launches_timed": dom.get("launches"), "avg_us": dom.get("avg_us"),
+                         "algorithmic_bytes_per_launch": None if not dom else dom.get("algorithmic_MB_per_launch", 0) * 1e6},
             "kernels": kernels,
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
         }

@@ -38,6 +38,7 @@ SIGNATURES = {
     "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
     "dg_densify": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dg_adamw_flat": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
+    "dg_adamw_flat_devstep": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     "dg_argmax_decode": (c_int, [_P, c_int64, c_int, _P, _P]),
     "dg_prof_enable": (c_int, [c_int]),
     "dg_prof_reset": (c_int, []),
@@ -99,8 +100,15 @@ def stream_of(t) -> int:
 
 
 # ---- profiler ---------------------------------------------------------------
-def prof_enable(on: bool) -> None:
-    check(load().dg_prof_enable(1 if on else 0), "dg_prof_enable")
+def prof_enable(on=True, kernels=None) -> None:
+    """Enable HIP-event timing for all kernels (``on=True``), none (``False``) or the named ones."""
+    if kernels is not None:
+        mask = 0
+        for k in kernels:
+            mask |= 1 << KERNEL_IDS[k]
+    else:
+        mask = -1 if on else 0
+    check(load().dg_prof_enable(mask), "dg_prof_enable")
 
 
 def prof_reset() -> None:

@@ -71,6 +71,28 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Graph-replay-safe variant: the step count lives in device memory, so a captured launch computes
+// fresh bias corrections on every replay (host-side scalars would be frozen into the graph).
+__global__ void adamw_bump_kernel(int* step) { *step += 1; }
+
+__global__ void adamw_devstep_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                     float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, const int* __restrict__ step) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = static_cast<float>(*step);
+    const float bc1 = 1.0f - powf(beta1, t);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
+    float pp = p[i] * (1.0f - lr * weight_decay);
+    const float gg = g[i];
+    const float mm = beta1 * m[i] + (1.0f - beta1) * gg;
+    const float vv = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+    pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+}
+
 // ---- argmax decode --------------------------------------------------------------------------
 // out[r] = index of the first maximum of logits[r, 0..E) (NaN counts as maximal, like torch.max)
 __global__ void argmax_kernel(const float* __restrict__ logits, int64_t rows, int E, unsigned char* __restrict__ out) {
@@ -126,6 +148,20 @@ extern "C" int dg_adamw_flat(float* param, const float* grad, float* exp_avg, fl
                        static_cast<hipStream_t>(stream_), param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, static_cast<float>(bc1), static_cast<float>(sqrt(bc2)));
     return check_launch("dg_adamw_flat");
+}
+
+extern "C" int dg_adamw_flat_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int* step_counter, dg_stream_t stream_) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter)
+        return fail(DG_E_ARG, "dg_adamw_flat_devstep: null pointer");
+    if (n < 0) return fail(DG_E_ARG, "dg_adamw_flat_devstep: n >= 0 required");
+    if (n == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step_counter);
+    hipLaunchKernelGGL(adamw_devstep_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, param,
+                       grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_counter);
+    return check_launch("dg_adamw_flat_devstep");
 }
 
 extern "C" int dg_argmax_decode(const float* logits, int64_t rows, int E, unsigned char* out, dg_stream_t stream_) {

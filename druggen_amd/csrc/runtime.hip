@@ -32,7 +32,7 @@ struct Span {
     hipEvent_t start, stop;
 };
 std::mutex g_mu;
-bool g_enabled = false;
+unsigned g_mask = 0;   // bit k set: launches of kernel id k are bracketed by events
 std::vector<Span> g_spans;
 std::vector<hipEvent_t> g_free;
 
@@ -50,7 +50,7 @@ hipEvent_t take_event() {
 
 ProfScope::ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), stream(s), slot(nullptr) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_enabled) return;
+    if (!((g_mask >> kernel_id) & 1u)) return;
     Span sp{kernel_id, take_event(), take_event()};
     (void)hipEventRecord(sp.start, stream);
     g_spans.push_back(sp);
@@ -72,9 +72,9 @@ int dg_version(void) { return DG_VERSION; }
 
 const char* dg_last_error_string(void) { return dg::error_buffer(); }
 
-int dg_prof_enable(int on) {
+int dg_prof_enable(int mask) {
     std::lock_guard<std::mutex> lock(dg::g_mu);
-    dg::g_enabled = on != 0;
+    dg::g_mask = static_cast<unsigned>(mask);
     return 0;
 }
 

@@ -26,6 +26,7 @@ class FlatAdamW:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.step_count = 0
+        self.device_step = None     # int32 device counter (graph-replay-safe stepping)
         self._live: Optional[List[int]] = None
         self.flat_param = self.flat_grad = self.exp_avg = self.exp_avg_sq = None
         self._grad_views: List[torch.Tensor] = []
@@ -86,12 +87,15 @@ class FlatAdamW:
             return
         self.step_count += 1
         lib = _lib.load()
+        if self.device_step is None:
+            self.device_step = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=self.flat_param.device)
         with _dev(self.flat_param):
-            _lib.check(lib.dg_adamw_flat(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                         self.flat_param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                         self.weight_decay, self.step_count, _lib.stream_of(self.flat_param)),
-                       "dg_adamw_flat")
+            # step count in device memory: the launch stays correct when captured into a hipGraph
+            _lib.check(lib.dg_adamw_flat_devstep(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+                                                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                 self.flat_param.numel(), self.lr, self.betas[0], self.betas[1],
+                                                 self.eps, self.weight_decay, self.device_step.data_ptr(),
+                                                 _lib.stream_of(self.flat_param)), "dg_adamw_flat_devstep")
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that
         # version-keyed caches (packed GEMM weights) notice, exactly as an in-place torch op would
         torch.autograd.graph.increment_version([self.params[i] for i in self._live])

@@ -156,14 +156,20 @@ int dg_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   dg_stream_t stream);
 
+/* Same update with the step count in device memory (`step_counter`, int32, incremented by the
+ * call): safe to capture into a hipGraph and replay.                                */
+int dg_adamw_flat_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int* step_counter, dg_stream_t stream);
+
 /* dg_argmax_decode: reference inference.py:197-198 `torch.max(x, -1)[1]` on logits
  * [rows, E] -> uint8 labels [rows] (first maximum), so only bytes cross PCIe.      */
 int dg_argmax_decode(const float* logits, int64_t rows, int E, unsigned char* out, dg_stream_t stream);
 
 /* ---- opt-in kernel timing with HIP events (bench.py roofline) ----------------
- * When enabled, every launch of a profiled kernel is bracketed by two events on
- * the caller's stream.  dg_prof_read() synchronises the recorded events and
- * returns the number of launches and their total device time.                    */
+ * dg_prof_enable(mask): bit k of `mask` set = every launch of kernel id k (enum below) is
+ * bracketed by two events on the caller's stream (0 = off, -1 = all).  dg_prof_read()
+ * synchronises the recorded events and returns the launches and their total device time. */
 enum {
     DG_K_ATTN_FWD = 0,
     DG_K_ATTN_BWD = 1,
@@ -175,7 +181,7 @@ enum {
     DG_K_ROW_GEMM = 7,
     DG_K_COUNT = 16
 };
-int dg_prof_enable(int on);
+int dg_prof_enable(int mask);
 int dg_prof_reset(void);
 int dg_prof_read(int kernel_id, int64_t* launches, double* total_ms);
 

@@ -149,3 +149,44 @@ def test_shared_generator_forward_is_exact():
         results.append([p.detach().clone() for p in list(G.parameters()) + list(D.parameters())] + list(losses))
     for a, b in zip(*results):
         assert torch.equal(a, b)
+
+
+def test_graphed_step_equals_eager_step():
+    """Replaying the captured iteration gives the same parameters as running it eagerly."""
+    import cases
+    import harness
+    from druggen_amd.model import Discriminator, Generator, discriminator_loss
+    from druggen_amd.trainer import GANStep, GraphedGANStep
+    case = cases.CASES["c1_b4"]
+    cfg = cases.net_config(case)
+    gp, dp = cases.build_params(case)
+    inp = harness.torch_inputs(case, torch.float32, "cuda")
+    eps = (inp["eps_edge"], inp["eps_node"])
+    fixed_eps = lambda *a, **k: discriminator_loss(*a, **{**k, "eps": eps})   # deterministic eps in both
+    outs = []
+    for graphed in (False, True):
+        args = (cfg.act, cfg.vertexes, cfg.edges, cfg.nodes, cfg.dropout)
+        kw = dict(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, mlp_ratio=cfg.mlp_ratio)
+        G, D = Generator(*args, **kw), Discriminator(*args, **kw)
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in gp.items()})
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+        G, D = G.cuda(), D.cuda()
+        st = GANStep(G, D, lambda_gp=case["lambda_gp"], d_loss_fn=fixed_eps, share_generator_forward=False)
+        batch = (inp["disc_edge"], inp["disc_node"], inp["gen_edge"], inp["gen_node"])
+        if graphed:
+            gs = GraphedGANStep(st, *batch, warmup=2)       # 2 warm-up + 1 captured(not run) ...
+            for _ in range(2):
+                gs.step(*batch)
+        else:
+            for _ in range(4):
+                st.step(*batch)
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in list(G.parameters()) + list(D.parameters())])
+    # 4 AdamW steps of size lr = 1e-5: a first-step Adam update is ~ lr * sign(g), so an element whose
+    # gradient is rounding noise may differ by a few lr between two runs that pick different BLAS
+    # kernels (capture vs eager); everything else must agree to rounding.
+    worst, mean = 0.0, 0.0
+    for a, b in zip(*outs):
+        d = (a - b).abs()
+        worst, mean = max(worst, d.max().item()), mean + d.mean().item() / len(outs[0])
+    assert worst <= 8.5e-5 and mean <= 2e-6, (worst, mean)

@@ -181,7 +181,7 @@ def test_deep_variant_shape_matches_oracle():
     d_loss.backward()
     _, _, od = orc.discriminator_loss(OG, OD, t64(da), t64(dx), t64(a), t64(x), 10.0, t64(ee), t64(en))
     od.backward()
-    harness.compare_scalar(d_loss, float(od), TOL_OUT, "d_loss")
+    harness.compare_scalar(d_loss, float(od.detach()), TOL_OUT, "d_loss")
     want = dict(zip(OD.names, OD.flat))
     tot = torch.sqrt(sum((p.grad ** 2).sum() for p in OD.flat if p.grad is not None)).item()
     live = [k for k, p in want.items() if p.grad is not None]
