@@ -90,7 +90,7 @@ __device__ __forceinline__ float half_sum(float x) {
 // 16-byte chunk index XOR-ed by (row & 15) inside every 512-byte segment (applied on the per-lane
 // SOURCE address, the DMA destination is lane-linear), which makes the ds_read_b128 fragment
 // reads bank-conflict free without padding.
-template <int KC, int NG, int MG, int TR, bool EXCH, bool PIPE, int MINW>
+template <int KC, int NG, int MG, int TR, bool EXCH, bool PIPE, int MINW, bool XPIPE = false>
 __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const float* __restrict__ a,
                                                                 const float* __restrict__ packed,
                                                                 float* __restrict__ y, int64_t R, Epilogue ep) {
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
     static_assert(!EXCH || (NG == 1 && MG == 1), "exchange epilogue needs the whole tile in one group");
     static_assert(TR % (32 * MG) == 0, "tile rows must split evenly over the row groups");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* lds = reinterpret_cast<float*>(smem_raw);   // [2][TR*K]
+    float* lds = reinterpret_cast<float*>(smem_raw);   // [2][TR*K] (+ [TR][128] exchange tile when XPIPE)
+    float* xtile = lds + 2 * TR * K;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wq = w & 3, g = (w >> 2) % NG, mg = (w >> 2) / NG;
@@ -139,6 +140,44 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
         if (row < R) y[row * N + n] = v;
     };
 
+    // exchange-epilogue helpers (EXCH): the wave's accumulators go to a [TR][128] LDS tile, then every
+    // half-wave finalises whole rows (residual add, optional LayerNorm, 512 B stores)
+    auto exch_write = [&](float* ex, const f32x16 (&acc)[MT], int m, int reg) {
+        const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        float v = acc[m][reg] + bias;
+        if (ep.relu) v = fmaxf(v, 0.f);
+        ex[rr * 128 + 32 * wq + col] = v;
+    };
+    auto exch_row = [&](const float* ex, int64_t r0, int it, float4 res) {
+        const int rr = wq * (TR / 4) + it * 2 + half;
+        const int64_t row = r0 + rr;
+        const bool ok = row < R;
+        float4 v = ld4(ex + rr * 128 + col * 4);
+        if (ep.residual) v += res;
+        if (ep.gamma == nullptr) {
+            if (ok) st4(y + row * N + col * 4, v);
+            return;
+        }
+        if (ep.pre && ok) st4(ep.pre + row * N + col * 4, v);
+        const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+        const float4 d = v - f4(mu);
+        const float var = half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+        const float rs = rsqrtf(var + ep.eps);
+        if (ok) {
+            st4(y + row * N + col * 4, fma4(rs * d, ld4(ep.gamma + col * 4), ld4(ep.beta + col * 4)));
+            if (col == 0) {
+                ep.mean[row] = mu;
+                ep.rstd[row] = rs;
+            }
+        }
+    };
+    auto load_res = [&](int64_t r0, int it) {
+        int64_t row = r0 + wq * (TR / 4) + it * 2 + half;
+        if (row >= R) row = R - 1;
+        return ep.residual ? ld4(ep.residual + row * N + col * 4) : f4(0.f);
+    };
+    float4 resP[TR / 8], resN[TR / 8];   // XPIPE: residual rows of the previous / current tile
+
     wait_all_vmem_visible();   // B fragments and bias are in registers (and the compiler knows it)
     int64_t tix = blockIdx.x;
     if (tix < tiles) dma_tile(tix, 0);
@@ -153,6 +192,10 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
         if (!EXCH && PIPE && tixP >= 0 && ep.mask_bits) {
             bitsP = ep.mask_bits[(tixP * WAVES + w) * 64 + lane];
             wait_all_vmem_visible();      // issued before this tile's DMA: does not wait for it
+        }
+        if (EXCH && XPIPE) {   // issued before the DMA: the end-of-phase vmcnt(0) covers them
+#pragma unroll
+            for (int it = 0; it < TR / 8; ++it) resN[it] = load_res(r0, it);
         }
         if (tix + gridDim.x < tiles) dma_tile(tix + gridDim.x, buf ^ 1);
         const float* at = lds + buf * (TR * K);
@@ -186,6 +229,19 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[kc][q].z, acc[m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[kc][q].w, acc[m], 0, 0, 0);
+            if (EXCH && XPIPE && tixP >= 0) {
+                // previous tile's exchange epilogue rides inside this tile's MFMA phase:
+                // steps 0..3 scatter the old accumulators into the exchange tile, a barrier, then one
+                // row pair per step is finalised; everything is issued in the first half of the phase
+                constexpr int WR = 16 * MT / 4;
+                if (st < 4) {
+#pragma unroll
+                    for (int i = 0; i < WR; ++i) exch_write(xtile, accP, (st * WR + i) / 16, (st * WR + i) % 16);
+                    if (st == 3) __syncthreads();
+                } else if (st - 4 < TR / 8) {
+                    exch_row(xtile, r0P, st - 4, resP[st - 4]);
+                }
+            }
             if (!EXCH && PIPE) {
                 // previous tile's stores ride in the shadow of this tile's MFMAs (first steps only, so
                 // they have drained by the time the DMA wait below needs vmcnt == 0)
@@ -218,6 +274,14 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
                 for (int reg = 0; reg < 16; ++reg) store_reg(acc, r0, bits, m, reg, nb);
             if (ep.relu_bits) ep.relu_bits[(tix * WAVES + w) * 64 + lane] = nb;
             __syncthreads();
+        } else if (XPIPE) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) accP[m] = acc[m];
+#pragma unroll
+            for (int it = 0; it < TR / 8; ++it) resP[it] = resN[it];
+            r0P = r0;
+            tixP = tix;
+            __syncthreads();   // DMA(t+1) landed everywhere, tile t read, exchange tile consumed
         } else {
             float* ex = lds + buf * (TR * K);   // consumed A buffer becomes the [TR][128] exchange tile
             __syncthreads();                    // all waves finished their fragment reads
@@ -266,6 +330,15 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
             }
             __syncthreads();   // exchange tile consumed before the next DMA overwrites it
         }
+    }
+    if (EXCH && XPIPE && tixP >= 0) {   // drain: exchange epilogue of the last tile (block-uniform)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) exch_write(xtile, accP, m, reg);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < TR / 8; ++it) exch_row(xtile, r0P, it, resP[it]);
     }
     if (!EXCH && PIPE && tixP >= 0) {   // drain: epilogue of the last tile
         unsigned bitsP = ep.mask_bits ? ep.mask_bits[(tixP * WAVES + w) * 64 + lane] : 0u, newbits = 0;
@@ -325,16 +398,17 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Epilogue ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
     ProfScope prof(DG_K_ROW_GEMM, stream);
-#define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_)                                                     \
+#define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_) LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, false)
+#define LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, XP_)                                               \
     {                                                                                                              \
-        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4;                                                         \
+        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4 + (XP_ ? TR_ * 128 * 4 : 0);                             \
         static const hipError_t attr = hipFuncSetAttribute(                                                        \
-            reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_>),                \
+            reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>),           \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                                \
         (void)attr;                                                                                                \
         const int64_t tiles = (R + TR_ - 1) / TR_;                                                                 \
         const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                          \
-        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_>), dim3(grid),                   \
+        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>), dim3(grid),              \
                            dim3(NG_ * MG_ * 256), lds_bytes, stream, a, packed, y, R, ep);                         \
     }
     static const int variant = getenv("DG_GEMM_VARIANT") ? atoi(getenv("DG_GEMM_VARIANT")) : 0;
@@ -345,8 +419,11 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
     } else if (K == 128 && N == 384) {
         LAUNCH(1, 3, 1, 32, false, true, 1, 1)
     } else {
-        LAUNCH(3, 1, 1, 32, true, false, 1, 1)
+        if (!exch) LAUNCH(3, 1, 1, 32, false, true, 1, 1)             /* plain: pipelined direct stores */
+        else if (variant == 2) LAUNCH(3, 1, 1, 32, true, false, 1, 1)  /* unpipelined exchange (A/B testing) */
+        else LAUNCHX(3, 1, 1, 32, true, false, 1, 1, true)
     }
 #undef LAUNCH
+#undef LAUNCHX
     return check_launch("dg_row_gemm");
 }
