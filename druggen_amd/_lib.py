@@ -36,6 +36,11 @@ SIGNATURES = {
     "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "dg_row_gemm_mask_words": (c_size_t, [c_int64, c_int, c_int]),
     "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
+    "dg_embed_sym_packed_floats": (c_size_t, []),
+    "dg_embed_sym_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dg_embed_sym_pack": (c_int, [_P, _P, _P]),
+    "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
+    "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 6 + [_P]),
     "dg_densify": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dg_adamw_flat": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "dg_adamw_flat_devstep": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P]),
@@ -45,7 +50,7 @@ SIGNATURES = {
     "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7}
+KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8}
 
 _lock = threading.Lock()
 _lib = None

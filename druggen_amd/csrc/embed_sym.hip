@@ -1,0 +1,429 @@
+// Edge embedding + symmetrisation of Generator / Discriminator (reference
+// src/model/models.py:57-61,92-94 and :159-163,197-199):
+//
+//     f(z)   = act( W2 . act( W1 . z + b1 ) + b2 )          Linear(E,64) - act - Linear(64,C) - act
+//     out_ij = ( f(a_ij) + f(a_ji) ) / 2                    (edge + edge.permute(0,2,1,3)) / 2
+//
+// One fused kernel per direction.  A workgroup owns a tile of 32 atom PAIRS {i <= j} of one
+// molecule = 64 edge rows: rows 0..31 hold the (i,j) orientation, rows 32..63 the transposed (j,i)
+// one.  After the MFMA stage the two orientations of a pair sit in the SAME accumulator slot of the
+// two 32-row blocks, so the symmetrisation (and, in the backward, the symmetrised upstream
+// gradient) is register arithmetic; both output rows are written from there.  Layer 1 (E <= 16
+// inputs) is VALU work, layer 2 (64 -> C=128) runs on v_mfma_f32_32x32x2_f32 with the packed weight
+// fragments resident in VGPRs; the hidden tile lives in LDS (XOR-swizzled, conflict-free b128
+// fragment reads).  Nothing but the inputs is saved: the backward recomputes both layers.
+#include "common.h"
+
+namespace dg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHid = 64;     // hidden width of the embedding MLP (fixed by the reference)
+constexpr int kC = 128;      // output width handled by this kernel
+constexpr int kPairs = 32;   // atom pairs per tile
+constexpr int kMaxE = 16;
+
+enum Act { kRelu = 0, kLeaky = 1, kSigmoid = 2, kTanh = 3 };
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case kRelu: return fmaxf(x, 0.f);
+        case kLeaky: return x > 0.f ? x : 0.01f * x;
+        case kSigmoid: return 1.0f / (1.0f + __expf(-x));
+        default: return tanhf(x);
+    }
+}
+// derivative expressed through the OUTPUT y = act(x)
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+    switch (act) {
+        case kRelu: return y > 0.f ? 1.f : 0.f;
+        case kLeaky: return y > 0.f ? 1.f : 0.01f;
+        case kSigmoid: return y * (1.f - y);
+        default: return 1.f - y * y;
+    }
+}
+
+// packed W2 for K = 64: P[(t*8 + q)*64 + lane] = { W2[32t + n][32h + 4q + j] }_j, n = lane&31, h = lane>>5
+__global__ void pack_w2_k64_kernel(const float* __restrict__ w2, float* __restrict__ p, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (C / 32) * 8 * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63, q = (idx >> 6) & 7, t = idx >> 9;
+    const float* src = w2 + static_cast<size_t>(32 * t + (lane & 31)) * kHid + 32 * (lane >> 5) + 4 * q;
+    st4(p + static_cast<size_t>(idx) * 4, ld4(src));
+}
+
+struct PairTile {
+    int b;        // molecule
+    int p0;       // first pair of the tile
+};
+
+// pair index p (0 <= p < N(N+1)/2, row-major over i <= j) -> (i, j)
+__device__ __forceinline__ void pair_to_ij(int p, int N, int* i_out, int* j_out) {
+    int i = 0;
+    while (p >= N - i) {
+        p -= N - i;
+        ++i;
+    }
+    *i_out = i;
+    *j_out = i + p;
+}
+
+template <bool BACKWARD>
+struct Smem {
+    int ij[kPairs][2];
+    float a[64][kMaxE];
+    float h1[64 * kHid];                          // swizzled [row][64]
+};
+
+// Stage the pair table, the input rows and the layer-1 activations of one tile.
+__device__ __forceinline__ void stage_tile(const float* __restrict__ a, const float* __restrict__ w1,
+                                           const float* __restrict__ b1, int act, int N, int E, int NP, PairTile t,
+                                           int (*ij)[2], float (*at)[kMaxE], float* h1) {
+    const int tid = threadIdx.x;
+    if (tid < kPairs) {
+        const int p = t.p0 + tid;
+        int i = 0, j = 0;
+        if (p < NP) pair_to_ij(p, N, &i, &j);
+        ij[tid][0] = p < NP ? i : -1;
+        ij[tid][1] = j;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * kMaxE; idx += 256) {
+        const int row = idx / kMaxE, e = idx % kMaxE;
+        const int pr = row & 31;
+        const int i = ij[pr][0], j = ij[pr][1];
+        float v = 0.f;
+        if (i >= 0 && e < E) {
+            const int64_t r = (static_cast<int64_t>(t.b) * N + (row < 32 ? i : j)) * N + (row < 32 ? j : i);
+            v = a[r * E + e];
+        }
+        at[row][e] = v;
+    }
+    __syncthreads();
+    // layer 1: thread = (unit u, row group g of 16 rows)
+    const int u = tid & 63, g = tid >> 6;
+    float w[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) w[e] = e < E ? w1[u * E + e] : 0.f;
+    const float bb = b1[u];
+    for (int r = 0; r < 16; ++r) {
+        const int row = g * 16 + r;
+        float s = bb;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) s = fmaf(w[e], at[row][e], s);
+        h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)] = act_fwd(s, act);
+    }
+    __syncthreads();
+}
+
+// layer 2 on the MFMA: this wave's 32-column slab for both orientations
+__device__ __forceinline__ void layer2_mfma(const float* h1, const float4 (&bf)[8], f32x16& acc0, f32x16& acc1) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 a0 = ld4(h1 + col * kHid + (((8 * half + q) ^ (col & 15)) << 2));
+        const float4 a1 = ld4(h1 + (32 + col) * kHid + (((8 * half + q) ^ (col & 15)) << 2));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf[q].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf[q].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf[q].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf[q].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf[q].w, acc1, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1,
+                                                          const float* __restrict__ w2p,
+                                                          const float* __restrict__ b2, float* __restrict__ out,
+                                                          int B, int N, int E, int act, int tiles_per_mol) {
+    __shared__ int ij[kPairs][2];
+    __shared__ float at[64][kMaxE];
+    __shared__ __attribute__((aligned(16))) float h1[64 * kHid];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int NP = N * (N + 1) / 2;
+    float4 bf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lane) * 4);
+    const int n = 32 * w + col;
+    const float bias2 = b2[n];
+    const int total = B * tiles_per_mol;
+    for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
+        const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
+        stage_tile(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        f32x16 acc0, acc1;
+        layer2_mfma(h1, bf, acc0, acc1);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const int i = ij[pr][0], j = ij[pr][1];
+            if (i < 0) continue;
+            const float s = 0.5f * (act_fwd(acc0[reg] + bias2, act) + act_fwd(acc1[reg] + bias2, act));
+            const int64_t base = static_cast<int64_t>(t.b) * N;
+            out[((base + i) * N + j) * kC + n] = s;
+            out[((base + j) * N + i) * kC + n] = s;
+        }
+        __syncthreads();   // LDS tiles are reused by the next iteration
+    }
+}
+
+// ------------------------------------------------------------------------------- backward ----
+// g = dL/d out [B,N,N,C].  gs = (g_ij + g_ji)/2 reaches BOTH orientations of a pair.
+//   dpre2 = gs * act'(f)                 (f recomputed)          db2 += sum_rows dpre2
+//   dW2  += dpre2^T h1                   (MFMA, contraction over the tile rows)
+//   dh1   = dpre2 W2                     (MFMA, contraction over C)
+//   dpre1 = dh1 * act'(h1)               db1 += sum_rows dpre1,  dW1 += dpre1^T a
+//   da    = dpre1 W1                     (optional: only when the input requires a gradient)
+// Per-workgroup partial sums go to `part`, reduced afterwards in a fixed order.
+struct BwdPart {
+    // floats per workgroup: dW2 [128*64] | db2 [128] | dW1 [64*16] | db1 [64]
+    static constexpr int kW2 = 0, kB2 = kC * kHid, kW1 = kB2 + kC, kB1 = kW1 + kHid * kMaxE, kTotal = kB1 + kHid;
+};
+
+__global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
+    const float* __restrict__ g, float* __restrict__ da, float* __restrict__ part, int B, int N, int E, int act,
+    int tiles_per_mol) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* h1 = reinterpret_cast<float*>(smem_raw);                 // [64][64] swizzled
+    float* d2 = h1 + 64 * kHid;                                      // dpre2, swizzled [64][128]
+    float* d1 = d2 + 64 * kC;                                        // dpre1 [64][65]
+    float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(d1 + 64 * (kHid + 1));
+    int(*ij)[2] = reinterpret_cast<int(*)[2]>(&at[64][0]);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int NP = N * (N + 1) / 2;
+    // weight fragments are re-read per tile (L2 hits) instead of pinning 96 VGPRs for the whole kernel
+    const int ut = w & 1, mt = w >> 1;   // dgrad: output tile ut (32 hidden units), row block mt
+    const int n = 32 * w + col;
+    const float bias2 = b2[n];
+    f32x16 aw2[2];                       // dW2 tiles (n tile w) x (unit tile 0,1)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aw2[0][i] = aw2[1][i] = 0.f;
+    float ab2 = 0.f, ab1 = 0.f, aw1[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) aw1[e] = 0.f;
+    const int total = B * tiles_per_mol;
+    for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
+        const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
+        stage_tile(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        f32x16 acc0, acc1;
+        {
+            float4 bf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lane) * 4);
+            layer2_mfma(h1, bf, acc0, acc1);
+        }
+        // dpre2 in the accumulator layout -> LDS (swizzled like a row-GEMM A tile)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const int i = ij[pr][0], j = ij[pr][1];
+            float p0 = 0.f, p1 = 0.f;
+            if (i >= 0) {
+                const int64_t base = static_cast<int64_t>(t.b) * N;
+                float gs = 0.5f * (g[((base + i) * N + j) * kC + n] + g[((base + j) * N + i) * kC + n]);
+                if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
+                p0 = gs * act_grad_from_output(act_fwd(acc0[reg] + bias2, act), act);
+                p1 = gs * act_grad_from_output(act_fwd(acc1[reg] + bias2, act), act);
+            }
+            ab2 += p0 + p1;
+            const int c = n >> 2;
+            d2[pr * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p0;
+            d2[(32 + pr) * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p1;
+        }
+        __syncthreads();
+        // dW2 += dpre2^T h1 : contraction over the 64 tile rows, operands by ds_read_b32
+#pragma unroll 4
+        for (int ks = 0; ks < 32; ++ks) {
+            const int r = 2 * ks + half;
+            const int c = n >> 2;
+            const float av = d2[r * kC + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2) + (n & 3)];
+            const float b0 = h1[r * kHid + ((((col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+            const float b1v = h1[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+            aw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, aw2[0], 0, 0, 0);
+            aw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, aw2[1], 0, 0, 0);
+        }
+        // dh1 = dpre2 W2 for (row block mt, unit tile ut); dpre1 = dh1 * act'(h1)
+        f32x16 dh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * mt + col;
+            const float4 bd = ld4(w2d + (static_cast<size_t>(ut * 16 + q) * 64 + lane) * 4);
+            const float4 av = ld4(d2 + row * kC + (((16 * half + q) ^ (col & 15)) << 2));
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bd.x, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bd.y, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bd.z, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bd.w, dh, 0, 0, 0);
+        }
+        const int u = 32 * ut + col;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const float hv = h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)];
+            const float p = dh[reg] * act_grad_from_output(hv, act);
+            ab1 += p;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e)
+                if (e < E) aw1[e] = fmaf(p, at[row][e], aw1[e]);
+            if (da) d1[row * (kHid + 1) + u] = p;
+        }
+        if (da) {
+            __syncthreads();
+            for (int idx = tid; idx < 64 * E; idx += 256) {
+                const int row = idx / E, e = idx % E;
+                const int pr = row & 31;
+                const int i = ij[pr][0], j = ij[pr][1];
+                if (i < 0 || (row >= 32 && i == j)) continue;      // diagonal: written once below
+                float s = 0.f;
+                for (int uu = 0; uu < kHid; ++uu) s = fmaf(d1[row * (kHid + 1) + uu], w1[uu * E + e], s);
+                if (i == j) {                                       // both blocks carry half of it
+                    float s2 = 0.f;
+                    for (int uu = 0; uu < kHid; ++uu) s2 = fmaf(d1[(32 + pr) * (kHid + 1) + uu], w1[uu * E + e], s2);
+                    s += s2;
+                }
+                const int64_t r = (static_cast<int64_t>(t.b) * N + (row < 32 ? i : j)) * N + (row < 32 ? j : i);
+                da[r * E + e] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- workgroup partials ----------------------------------------------------------------
+    float* pw = part + static_cast<size_t>(blockIdx.x) * BwdPart::kTotal;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int nn = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            pw[BwdPart::kW2 + nn * kHid + 32 * t2 + col] = aw2[t2][reg];
+        }
+    // db2: lanes of the two halves hold the same column
+    ab2 += __shfl_xor(ab2, 32, 64);
+    if (half == 0) pw[BwdPart::kB2 + n] = ab2;
+    // dW1 / db1: unit u = 32*ut + col is held by 2 half-waves x 2 row blocks (waves ut and ut+2)
+    __syncthreads();
+    float* red = d2;   // [4 waves][2 halves][32 cols][kMaxE + 1]
+    {
+        float* slot = red + ((w * 2 + half) * 32 + col) * (kMaxE + 1);
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) slot[e] = aw1[e];
+        slot[kMaxE] = ab1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kHid * (kMaxE + 1); idx += 256) {
+        const int uu = idx / (kMaxE + 1), e = idx % (kMaxE + 1);
+        const int utile = uu >> 5, c = uu & 31;
+        float s = 0.f;
+        for (int mm = 0; mm < 2; ++mm)
+            for (int hh = 0; hh < 2; ++hh) s += red[(((utile + 2 * mm) * 2 + hh) * 32 + c) * (kMaxE + 1) + e];
+        if (e < kMaxE)
+            pw[BwdPart::kW1 + uu * kMaxE + e] = s;
+        else
+            pw[BwdPart::kB1 + uu] = s;
+    }
+}
+
+// out[i] = sum_s part[s][i] (fixed order)
+__global__ __launch_bounds__(256) void embed_reduce_kernel(const float* __restrict__ part, int S, int n,
+                                                         float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < S; ++p) s += part[static_cast<size_t>(p) * n + i];
+    out[i] = s;
+}
+
+// scatter the reduced [dW2 | db2 | dW1(16-padded) | db1] vector into the caller's tensors
+__global__ void embed_unpack_kernel(const float* __restrict__ red, float* __restrict__ dw1, float* __restrict__ db1,
+                                    float* __restrict__ dw2, float* __restrict__ db2, int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kC * kHid) dw2[i] = red[BwdPart::kW2 + i];
+    if (i < kC) db2[i] = red[BwdPart::kB2 + i];
+    if (i < kHid * E) dw1[i] = red[BwdPart::kW1 + (i / E) * kMaxE + (i % E)];
+    if (i < kHid) db1[i] = red[BwdPart::kB1 + i];
+}
+
+int embed_grid(int total_tiles, int per_cu) {
+    const int cap = 256 * per_cu;
+    return total_tiles < cap ? (total_tiles < 1 ? 1 : total_tiles) : cap;
+}
+
+bool embed_shape_ok(int N, int E, int H, int C, int act) {
+    return N >= 1 && E >= 1 && E <= kMaxE && H == kHid && C == kC && act >= 0 && act <= 3;
+}
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" size_t dg_embed_sym_packed_floats(void) { return static_cast<size_t>(kC / 32) * 8 * 64 * 4; }
+
+extern "C" size_t dg_embed_sym_workspace_bytes(int B, int N) {
+    const int tiles = B * ((N * (N + 1) / 2 + kPairs - 1) / kPairs);
+    return (static_cast<size_t>(embed_grid(tiles, 1)) + 1) * BwdPart::kTotal * sizeof(float);
+}
+
+extern "C" int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream_) {
+    if (!w2 || !packed) return fail(DG_E_ARG, "dg_embed_sym_pack: null pointer");
+    const int total = (kC / 32) * 8 * 64;
+    hipLaunchKernelGGL(pack_w2_k64_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), w2,
+                       packed, kC);
+    return check_launch("dg_embed_sym_pack");
+}
+
+extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
+                                const float* b2, float* out, int B, int N, int E, int H, int C, int act,
+                                dg_stream_t stream_) {
+    if (!a || !w1 || !b1 || !w2_packed || !b2 || !out) return fail(DG_E_ARG, "dg_embed_sym_fwd: null pointer");
+    if (B < 0 || !embed_shape_ok(N, E, H, C, act))
+        return fail(DG_E_SHAPE, "dg_embed_sym_fwd: unsupported N=%d E=%d H=%d C=%d act=%d (need E<=16, H=64, C=128)", N, E,
+                    H, C, act);
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
+    ProfScope prof(DG_K_EMBED_SYM, stream);
+    hipLaunchKernelGGL(embed_sym_fwd_kernel, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1, w2_packed, b2,
+                       out, B, N, E, act, tpm);
+    return check_launch("dg_embed_sym_fwd");
+}
+
+extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
+                                const float* w2_dgrad_packed, const float* b2, const float* g, float* da, float* dw1,
+                                float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int B,
+                                int N, int E, int H, int C, int act, dg_stream_t stream_) {
+    if (!a || !w1 || !b1 || !w2_packed || !w2_dgrad_packed || !b2 || !g || !dw1 || !db1 || !dw2 || !db2 || !workspace)
+        return fail(DG_E_ARG, "dg_embed_sym_bwd: null pointer");
+    if (B < 1 || !embed_shape_ok(N, E, H, C, act))
+        return fail(DG_E_SHAPE, "dg_embed_sym_bwd: unsupported B=%d N=%d E=%d H=%d C=%d act=%d", B, N, E, H, C, act);
+    if (workspace_bytes < dg_embed_sym_workspace_bytes(B, N))
+        return fail(DG_E_WORKSPACE, "dg_embed_sym_bwd: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
+    const int grid = embed_grid(B * tpm, 1);
+    float* part = static_cast<float*>(workspace);
+    float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
+    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)attr;
+    ProfScope prof(DG_K_EMBED_SYM, stream);
+    hipLaunchKernelGGL(embed_sym_bwd_kernel, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
+                       w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
+    hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
+                       BwdPart::kTotal, red);
+    hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,
+                       E);
+    return check_launch("dg_embed_sym_bwd");
+}

@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "inputs_only_backward",
+__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
@@ -702,3 +702,88 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
     else:
         out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
     return out if need_edge else (out, None)
+
+
+# --------------------------------------------------------------------------
+# edge embedding MLP + symmetrisation (reference models.py:57-61,92-94 / 159-163,197-199)
+# --------------------------------------------------------------------------
+_ACT_IDS = {"relu": 0, "leaky": 1, "sigmoid": 2, "tanh": 3}
+_ACT_FNS = {"relu": torch.relu, "leaky": lambda t: torch.nn.functional.leaky_relu(t, 0.01),
+            "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+_embed_pack_cache = {}
+
+
+def _embed_packed_w2(w2):
+    key = id(w2)
+    hit = _embed_pack_cache.get(key)
+    if hit is not None and hit[0]() is w2 and hit[1] == w2._version and hit[3] == w2.data_ptr():
+        return hit[2]
+    lib = _lib.load()
+    packed = torch.empty(int(lib.dg_embed_sym_packed_floats()), dtype=torch.float32, device=w2.device)
+    wd = _c(w2.detach())
+    with _dev(w2):
+        _lib.check(lib.dg_embed_sym_pack(_lib.ptr(wd), _lib.ptr(packed), _lib.stream_of(w2)), "dg_embed_sym_pack")
+    _embed_pack_cache[key] = (weakref.ref(w2), w2._version, packed, w2.data_ptr())
+    return packed
+
+
+def _composite_embed_sym(a, w1, b1, w2, b2, act):
+    f = _ACT_FNS[act]
+    h = f(linear(a, w1, b1))
+    e = f(linear(h, w2, b2))
+    return (e + e.permute(0, 2, 1, 3)) / 2
+
+
+class _EmbedSym(Function):
+    @staticmethod
+    def forward(ctx, a, w1, b1, w2, b2, act):
+        a = _c(a)
+        B, N, _, E = a.shape
+        H, C = w1.shape[0], w2.shape[0]
+        lib = _lib.load()
+        out = torch.empty(B, N, N, C, dtype=torch.float32, device=a.device)
+        with _dev(a):
+            _lib.check(lib.dg_embed_sym_fwd(_lib.ptr(a), _lib.ptr(_c(w1)), _lib.ptr(_c(b1)), _lib.ptr(_embed_packed_w2(w2)),
+                                            _lib.ptr(_c(b2)), _lib.ptr(out), B, N, E, H, C, _ACT_IDS[act],
+                                            _lib.stream_of(a)), "dg_embed_sym_fwd")
+        _account("embed_sym", 4 * B * N * N * (E + C), 2 * B * N * N * (E * H + H * C))
+        ctx.save_for_backward(a, w1, b1, w2, b2)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w1, b1, w2, b2 = ctx.saved_tensors
+        act = ctx.act
+        if torch.is_grad_enabled():
+            return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act), (a, w1, b1, w2, b2), g) + (None,)
+        B, N, _, E = a.shape
+        H, C = w1.shape[0], w2.shape[0]
+        lib = _lib.load()
+        g = _c(g)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+        need = int(lib.dg_embed_sym_workspace_bytes(B, N))
+        with _dev(a):
+            ws = _scratch(a, need, "embed")
+            _lib.check(lib.dg_embed_sym_bwd(_lib.ptr(a), _lib.ptr(_c(w1)), _lib.ptr(_c(b1)),
+                                            _lib.ptr(_embed_packed_w2(w2)), _lib.ptr(packed_weight(w2, 1)),
+                                            _lib.ptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
+                                            _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
+                                            _ACT_IDS[act], _lib.stream_of(a)), "dg_embed_sym_bwd")
+        _account("embed_sym", 4 * B * N * N * (E * (2 if da is not None else 1) + C),
+                 2 * B * N * N * (E * H + H * C) * 3)
+        if not ctx.needs_input_grad[1] or getattr(_tls, "inputs_only", False):
+            dw1 = db1 = dw2 = db2 = None
+        return da, dw1, db1, dw2, db2, None
+
+
+def embed_sym(a, w1, b1, w2, b2, act: str):
+    """(f(a) + f(a)^T(i<->j)) / 2 with f = act(W2 act(W1 a + b1) + b2): the edge embedding MLP and the
+    symmetrisation of Generator / Discriminator in one kernel per direction (hidden 64, dim 128)."""
+    ok = (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape[1] == a.shape[2] and act in _ACT_IDS
+          and a.shape[-1] <= 16 and tuple(w1.shape) == (64, a.shape[-1]) and tuple(w2.shape) == (128, 64)
+          and b1 is not None and b2 is not None)
+    if not ok or in_second_order_forward():
+        return _composite_embed_sym(a, w1, b1, w2, b2, act)
+    return _EmbedSym.apply(a, w1, b1, w2, b2, act)

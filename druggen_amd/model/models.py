@@ -31,6 +31,7 @@ class _Trunk(nn.Module):
         self.TransformerEncoder = TransformerEncoder(dim=dim, depth=depth, heads=heads, act=act,
                                                      mlp_ratio=mlp_ratio, drop_rate=dropout)
         self._act = act
+        self._act_name = {nn.ReLU: "relu", nn.LeakyReLU: "leaky", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh"}.get(type(act))
 
     def _embed(self, seq, z):
         """Linear(in,64) - act - Linear(64,dim) - act - Dropout (models.py:52-61); the
@@ -44,8 +45,13 @@ class _Trunk(nn.Module):
             raise RuntimeError("druggen_amd modules run on MI355X only (no CPU fallback): move the model and "
                                "its inputs to a GPU device")
         node = self._embed(self.node_layers, z_n)
-        edge = self._embed(self.edge_layers, z_e)
-        edge = (edge + edge.permute(0, 2, 1, 3)) / 2
+        el = self.edge_layers
+        if self._act_name is not None and not (self.training and self.dropout > 0.0):
+            # Linear(E,64) - act - Linear(64,dim) - act - symmetrise: one kernel (dg_embed_sym_fwd)
+            edge = dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name)
+        else:
+            edge = self._embed(el, z_e)
+            edge = (edge + edge.permute(0, 2, 1, 3)) / 2
         return self.TransformerEncoder(node, edge, need_edge)
 
 

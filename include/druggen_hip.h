@@ -141,6 +141,25 @@ int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K,
                 const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                 float eps, dg_stream_t stream);
 
+/* ---- edge embedding + symmetrisation: src/model/models.py:57-61,92-94 (Generator) and
+ * :159-163,197-199 (Discriminator) ---------------------------------------------------
+ *   f(z) = act(W2.act(W1.z + b1) + b2),  out[b,i,j,:] = (f(a[b,i,j,:]) + f(a[b,j,i,:])) / 2
+ * a: [B,N,N,E] (E <= 16), w1: [64,E], w2: [128,64] given in the fragment order made by
+ * dg_embed_sym_pack (forward) and dg_row_gemm_pack(w2,128,64,mode 1) (backward), out / g:
+ * [B,N,N,128]; act: 0 relu, 1 leaky(0.01), 2 sigmoid, 3 tanh (models.py:39-46).
+ * The backward recomputes both layers (nothing but the inputs is saved) and returns
+ * da (may be NULL when the input needs no gradient), dw1, db1, dw2, db2.            */
+size_t dg_embed_sym_packed_floats(void);
+size_t dg_embed_sym_workspace_bytes(int B, int N);
+int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream);
+int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed, const float* b2,
+                     float* out, int B, int N, int E, int H, int C, int act, dg_stream_t stream);
+int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
+                     const float* w2_dgrad_packed, const float* b2, const float* g,
+                     float* da, float* dw1, float* db1, float* dw2, float* db2,
+                     void* workspace, size_t workspace_bytes,
+                     int B, int N, int E, int H, int C, int act, dg_stream_t stream);
+
 /* ---- the steps either side of the path -------------------
  * dg_densify: reference src/data/utils.py:128-137 -- PyG to_dense_adj (scatter-ADD
  * of edge_attr at [b = u/N, u%N, v%N]; every graph is padded to N nodes) followed by
@@ -179,6 +198,7 @@ enum {
     DG_K_LN_BWD2 = 5,
     DG_K_LINEAR_WGRAD = 6,
     DG_K_ROW_GEMM = 7,
+    DG_K_EMBED_SYM = 8,
     DG_K_COUNT = 16
 };
 int dg_prof_enable(int mask);

@@ -412,3 +412,43 @@ def test_fused_attn_block_matches_reference_module_all_orders(need_edge):
     hr = torch.autograd.grad((sr[0] * tx).sum() + (sr[1] * ty).sum(), [attn.q.weight, attn.e.weight, ln3.weight])
     for a_, b_ in zip(hm, hr):
         assert _rel(a_, b_.double().cpu()) < 2e-4
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky", "sigmoid", "tanh"])
+@pytest.mark.parametrize("B,N,E", [(2, 6, 5), (3, 9, 3), (2, 45, 5), (1, 17, 10)])
+def test_embed_sym_all_orders(act, B, N, E):
+    """dg_embed_sym_fwd/bwd vs the oracle's embed() (Linear-act-Linear-act + symmetrise), incl. the
+    gradient w.r.t. the input adjacency and the create_graph fallback."""
+    from druggen_amd import functional as dgf
+    from oracle import druggen_oracle as orc
+    cfg = orc.NetConfig(act=act, vertexes=N, edges=E, nodes=4, dim=128)
+    a = _gen((B, N, N, E), 1)
+    w1, b1 = _gen((64, E), 2) * 0.5, _gen((64,), 3) * 0.3
+    w2, b2 = _gen((128, 64), 4) * 0.2, _gen((128,), 5) * 0.3
+    g = _gen((B, N, N, 128), 6)
+    P = {"edge_layers.0.weight": w1, "edge_layers.0.bias": b1, "edge_layers.2.weight": w2, "edge_layers.2.bias": b2,
+         "node_layers.0.weight": torch.zeros(64, 4, dtype=torch.float64), "node_layers.0.bias": torch.zeros(64, dtype=torch.float64),
+         "node_layers.2.weight": torch.zeros(128, 64, dtype=torch.float64), "node_layers.2.bias": torch.zeros(128, dtype=torch.float64)}
+    ins = [t.clone().requires_grad_(True) for t in (a, w1, b1, w2, b2)]
+    Pr = dict(P, **{"edge_layers.0.weight": ins[1], "edge_layers.0.bias": ins[2], "edge_layers.2.weight": ins[3],
+                    "edge_layers.2.bias": ins[4]})
+    _, want = orc.embed(Pr, ins[0], torch.zeros(B, N, 4, dtype=torch.float64), cfg)
+    gw = torch.autograd.grad(want, ins, g)
+    f = lambda t: t.float().cuda().requires_grad_(True)
+    dins = [f(t) for t in (a, w1, b1, w2, b2)]
+    out = dgf.embed_sym(*dins, act)
+    assert _rel(out, want.detach()) < TOL
+    assert (out - out.permute(0, 2, 1, 3)).abs().max().item() == 0.0      # exactly symmetric
+    gm = torch.autograd.grad(out, dins, g.float().cuda())
+    for name, x, y in zip("da dw1 db1 dw2 db2".split(), gm, gw):
+        assert _rel(x, y) < 1e-4, name
+    # create_graph path (what the reference loss.py would trigger): second-order through the fallback
+    ta = _gen((B, N, N, E), 7)
+    ga = torch.autograd.grad(dgf.embed_sym(*dins, act), dins[0], g.float().cuda(), create_graph=True)[0]
+    gr = torch.autograd.grad(orc.embed(Pr, ins[0], torch.zeros(B, N, 4, dtype=torch.float64), cfg)[1], ins[0], g,
+                             create_graph=True)[0]
+    assert _rel(ga, gr.detach()) < 1e-4
+    if act != "relu" and act != "leaky":         # piecewise-linear activations have zero second derivative
+        h1 = torch.autograd.grad((ga * ta.float().cuda()).sum(), dins[3])[0]
+        h2 = torch.autograd.grad((gr * ta).sum(), ins[3])[0]
+        assert _rel(h1, h2) < 2e-4
