@@ -78,6 +78,8 @@ struct Smem {
 };
 
 // Stage the pair table, the input rows and the layer-1 activations of one tile.
+// EP = padded number of input features (8 or 16): sizes the per-lane weight / accumulator arrays.
+template <int EP>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const float* __restrict__ w1,
                                            const float* __restrict__ b1, int act, int N, int E, int NP, PairTile t,
                                            int (*ij)[2], float (*at)[kMaxE], float* h1) {
@@ -90,8 +92,8 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const fl
         ij[tid][1] = j;
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * kMaxE; idx += 256) {
-        const int row = idx / kMaxE, e = idx % kMaxE;
+    for (int idx = tid; idx < 64 * EP; idx += 256) {
+        const int row = idx / EP, e = idx % EP;
         const int pr = row & 31;
         const int i = ij[pr][0], j = ij[pr][1];
         float v = 0.f;
@@ -104,15 +106,15 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const fl
     __syncthreads();
     // layer 1: thread = (unit u, row group g of 16 rows)
     const int u = tid & 63, g = tid >> 6;
-    float w[kMaxE];
+    float w[EP];
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) w[e] = e < E ? w1[u * E + e] : 0.f;
+    for (int e = 0; e < EP; ++e) w[e] = e < E ? w1[u * E + e] : 0.f;
     const float bb = b1[u];
     for (int r = 0; r < 16; ++r) {
         const int row = g * 16 + r;
         float s = bb;
 #pragma unroll
-        for (int e = 0; e < kMaxE; ++e) s = fmaf(w[e], at[row][e], s);
+        for (int e = 0; e < EP; ++e) s = fmaf(w[e], at[row][e], s);
         h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)] = act_fwd(s, act);
     }
     __syncthreads();
@@ -138,6 +140,7 @@ __device__ __forceinline__ void layer2_mfma(const float* h1, const float4 (&bf)[
     }
 }
 
+template <int EP>
 __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w1,
                                                           const float* __restrict__ b1,
                                                           const float* __restrict__ w2p,
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
     const int total = B * tiles_per_mol;
     for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
-        stage_tile(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        stage_tile<EP>(a, w1, b1, act, N, E, NP, t, ij, at, h1);
         f32x16 acc0, acc1;
         layer2_mfma(h1, bf, acc0, acc1);
 #pragma unroll
@@ -187,6 +190,7 @@ struct BwdPart {
     static constexpr int kW2 = 0, kB2 = kC * kHid, kW1 = kB2 + kC, kB1 = kW1 + kHid * kMaxE, kTotal = kB1 + kHid;
 };
 
+template <int EP>
 __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
@@ -208,13 +212,13 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
     f32x16 aw2[2];                       // dW2 tiles (n tile w) x (unit tile 0,1)
 #pragma unroll
     for (int i = 0; i < 16; ++i) aw2[0][i] = aw2[1][i] = 0.f;
-    float ab2 = 0.f, ab1 = 0.f, aw1[kMaxE];
+    float ab2 = 0.f, ab1 = 0.f, aw1[EP];
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) aw1[e] = 0.f;
+    for (int e = 0; e < EP; ++e) aw1[e] = 0.f;
     const int total = B * tiles_per_mol;
     for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
-        stage_tile(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        stage_tile<EP>(a, w1, b1, act, N, E, NP, t, ij, at, h1);
         f32x16 acc0, acc1;
         {
             float4 bf[8];
@@ -274,8 +278,7 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
             const float p = dh[reg] * act_grad_from_output(hv, act);
             ab1 += p;
 #pragma unroll
-            for (int e = 0; e < kMaxE; ++e)
-                if (e < E) aw1[e] = fmaf(p, at[row][e], aw1[e]);
+            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, at[row][e], aw1[e]);
             if (da) d1[row * (kHid + 1) + u] = p;
         }
         if (da) {
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
     {
         float* slot = red + ((w * 2 + half) * 32 + col) * (kMaxE + 1);
 #pragma unroll
-        for (int e = 0; e < kMaxE; ++e) slot[e] = aw1[e];
+        for (int e = 0; e < kMaxE; ++e) slot[e] = e < EP ? aw1[e < EP ? e : 0] : 0.f;
         slot[kMaxE] = ab1;
     }
     __syncthreads();
@@ -394,8 +397,12 @@ extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     ProfScope prof(DG_K_EMBED_SYM, stream);
-    hipLaunchKernelGGL(embed_sym_fwd_kernel, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1, w2_packed, b2,
-                       out, B, N, E, act, tpm);
+    if (E <= 8)
+        hipLaunchKernelGGL(embed_sym_fwd_kernel<8>, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1,
+                           w2_packed, b2, out, B, N, E, act, tpm);
+    else
+        hipLaunchKernelGGL(embed_sym_fwd_kernel<16>, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1,
+                           w2_packed, b2, out, B, N, E, act, tpm);
     return check_launch("dg_embed_sym_fwd");
 }
 
@@ -415,12 +422,19 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)attr;
+    static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel<8>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    static const hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel<16>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)attr8;
+    (void)attr16;
     ProfScope prof(DG_K_EMBED_SYM, stream);
-    hipLaunchKernelGGL(embed_sym_bwd_kernel, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
-                       w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
+    if (E <= 8)
+        hipLaunchKernelGGL(embed_sym_bwd_kernel<8>, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
+                           w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
+    else
+        hipLaunchKernelGGL(embed_sym_bwd_kernel<16>, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
+                           w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
     hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
                        BwdPart::kTotal, red);
     hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,

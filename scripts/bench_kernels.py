@@ -96,8 +96,29 @@ def gemm():
             print(f"   + residual+LN epilogue: mine {t_mine:8.1f} us | lib linear+add+LN {t_lib:8.1f} us")
 
 
+def embed():
+    B, N, E = 256, 45, 5
+    a = torch.zeros(B, N, N, E, device="cuda"); a[..., 0] = 1
+    w1, b1 = torch.randn(64, E, device="cuda") * 0.3, torch.randn(64, device="cuda") * 0.1
+    w2, b2 = torch.randn(128, 64, device="cuda") * 0.1, torch.randn(128, device="cuda") * 0.1
+    t = timeit(lambda: dgf._EmbedSym.apply(a, w1, b1, w2, b2, "relu"))
+    print(f"embed_sym fwd: {t:.1f} us")
+    t = timeit(lambda: dgf._composite_embed_sym(a, w1, b1, w2, b2, "relu"))
+    print(f"composite fwd: {t:.1f} us")
+    g = torch.randn(B, N, N, 128, device="cuda")
+    for need_da in (False, True):
+        ins = [a.clone().requires_grad_(need_da)] + [x.clone().requires_grad_(True) for x in (w1, b1, w2, b2)]
+        def fb():
+            out = dgf._EmbedSym.apply(*ins, "relu")
+            torch.autograd.grad(out, [i for i in ins if i.requires_grad], g)
+        def fbc():
+            out = dgf._composite_embed_sym(*ins, "relu")
+            torch.autograd.grad(out, [i for i in ins if i.requires_grad], g)
+        print(f"embed_sym fwd+bwd (da={need_da}): {timeit(fb):.1f} us | composite {timeit(fbc):.1f} us")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for name, fn in (("wgrad", wgrad), ("attn", attn), ("ln", ln), ("gemm", gemm)):
+    for name, fn in (("wgrad", wgrad), ("attn", attn), ("ln", ln), ("gemm", gemm), ("embed", embed)):
         if which in (name, "all"):
             fn()
