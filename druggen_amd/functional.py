@@ -500,9 +500,22 @@ class _FFNLN(Function):
     def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
         H, C = w1.shape
         x2 = _c(x).reshape(-1, C)
-        h, bits = row_gemm(x2, packed_weight(w1, 0), C, H, bias=b1, relu=True, want_relu_bits=True)
-        y, mean, rstd, pre = row_gemm(h, packed_weight(w2, 0), H, C, bias=b2, residual=x2,
-                                      ln=(_c(gamma), _c(beta), eps), want_pre=True)
+        R = x2.shape[0]
+        lib = _lib.load()
+        dev = x2.device
+        y = torch.empty(R, C, dtype=torch.float32, device=dev)
+        h = torch.empty(R, H, dtype=torch.float32, device=dev)
+        pre = torch.empty(R, C, dtype=torch.float32, device=dev)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H)), dtype=torch.int32, device=dev)
+        with _dev(x2):
+            _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), _lib.ptr(packed_weight(w1, 0)), _lib.ptr(_c(b1)),
+                                              _lib.ptr(packed_weight(w2, 0)), _lib.ptr(_c(b2)), _lib.ptr(_c(gamma)),
+                                              _lib.ptr(_c(beta)), _lib.ptr(y), _lib.ptr(h), bits.data_ptr(),
+                                              _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps,
+                                              _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
+        _account("row_gemm", 4 * R * (C + H) + 4 * R * (H + 2 * C), 4 * R * C * H)
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         return y.view(x.shape)
@@ -516,17 +529,34 @@ class _FFNLN(Function):
                                           (x, w1, b1, w2, b2, gamma, beta), dy)
             return g + (None,)
         H, C = w1.shape
-        dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy).reshape(-1, C))
-        # dh = (dz @ W2) * (h > 0): ReLU backward in the epilogue
-        dh = row_gemm(dz, packed_weight(w2, 1), C, H, mask_bits=bits)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = row_gemm(dh, packed_weight(w1, 1), H, C, residual=dz).view(x.shape)   # + residual path
+        R = pre.shape[0]
+        lib = _lib.load()
+        dev = pre.device
+        dy2 = _c(dy).reshape(-1, C)
+        x2 = _c(x).reshape(-1, C)
+        want_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
+        dz = torch.empty(R, C, dtype=torch.float32, device=dev)
+        dh = torch.empty(R, H, dtype=torch.float32, device=dev)
+        dx = torch.empty(R, C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dw1 = db1 = dw2 = db2 = None
-        if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
-            dw2, db2 = _wgrad(dz, h, True)
-            dw1, db1 = _wgrad(dh, _c(x).reshape(-1, C), True)
-        return dx, dw1, db1, dw2, db2, dgamma, dbeta, None
+        if want_w:
+            dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+        need = int(lib.dg_edge_ffn_ln_workspace_bytes(R, C, H))
+        with _dev(pre):
+            ws = _scratch(pre, need, "ffn")
+            _lib.check(lib.dg_edge_ffn_ln_bwd(_lib.ptr(x2), _lib.ptr(h), bits.data_ptr(), _lib.ptr(pre), _lib.ptr(mean),
+                                              _lib.ptr(rstd), _lib.ptr(_c(gamma)), _lib.ptr(packed_weight(w1, 1)),
+                                              _lib.ptr(packed_weight(w2, 1)), _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dh),
+                                              _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dw1),
+                                              _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(),
+                                              R, C, H, _lib.stream_of(pre)), "dg_edge_ffn_ln_bwd")
+        _account("ln_bwd", 4 * R * C * 3)
+        _account("row_gemm", 4 * R * (C + H) + (4 * R * (H + 2 * C) if dx is not None else 0),
+                 2 * R * C * H * (2 if dx is not None else 1))
+        if want_w:
+            _account("linear_wgrad", 8 * R * (C + H), 4 * R * C * H)
+        return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta, None
 
 
 def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):

@@ -141,6 +141,27 @@ int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K,
                 const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                 float eps, dg_stream_t stream);
 
+/* ---- feed-forward half of an Encoder_Block: src/model/layers.py:191-192 + MLP (:40-54) ----
+ *   y = LayerNorm(x + fc2(relu(fc1(x)))) * gamma + beta      (dim C = 128, hidden H = 384)
+ * One call per direction; internally the row-GEMM / LayerNorm / weight-gradient kernels above,
+ * sequenced on `stream` (bias, ReLU, ReLU mask, residual and LayerNorm all live in GEMM
+ * epilogues).  Weights are passed in fragment order: forward packs (dg_row_gemm_pack mode 0) for
+ * _fwd, input-gradient packs (mode 1) for _bwd.  The forward saves h [R,H], the packed ReLU
+ * bits (dg_row_gemm_mask_words(R,C,H) words), the pre-LayerNorm sum [R,C] and mean/rstd [R].
+ * _bwd outputs: dz [R,C] and dh [R,H] (scratch the caller owns), dx (nullable), dgamma, dbeta,
+ * dw1 [H,C], db1, dw2 [C,H], db2 (dw1/dw2 nullable = skip the weight gradients).             */
+size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H);
+int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const float* b1, const float* w2_packed,
+                       const float* b2, const float* gamma, const float* beta,
+                       float* y, float* h, unsigned* relu_bits, float* pre_ln, float* mean, float* rstd,
+                       int64_t R, int C, int H, float eps, dg_stream_t stream);
+int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits, const float* pre_ln,
+                       const float* mean, const float* rstd, const float* gamma,
+                       const float* w1_dgrad_packed, const float* w2_dgrad_packed, const float* dy,
+                       float* dz, float* dh, float* dx, float* dgamma, float* dbeta,
+                       float* dw1, float* db1, float* dw2, float* db2,
+                       void* workspace, size_t workspace_bytes, int64_t R, int C, int H, dg_stream_t stream);
+
 /* ---- edge embedding + symmetrisation: src/model/models.py:57-61,92-94 (Generator) and
  * :159-163,197-199 (Discriminator) ---------------------------------------------------
  *   f(z) = act(W2.act(W1.z + b1) + b2),  out[b,i,j,:] = (f(a[b,i,j,:]) + f(a[b,j,i,:])) / 2
