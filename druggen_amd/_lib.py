@@ -29,6 +29,7 @@ SIGNATURES = {
     "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P]),
     "dg_ln_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, _P]),
+    "dg_ln_residual_bwd_add": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
     "dg_ln_residual_bwd2": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
     "dg_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "dg_linear_wgrad": (c_int, [_P] * 5 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
@@ -38,7 +39,7 @@ SIGNATURES = {
     "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
     "dg_edge_ffn_ln_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, _P]),
-    "dg_edge_ffn_ln_bwd": (c_int, [_P] * 19 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
     "dg_embed_sym_packed_floats": (c_size_t, []),
     "dg_embed_sym_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dg_embed_sym_pack": (c_int, [_P, _P, _P]),

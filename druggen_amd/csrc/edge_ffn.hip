@@ -40,7 +40,7 @@ extern "C" int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const 
 extern "C" int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits, const float* pre_ln,
                                   const float* mean, const float* rstd, const float* gamma,
                                   const float* w1_dgrad_packed, const float* w2_dgrad_packed, const float* dy,
-                                  float* dz, float* dh, float* dx, float* dgamma, float* dbeta, float* dw1,
+                                  const float* dz_add, float* dz, float* dh, float* dx, float* dgamma, float* dbeta, float* dw1,
                                   float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
                                   int64_t R, int C, int H, dg_stream_t stream) {
     if (!x || !h || !relu_bits || !pre_ln || !mean || !rstd || !gamma || !w1_dgrad_packed || !w2_dgrad_packed ||
@@ -49,8 +49,8 @@ extern "C" int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned
     if (C != 128 || H != 384) return fail(DG_E_SHAPE, "dg_edge_ffn_ln_bwd: needs dim 128, hidden 384 (got %d, %d)", C, H);
     if (workspace_bytes < dg_edge_ffn_ln_workspace_bytes(R, C, H))
         return fail(DG_E_WORKSPACE, "dg_edge_ffn_ln_bwd: workspace too small");
-    int st = dg_ln_residual_bwd(pre_ln, nullptr, gamma, mean, rstd, dy, dz, dgamma, dbeta, workspace, workspace_bytes,
-                                R, C, stream);
+    int st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
+                                    workspace_bytes, R, C, stream);
     if (st) return st;
     // dh = (dz @ W2) masked by the forward's ReLU bits
     st = dg_row_gemm(dz, w2_dgrad_packed, dh, R, C, H, nullptr, 0, nullptr, relu_bits, nullptr, nullptr, nullptr,

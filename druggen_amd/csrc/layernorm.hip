@@ -96,7 +96,8 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const float* __restrict_
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ dy, float* __restrict__ dz,
-                                                      float* __restrict__ part, int64_t R, int C) {
+                                                      float* __restrict__ part, int64_t R, int C,
+                                                      const float* __restrict__ dz_add) {
     constexpr int RPB = kBlock / G;
     __shared__ float4 red[2][QPL][kBlock];
     const int64_t passes = (R + RPB - 1) / RPB;
@@ -135,7 +136,11 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const float* __restrict_
         const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
 #pragma unroll
         for (int t = 0; t < QPL; ++t) {
-            if (cok[t] && m.ok) st4(dz + m.row * C + coff[t], rs * (u[t] - f4(c1) - c2 * xh[t]));
+            if (cok[t] && m.ok) {
+                float4 out = rs * (u[t] - f4(c1) - c2 * xh[t]);
+                if (dz_add) out += ld4(dz_add + m.row * C + coff[t]);   // second gradient source of the pre-LN sum
+                st4(dz + m.row * C + coff[t], out);
+            }
         }
     }
     // block partial: sum over the RPB row groups in a fixed order
@@ -322,9 +327,22 @@ extern "C" int dg_ln_residual_fwd(const float* a, const float* r, const float* g
     return check_launch("dg_ln_residual_fwd");
 }
 
+extern "C" int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dy, const float* dz_add, float* dz,
+                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int64_t R,
+                                      int C, dg_stream_t stream_);
+
 extern "C" int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma, const float* mean,
                                   const float* rstd, const float* dy, float* dz, float* dgamma, float* dbeta,
                                   void* workspace, size_t workspace_bytes, int64_t R, int C, dg_stream_t stream_) {
+    return dg_ln_residual_bwd_add(a, r, gamma, mean, rstd, dy, nullptr, dz, dgamma, dbeta, workspace, workspace_bytes,
+                                  R, C, stream_);
+}
+
+extern "C" int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dy, const float* dz_add, float* dz,
+                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int64_t R,
+                                      int C, dg_stream_t stream_) {
     if (!a || !gamma || !mean || !rstd || !dy || !dz || !workspace)
         return fail(DG_E_ARG, "dg_ln_residual_bwd: null pointer");
     LnGeom g;
@@ -336,7 +354,7 @@ extern "C" int dg_ln_residual_bwd(const float* a, const float* r, const float* g
     ProfScope prof(DG_K_LN_BWD, stream);
 #define LAUNCH(GG, QQ)            \
     if (g.G == GG && g.QPL == QQ) \
-        hipLaunchKernelGGL((ln_bwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, dz, part, R, C);
+        hipLaunchKernelGGL((ln_bwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, dz, part, R, C, dz_add);
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
     if (dgamma || dbeta)

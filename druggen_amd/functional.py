@@ -469,20 +469,36 @@ def _fusable(x, w):
     return x.is_cuda and x.dtype == torch.float32 and row_gemm_supported(K, N)
 
 
-def _ln_bwd_rows(pre, gamma, mean, rstd, dy2):
-    """LayerNorm backward over rows of the saved pre-LN sum -> (dz, dgamma, dbeta)."""
+def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None):
+    """LayerNorm backward over rows of the saved pre-LN sum -> (dz [+ dz_add], dgamma, dbeta)."""
     R, N = pre.shape
     lib = _lib.load()
     dz = torch.empty_like(pre)
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
     with _dev(pre):
         ws, _ = _workspace(pre, R, N)
-        _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean), _lib.ptr(rstd),
-                                          _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                          ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
-                   "dg_ln_residual_bwd")
-    _account("ln_bwd", 4 * R * N * 3)
+        _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean),
+                                              _lib.ptr(rstd), _lib.ptr(dy2), _lib.ptr(dz_add), _lib.ptr(dz),
+                                              _lib.ptr(dgamma), _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, N,
+                                              _lib.stream_of(pre)), "dg_ln_residual_bwd")
+    _account("ln_bwd", 4 * R * N * (4 if dz_add is not None else 3))
     return dz, dgamma, dbeta
+
+
+def _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, tz):
+    """Backward of ``_ln_bwd_rows`` w.r.t. the adjoint ``tz`` of dz -> (gz, gdy, ggamma)."""
+    R, N = pre.shape
+    lib = _lib.load()
+    gz, gdy = torch.empty_like(pre), torch.empty_like(pre)
+    ggamma = torch.empty_like(gamma)
+    with _dev(pre):
+        ws, _ = _workspace(pre, R, N)
+        _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean), _lib.ptr(rstd),
+                                           _lib.ptr(dy2), _lib.ptr(tz), _lib.ptr(gz), _lib.ptr(gdy), _lib.ptr(ggamma),
+                                           ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
+                   "dg_ln_residual_bwd2")
+    _account("ln_bwd2", 4 * R * N * 5)
+    return gz, gdy, ggamma
 
 
 def _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps):
@@ -518,45 +534,95 @@ class _FFNLN(Function):
         _account("row_gemm", 4 * R * (C + H) + 4 * R * (H + 2 * C), 4 * R * C * H)
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
-        return y.view(x.shape)
+        ctx.set_materialize_grads(False)
+        # `pre` (the pre-LayerNorm sum) is a second output only so that the gradient penalty's second
+        # order can hand its adjoint back to THIS node: it then joins the LayerNorm gradient inside one
+        # backward pass instead of triggering a second walk through fc2 / fc1.
+        return y.view(x.shape), pre
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpre):
         x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = ctx.saved_tensors
-        if torch.is_grad_enabled():
-            eps = ctx.eps
-            g = _double_backward_fallback(lambda *t: _composite_ffn_ln(*t, eps),
-                                          (x, w1, b1, w2, b2, gamma, beta), dy)
-            return g + (None,)
+        want_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
+        if dy is None:
+            dy = torch.zeros_like(pre)
+        dx, dw1, db1, dw2, db2, dgamma, dbeta = _FFNLNBwd.apply(x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits,
+                                                                 dy, dpre, ctx.needs_input_grad[0], want_w)
+        return dx, dw1, db1, dw2, db2, dgamma, dbeta, None
+
+
+class _FFNLNBwd(Function):
+    """Backward of ``_FFNLN`` as a differentiable node: its own backward (the gradient penalty's second
+    order, reference loss.py:32-39 + train.py:367) is again a sequence of row-GEMM / LayerNorm /
+    weight-gradient launches.  With u = dz = LN'(z; dy), m the ReLU mask, dx = u + ((u W2) * m) W1:
+        adj u  = t + ((t W1^T) * m) W2^T          adj W1 += ((u W2)*m)^T t      adj W2 += u^T ((t W1^T)*m)
+        (adj z, adj gamma, adj dy) = LN''(z; dy, adj u)
+    and adj z then runs the first-order backward of z = x + fc2(relu(fc1 x)) (no LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w):
         H, C = w1.shape
         R = pre.shape[0]
         lib = _lib.load()
         dev = pre.device
         dy2 = _c(dy).reshape(-1, C)
         x2 = _c(x).reshape(-1, C)
-        want_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
         dz = torch.empty(R, C, dtype=torch.float32, device=dev)
         dh = torch.empty(R, H, dtype=torch.float32, device=dev)
-        dx = torch.empty(R, C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(R, C, dtype=torch.float32, device=dev) if want_x else None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
-            dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+            dw1 = torch.empty_like(w1)
+            db1 = torch.empty(H, dtype=torch.float32, device=dev)
+            dw2 = torch.empty_like(w2)
+            db2 = torch.empty(C, dtype=torch.float32, device=dev)
         need = int(lib.dg_edge_ffn_ln_workspace_bytes(R, C, H))
         with _dev(pre):
             ws = _scratch(pre, need, "ffn")
             _lib.check(lib.dg_edge_ffn_ln_bwd(_lib.ptr(x2), _lib.ptr(h), bits.data_ptr(), _lib.ptr(pre), _lib.ptr(mean),
                                               _lib.ptr(rstd), _lib.ptr(_c(gamma)), _lib.ptr(packed_weight(w1, 1)),
-                                              _lib.ptr(packed_weight(w2, 1)), _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dh),
-                                              _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dw1),
-                                              _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(),
-                                              R, C, H, _lib.stream_of(pre)), "dg_edge_ffn_ln_bwd")
+                                              _lib.ptr(packed_weight(w2, 1)), _lib.ptr(dy2),
+                                              _lib.ptr(None if dz_add is None else _c(dz_add)), _lib.ptr(dz),
+                                              _lib.ptr(dh), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                              _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
+                                              ws.data_ptr(), ws.numel(), R, C, H, _lib.stream_of(pre)),
+                       "dg_edge_ffn_ln_bwd")
         _account("ln_bwd", 4 * R * C * 3)
         _account("row_gemm", 4 * R * (C + H) + (4 * R * (H + 2 * C) if dx is not None else 0),
                  2 * R * C * H * (2 if dx is not None else 1))
         if want_w:
             _account("linear_wgrad", 8 * R * (C + H), 4 * R * C * H)
-        return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta, None
+        ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)
+        ctx.had_add = dz_add is not None
+        ctx.set_materialize_grads(False)
+        ctx.xshape = x.shape
+        return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, t_dx, t_dw1, t_db1, t_dw2, t_db2, t_dg, t_db):
+        if any(t is not None for t in (t_dw1, t_db1, t_dw2, t_db2, t_dg, t_db)):
+            raise RuntimeError("ffn_ln: second-order terms through parameter gradients are not implemented")
+        if t_dx is None:
+            return (None,) * 15
+        if ctx.had_add:
+            raise RuntimeError("ffn_ln: third-order differentiation is not implemented")
+        x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh = ctx.saved_tensors
+        H, C = w1.shape
+        t = _c(t_dx).reshape(-1, C)
+        pw = packed_weight
+        vbar = row_gemm(t, pw(w1, 0), C, H, mask_bits=bits)              # (t W1^T) * m
+        ubar = row_gemm(vbar, pw(w2, 0), H, C, residual=t)               # t + vbar W2^T
+        zbar, dybar, gbar = _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, ubar)
+        gw1 = gw2 = None
+        if not getattr(_tls, "inputs_only", False):
+            gw1, _ = _wgrad(dh, t, False)                                  # ((u W2)*m)^T t
+            gw2, _ = _wgrad(dz, vbar, False)                               # u^T ((t W1^T)*m)
+        # dx depends on x only through the saved pre-LN sum z: its adjoint goes back to the forward
+        # node (second output of _FFNLN), which runs ONE backward pass for both gradient sources.
+        # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w
+        return None, gw1, None, gw2, None, gbar, None, None, None, zbar, None, dybar.view_as(t_dx), None, None, None
 
 
 def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):
@@ -565,9 +631,9 @@ def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):
     H, C = w1.shape
     ok = (x.is_cuda and x.dtype == torch.float32 and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
           and b1 is not None and b2 is not None)
-    if not ok or in_second_order_forward():
+    if not ok:
         return _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, float(eps))
-    return _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
+    return _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))[0]
 
 
 def linear_relu(x, weight, bias):
@@ -674,47 +740,147 @@ class _AttnBlock(Function):
         alpha, eps3, eps4, need_edge, (B, N, C) = ctx.cfg
         sv = ctx.saved_tensors
         x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3 = sv[:19]
-        if torch.is_grad_enabled():
-            bq, bk, bv, be, boe, bon, b3, b4 = ctx.extra
-            ins = (x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4)
-            fn = lambda *t: _composite_attn_block(*t, alpha, eps3, eps4, need_edge)
-            gout = (dx2, dy2) if need_edge else dx2
-            return _double_backward_fallback(fn, ins, gout) + (None, None, None, None)
-        pw = packed_weight
+        mean4, rstd4, pre4 = sv[19:22] if need_edge else (None, None, None)
+        bq, bk, bv, be, boe, bon, b3, b4 = ctx.extra
         wants_w = ctx.needs_input_grad[2] and not getattr(_tls, "inputs_only", False)
+        outs = _AttnBlockBwd.apply(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4,
+                                   q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
+                                   alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w)
+        (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4) = outs
+        return (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4,
+                None, None, None, None)
+
+
+def _attn_bwd_launch(q, k, v, e, ws, wo, alpha):
+    B, N, C = q.shape[0], q.shape[1], q.shape[2]
+    lib = _lib.load()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    de = torch.empty_like(e)
+    with _dev(q):
+        _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws), _lib.ptr(wo),
+                                        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), B, N, C, alpha,
+                                        _lib.stream_of(q)), "dg_attn_core_bwd")
+    _account("attn_bwd", 4 * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
+    return dq, dk, dv, de
+
+
+def _attn_bwd2_launch(q, k, v, e, ws, wo, tq, tk, tv, te, alpha):
+    B, N, C = q.shape[0], q.shape[1], q.shape[2]
+    lib = _lib.load()
+    gq, gk, gv, gwo = (torch.empty_like(q) for _ in range(4))
+    ge = torch.empty_like(e)
+    gws = torch.empty_like(e) if ws is not None else None
+    with _dev(q):
+        _lib.check(lib.dg_attn_core_bwd2(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws), _lib.ptr(wo),
+                                         _lib.ptr(tq), _lib.ptr(tk), _lib.ptr(tv), _lib.ptr(te), _lib.ptr(gq),
+                                         _lib.ptr(gk), _lib.ptr(gv), _lib.ptr(ge), _lib.ptr(gws), _lib.ptr(gwo),
+                                         B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd2")
+    _account("attn_bwd2", 4 * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
+    return gq, gk, gv, ge, gws, gwo
+
+
+class _AttnBlockBwd(Function):
+    """Backward of ``_AttnBlock`` as a differentiable node; its own backward (second order of the
+    gradient penalty) chains the same kernels: row GEMMs for every projection (forward packs where the
+    first backward used the input-gradient packs and vice versa), dg_attn_core_bwd2 for the attention
+    core, dg_ln_residual_bwd2 for ln3 / ln4, then the first-order backward of the forward graph for the
+    adjoints that reach the pre-LayerNorm sums, s, o, q, k, v and e."""
+
+    @staticmethod
+    def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
+                mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, alpha, need_edge, want_x, want_y, wants_w):
+        B, N, C = x1.shape
+        pw = packed_weight
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(dx2).reshape(-1, C))
-        do = row_gemm(dz3, pw(won, 1), C, C)
-        ds = dz4 = dg4 = db4 = None
+        dx2f = _c(dx2).reshape(-1, C)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f)
+        do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
+        ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
-            mean4, rstd4, pre4 = sv[19:22]
-            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, _c(dy2).reshape(-1, C))
-            ds = row_gemm(dz4, pw(woe, 1), C, C)
-        lib = _lib.load()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        de = torch.empty_like(e)
-        with _dev(q):
-            _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ds),
-                                            _lib.ptr(do), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de),
-                                            B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd")
-        _account("attn_bwd", 4 * B * ((3 if ds is not None else 2) * N * N * C + 7 * N * C))
+            dy2f = _c(dy2).reshape(-1, C)
+            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f)
+            ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
+        qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
+        dq, dk, dv, de = _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha)
+        dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
         dy = dx1 = None
-        if ctx.needs_input_grad[1]:
-            dy = row_gemm(de, pw(we, 1), C, C, residual=dz4).view(y.shape)        # + ln4 residual path
-        if ctx.needs_input_grad[0]:
-            t = row_gemm(dq, pw(wq, 1), C, C, residual=dz3)                       # + ln3 residual path
-            t = row_gemm(dk, pw(wk, 1), C, C, residual=t)
-            dx1 = row_gemm(dv, pw(wv, 1), C, C, residual=t).view(x1.shape)
+        if want_y:
+            dy = row_gemm(def_, pw(we, 1), C, C, residual=dz4).view(y.shape)      # + ln4 residual path
+        if want_x:
+            t = row_gemm(dqf, pw(wq, 1), C, C, residual=dz3)                       # + ln3 residual path
+            t = row_gemm(dkf, pw(wk, 1), C, C, residual=t)
+            dx1 = row_gemm(dvf, pw(wv, 1), C, C, residual=t).view(x1.shape)
         gw = [None] * 12
         if wants_w:
-            gw[0], gw[1] = _wgrad(dq, x1f, True)
-            gw[2], gw[3] = _wgrad(dk, x1f, True)
-            gw[4], gw[5] = _wgrad(dv, x1f, True)
-            gw[6], gw[7] = _wgrad(de, yf, True)
+            gw[0], gw[1] = _wgrad(dqf, x1f, True)
+            gw[2], gw[3] = _wgrad(dkf, x1f, True)
+            gw[4], gw[5] = _wgrad(dvf, x1f, True)
+            gw[6], gw[7] = _wgrad(def_, yf, True)
             if need_edge:
                 gw[8], gw[9] = _wgrad(dz4, s, True)
             gw[10], gw[11] = _wgrad(dz3, o, True)
-        return (dx1, dy, *gw, dg3, db3, dg4, db4, None, None, None, None)
+        ctx.save_for_backward(x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3,
+                              mean4, rstd4, pre4, dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de)
+        ctx.cfg = (alpha, need_edge, (B, N, C), dx2.shape, None if dy2 is None else dy2.shape)
+        ctx.set_materialize_grads(False)
+        return (dx1, dy, *gw, dg3, db3, dg4, db4)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, t1, ty, *rest):
+        if any(r is not None for r in rest):
+            raise RuntimeError("attn_block: second-order terms through parameter gradients are not implemented")
+        alpha, need_edge, (B, N, C), dx2_shape, dy2_shape = ctx.cfg
+        (x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4,
+         dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de) = ctx.saved_tensors
+        pw = packed_weight
+        with_w = not getattr(_tls, "inputs_only", False)
+        x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
+        RN, RE = B * N, B * N * N
+        zn = lambda: torch.zeros(RN, C, dtype=torch.float32, device=q.device)
+        t1f = _c(t1).reshape(-1, C) if t1 is not None else zn()
+        tyf = _c(ty).reshape(-1, C) if ty is not None else torch.zeros(RE, C, dtype=torch.float32, device=q.device)
+        dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
+        # adjoints of dq, dk, dv, de (dx1 = dz3 + dq Wq + dk Wk + dv Wv ; dy = dz4 + de We)
+        tq = row_gemm(t1f, pw(wq, 0), C, C)
+        tk = row_gemm(t1f, pw(wk, 0), C, C)
+        tv = row_gemm(t1f, pw(wv, 0), C, C)
+        te = row_gemm(tyf, pw(we, 0), C, C)
+        qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
+        gq, gk, gv, ge, gws, gwo = _attn_bwd2_launch(qv, kv, vv, ev, ds, do, tq.view(B, N, C), tk.view(B, N, C),
+                                                     tv.view(B, N, C), te.view(B, N, N, C), alpha)
+        # adjoints of dz3 / dz4 (do = dz3 Won, ds = dz4 Woe, plus the direct residual terms)
+        adz3 = row_gemm(gwo.view(-1, C), pw(won, 0), C, C, residual=t1f)
+        z3bar, dx2bar, g3bar = _ln_bwd2_rows(pre3, g3, mean3, rstd3, dx2f, adz3)
+        obar = row_gemm(z3bar, pw(won, 1), C, C).view(B, N, C)
+        sbar = z4bar = dy2bar = g4bar = None
+        if need_edge:
+            adz4 = row_gemm(gws.view(-1, C), pw(woe, 0), C, C, residual=tyf)
+            z4bar, dy2bar, g4bar = _ln_bwd2_rows(pre4, g4, mean4, rstd4, dy2f, adz4)
+            sbar = row_gemm(z4bar, pw(woe, 1), C, C).view(B, N, N, C)
+        # first-order backward of the forward graph for (sbar, obar), added to the bwd2 adjoints
+        dq2, dk2, dv2, de2 = _attn_bwd_launch(qv, kv, vv, ev, sbar, obar, alpha)
+        Q, K, V, Eg = (gq + dq2).view(-1, C), (gk + dk2).view(-1, C), (gv + dv2).view(-1, C), (ge + de2).view(-1, C)
+        t = row_gemm(Q, pw(wq, 1), C, C, residual=z3bar)
+        t = row_gemm(K, pw(wk, 1), C, C, residual=t)
+        x1bar = row_gemm(V, pw(wv, 1), C, C, residual=t).view(x1.shape)
+        ybar = row_gemm(Eg, pw(we, 1), C, C, residual=z4bar).view(y.shape)
+        gW = [None] * 12
+        if with_w:
+            def both(a_dy, a_x, b_dy, b_x):
+                wa, _ = _wgrad(a_dy, a_x, False)
+                wb, bb = _wgrad(b_dy, b_x, True)
+                return wa + wb, bb
+            gW[0], gW[1] = both(dqf, t1f, Q, x1f)
+            gW[2], gW[3] = both(dkf, t1f, K, x1f)
+            gW[4], gW[5] = both(dvf, t1f, V, x1f)
+            gW[6], gW[7] = both(def_, tyf, Eg, yf)
+            if need_edge:
+                gW[8], gW[9] = both(dz4, gws.view(-1, C), z4bar, s)
+            gW[10], gW[11] = both(dz3, gwo.view(-1, C), z3bar, o)
+        # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, [12 saved], dx2, dy2, 5 flags
+        return (x1bar, ybar, *gW, g3bar, g4bar, *([None] * 12), dx2bar.view(dx2_shape),
+                None if dy2bar is None else dy2bar.view(dy2_shape), None, None, None, None, None)
 
 
 def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
@@ -726,7 +892,7 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
             attn.e.weight, attn.e.bias, attn.out_e.weight, attn.out_e.bias, attn.out_n.weight, attn.out_n.bias,
             ln3.weight, ln3.bias, ln4.weight, ln4.bias)
     fused = (x1.is_cuda and x1.dtype == torch.float32 and C == 128 and x1.dim() == 3
-             and all(t is not None for t in args) and not in_second_order_forward())
+             and all(t is not None for t in args))
     if not fused:
         out = _composite_attn_block(*args, alpha, ln3.eps, ln4.eps, need_edge)
     else:

@@ -89,6 +89,14 @@ int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma,
                        void* workspace, size_t workspace_bytes,
                        int64_t R, int C, dg_stream_t stream);
 
+/* Same, with dz += dz_add (nullable): a second gradient source of the pre-LayerNorm sum
+ * (the second-order pass of the gradient penalty) joins inside the kernel.             */
+int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma,
+                           const float* mean, const float* rstd, const float* dy, const float* dz_add,
+                           float* dz, float* dgamma, float* dbeta,
+                           void* workspace, size_t workspace_bytes,
+                           int64_t R, int C, dg_stream_t stream);
+
 /* Backward of dg_ln_residual_bwd w.r.t. the adjoint tz of dz (the gradient
  * penalty differentiates the first backward w.r.t. inputs only):
  * -> gz [R,C] (adjoint of a and r), gdy [R,C] (adjoint of dy), ggamma [C].       */
@@ -148,7 +156,8 @@ int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K,
  * epilogues).  Weights are passed in fragment order: forward packs (dg_row_gemm_pack mode 0) for
  * _fwd, input-gradient packs (mode 1) for _bwd.  The forward saves h [R,H], the packed ReLU
  * bits (dg_row_gemm_mask_words(R,C,H) words), the pre-LayerNorm sum [R,C] and mean/rstd [R].
- * _bwd outputs: dz [R,C] and dh [R,H] (scratch the caller owns), dx (nullable), dgamma, dbeta,
+ * _bwd: dz_add (nullable, [R,C]) is added to the LayerNorm input-gradient; outputs: dz [R,C] and
+ * dh [R,H] (scratch the caller owns), dx (nullable), dgamma, dbeta,
  * dw1 [H,C], db1, dw2 [C,H], db2 (dw1/dw2 nullable = skip the weight gradients).             */
 size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H);
 int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const float* b1, const float* w2_packed,
@@ -158,6 +167,7 @@ int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const float* b1, 
 int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits, const float* pre_ln,
                        const float* mean, const float* rstd, const float* gamma,
                        const float* w1_dgrad_packed, const float* w2_dgrad_packed, const float* dy,
+                       const float* dz_add,
                        float* dz, float* dh, float* dx, float* dgamma, float* dbeta,
                        float* dw1, float* db1, float* dw2, float* db2,
                        void* workspace, size_t workspace_bytes, int64_t R, int C, int H, dg_stream_t stream);
