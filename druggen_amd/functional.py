@@ -732,19 +732,33 @@ class _AttnBlock(Function):
             saved += [mean4, rstd4, pre4]
         ctx.save_for_backward(*saved)
         ctx.cfg = (alpha, eps3, eps4, need_edge, (B, N, C))
-        ctx.extra = (bq, bk, bv, be, boe, bon, b3, b4)     # only needed by the create_graph fallback
-        return tuple(outs) if need_edge else outs[0]
+        ctx.extra = (bq, bk, bv, be, boe, bon, b3, b4)
+        ctx.set_materialize_grads(False)
+        # pre3 / pre4 / q / k / v / e are outputs only so that the second order of the gradient penalty
+        # can return their adjoints to THIS node, where they join the first-order gradients inside one
+        # backward pass (see _AttnBlockBwd.backward); module code never sees them.
+        return tuple(outs) + ((pre3, pre4) if need_edge else (pre3,)) + (q, k, v, e)
 
     @staticmethod
-    def backward(ctx, dx2, dy2=None):
+    def backward(ctx, dx2, *more):
         alpha, eps3, eps4, need_edge, (B, N, C) = ctx.cfg
         sv = ctx.saved_tensors
         x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3 = sv[:19]
         mean4, rstd4, pre4 = sv[19:22] if need_edge else (None, None, None)
         bq, bk, bv, be, boe, bon, b3, b4 = ctx.extra
+        if need_edge:
+            dy2, add3, add4, aq, ak, av, ae = more
+            if dy2 is None:
+                dy2 = torch.zeros_like(pre4)
+        else:
+            dy2 = add4 = None
+            add3, aq, ak, av, ae = more
+        if dx2 is None:
+            dx2 = torch.zeros_like(pre3)
         wants_w = ctx.needs_input_grad[2] and not getattr(_tls, "inputs_only", False)
         outs = _AttnBlockBwd.apply(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4,
                                    q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
+                                   add3, add4, aq, ak, av, ae,
                                    alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w)
         (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4) = outs
         return (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4,
@@ -783,25 +797,33 @@ class _AttnBlockBwd(Function):
     """Backward of ``_AttnBlock`` as a differentiable node; its own backward (second order of the
     gradient penalty) chains the same kernels: row GEMMs for every projection (forward packs where the
     first backward used the input-gradient packs and vice versa), dg_attn_core_bwd2 for the attention
-    core, dg_ln_residual_bwd2 for ln3 / ln4, then the first-order backward of the forward graph for the
-    adjoints that reach the pre-LayerNorm sums, s, o, q, k, v and e."""
+    core, dg_ln_residual_bwd2 for ln3 / ln4.  The adjoints that reach the forward intermediates
+    (pre-LayerNorm sums, q, k, v, e) are handed to the forward node as gradients of its extra outputs;
+    they come back in as add3 / add4 / aq / ak / av / ae and are summed into the single first-order
+    pass of that node."""
 
     @staticmethod
     def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
-                mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, alpha, need_edge, want_x, want_y, wants_w):
+                mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
+                alpha, need_edge, want_x, want_y, wants_w):
         B, N, C = x1.shape
         pw = packed_weight
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         dx2f = _c(dx2).reshape(-1, C)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f)
+        cadd = lambda t: None if t is None else _c(t).reshape(-1, C)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3))
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
             dy2f = _c(dy2).reshape(-1, C)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f)
+            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4))
             ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         dq, dk, dv, de = _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha)
+        for got, extra in ((dq, aq), (dk, ak), (dv, av), (de, ae)):
+            if extra is not None:
+                got.add_(extra.view(got.shape))
+        ctx.third = any(t is not None for t in (add3, add4, aq, ak, av, ae))
         dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
         dy = dx1 = None
         if want_y:
@@ -830,6 +852,8 @@ class _AttnBlockBwd(Function):
     def backward(ctx, t1, ty, *rest):
         if any(r is not None for r in rest):
             raise RuntimeError("attn_block: second-order terms through parameter gradients are not implemented")
+        if ctx.third:
+            raise RuntimeError("attn_block: third-order differentiation is not implemented")
         alpha, need_edge, (B, N, C), dx2_shape, dy2_shape = ctx.cfg
         (x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4,
          dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de) = ctx.saved_tensors
@@ -852,35 +876,26 @@ class _AttnBlockBwd(Function):
         # adjoints of dz3 / dz4 (do = dz3 Won, ds = dz4 Woe, plus the direct residual terms)
         adz3 = row_gemm(gwo.view(-1, C), pw(won, 0), C, C, residual=t1f)
         z3bar, dx2bar, g3bar = _ln_bwd2_rows(pre3, g3, mean3, rstd3, dx2f, adz3)
-        obar = row_gemm(z3bar, pw(won, 1), C, C).view(B, N, C)
-        sbar = z4bar = dy2bar = g4bar = None
+        z4bar = dy2bar = g4bar = None
         if need_edge:
             adz4 = row_gemm(gws.view(-1, C), pw(woe, 0), C, C, residual=tyf)
             z4bar, dy2bar, g4bar = _ln_bwd2_rows(pre4, g4, mean4, rstd4, dy2f, adz4)
-            sbar = row_gemm(z4bar, pw(woe, 1), C, C).view(B, N, N, C)
-        # first-order backward of the forward graph for (sbar, obar), added to the bwd2 adjoints
-        dq2, dk2, dv2, de2 = _attn_bwd_launch(qv, kv, vv, ev, sbar, obar, alpha)
-        Q, K, V, Eg = (gq + dq2).view(-1, C), (gk + dk2).view(-1, C), (gv + dv2).view(-1, C), (ge + de2).view(-1, C)
-        t = row_gemm(Q, pw(wq, 1), C, C, residual=z3bar)
-        t = row_gemm(K, pw(wk, 1), C, C, residual=t)
-        x1bar = row_gemm(V, pw(wv, 1), C, C, residual=t).view(x1.shape)
-        ybar = row_gemm(Eg, pw(we, 1), C, C, residual=z4bar).view(y.shape)
         gW = [None] * 12
         if with_w:
-            def both(a_dy, a_x, b_dy, b_x):
-                wa, _ = _wgrad(a_dy, a_x, False)
-                wb, bb = _wgrad(b_dy, b_x, True)
-                return wa + wb, bb
-            gW[0], gW[1] = both(dqf, t1f, Q, x1f)
-            gW[2], gW[3] = both(dkf, t1f, K, x1f)
-            gW[4], gW[5] = both(dvf, t1f, V, x1f)
-            gW[6], gW[7] = both(def_, tyf, Eg, yf)
+            gW[0], _ = _wgrad(dqf, t1f, False)
+            gW[2], _ = _wgrad(dkf, t1f, False)
+            gW[4], _ = _wgrad(dvf, t1f, False)
+            gW[6], _ = _wgrad(def_, tyf, False)
             if need_edge:
-                gW[8], gW[9] = both(dz4, gws.view(-1, C), z4bar, s)
-            gW[10], gW[11] = both(dz3, gwo.view(-1, C), z3bar, o)
-        # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, [12 saved], dx2, dy2, 5 flags
-        return (x1bar, ybar, *gW, g3bar, g4bar, *([None] * 12), dx2bar.view(dx2_shape),
-                None if dy2bar is None else dy2bar.view(dy2_shape), None, None, None, None, None)
+                gW[8], _ = _wgrad(dz4, gws.view(-1, C), False)
+            gW[10], _ = _wgrad(dz3, gwo.view(-1, C), False)
+        # The outputs depend on x1 / y only through the forward intermediates: their adjoints
+        # (z3bar, z4bar at the pre-LayerNorm sums; gq, gk, gv, ge) go to the forward node.
+        # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, q,k,v,e, s,o,
+        #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags
+        return (None, None, *gW, g3bar, g4bar, gq.view_as(q), gk.view_as(k), gv.view_as(v), ge.view_as(e), None, None,
+                None, None, z3bar, None, None, z4bar, dx2bar.view(dx2_shape),
+                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 11))
 
 
 def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
@@ -897,6 +912,7 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
         out = _composite_attn_block(*args, alpha, ln3.eps, ln4.eps, need_edge)
     else:
         out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
+        return (out[0], out[1]) if need_edge else (out[0], None)
     return out if need_edge else (out, None)
 
 
