@@ -36,7 +36,35 @@ CASES = {
     # BASELINE.json configs[1] shape (N=45, L=4, E=5, M=13, dim 128) at batch 2
     "c2_b2": dict(cfg=dict(act="relu", vertexes=45, edges=5, nodes=13, dim=128, depth=4, heads=8, mlp_ratio=3),
                   batch=2, submodel="DrugGEN", seed=22, lambda_gp=10.0, full=False),
+    # Real molecular graphs: SMILES shipped with the reference's results (tests/golden/chembl_like_smiles.csv),
+    # featurised by druggen_amd.smiles with the atom / bond tables the reference's encoder construction
+    # (src/data/utils.py:70-126) yields over those result files: atoms {PAD,B,C,N,O,F,P,S,Cl}, bonds
+    # {ZERO,SINGLE,DOUBLE,TRIPLE,AROMATIC}; max_atom 45, default 4-layer / 8-head network.
+    "chembl_b4": dict(cfg=dict(act="relu", vertexes=45, edges=5, nodes=9, dim=128, depth=4, heads=8, mlp_ratio=3),
+                      batch=4, submodel="DrugGEN", seed=23, lambda_gp=10.0, full=False, source="smiles"),
 }
+
+CHEMBL_ATOM_ENCODER = {0: 0, 5: 1, 6: 2, 7: 3, 8: 4, 9: 5, 15: 6, 16: 7, 17: 8}
+CHEMBL_BOND_ENCODER = {0: 0, 1: 1, 2: 2, 3: 3, 12: 4}
+
+
+def smiles_batches(case: dict):
+    """(generator-side, drug-side) dense one-hot batches of the real-molecule sample."""
+    from druggen_amd import smiles as sm
+    cfg = net_config(case)
+    rows = [ln.strip().split(",") for ln in open(os.path.join(HERE, "chembl_like_smiles.csv"))
+            if ln.strip() and not ln.startswith("#")][1:]
+    out = []
+    for role in ("mol", "drug"):
+        graphs = [sm.molecule_graph(r[2], CHEMBL_ATOM_ENCODER, CHEMBL_BOND_ENCODER, cfg.vertexes) for r in rows if r[0] == role]
+        assert len(graphs) == case["batch"] and all(g is not None for g in graphs)
+        a = np.zeros((len(graphs), cfg.vertexes, cfg.vertexes, cfg.edges), dtype=np.float32)
+        for b, g in enumerate(graphs):
+            labels = np.zeros((cfg.vertexes, cfg.vertexes), dtype=np.int64)
+            labels[g.edge_index[0], g.edge_index[1]] = g.edge_attr
+            a[b] = np.eye(cfg.edges, dtype=np.float32)[labels]
+        out.append((a, np.stack([g.x for g in graphs])))
+    return out
 
 
 def net_config(case: dict) -> NetConfig:
@@ -47,6 +75,10 @@ def build_inputs(case: dict):
     """Numpy inputs of one GAN step: generator batch, D-real batch, eps."""
     cfg = net_config(case)
     B, seed = case["batch"], case["seed"]
+    if case.get("source") == "smiles":
+        (a, x), (da, dx) = smiles_batches(case)
+        eps_edge, eps_node = synth.interpolation_eps(B, seed)
+        return dict(gen_edge=a, gen_node=x, disc_edge=da, disc_node=dx, eps_edge=eps_edge, eps_node=eps_node)
     a, x, _, _ = synth.molecule_batch(B, cfg.vertexes, cfg.edges, cfg.nodes, seed=1000 + seed)
     if case["submodel"] == "DrugGEN":       # train.py:340-342: independent drug batch
         da, dx, _, _ = synth.molecule_batch(B, cfg.vertexes, cfg.edges, cfg.nodes, seed=2000 + seed)

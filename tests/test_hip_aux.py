@@ -190,3 +190,24 @@ def test_graphed_step_equals_eager_step():
         d = (a - b).abs()
         worst, mean = max(worst, d.max().item()), mean + d.mean().item() / len(outs[0])
     assert worst <= 8.5e-5 and mean <= 2e-6, (worst, mean)
+
+
+def test_smiles_to_device_batch_end_to_end():
+    """Real molecules (the reference's result SMILES) -> druggen_amd.smiles -> collate ->
+    load_molecules (dg_densify on the GPU) reproduce the dense one-hot batches the real-graph golden
+    case was generated from, bit for bit."""
+    import os
+    import cases
+    from druggen_amd import smiles as sm
+    from druggen_amd.data import load_molecules
+    case = cases.CASES["chembl_b4"]
+    (a, x), (da, dx) = cases.smiles_batches(case)
+    rows = [ln.strip().split(",") for ln in open(os.path.join(os.path.dirname(cases.__file__), "chembl_like_smiles.csv"))
+            if ln.strip() and not ln.startswith("#")][1:]
+    for role, want_a, want_x in (("mol", a, x), ("drug", da, dx)):
+        graphs = [sm.molecule_graph(r[2], cases.CHEMBL_ATOM_ENCODER, cases.CHEMBL_BOND_ENCODER, 45)
+                  for r in rows if r[0] == role]
+        real, a_t, x_t = load_molecules(data=sm.collate(graphs), b_dim=5, m_dim=9, device="cuda", batch_size=4)
+        assert torch.equal(a_t.cpu(), torch.from_numpy(want_a))
+        assert torch.equal(x_t.cpu(), torch.from_numpy(want_x))
+        assert real.shape == (4, 45 * 9 + 45 * 45 * 5)

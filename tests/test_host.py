@@ -220,3 +220,61 @@ def test_aux_oracle_to_dense_adj_semantics():
     assert adj.shape == (2, 3, 3) and adj[0, 0, 1] == 2 and adj[0, 1, 0] == 2 and adj[1, 1, 2] == 2 and adj.sum() == 6
     oh = aux.label2onehot(adj, 4)
     assert oh.shape == (2, 3, 3, 4) and np.all(oh.sum(-1) == 1) and oh[1, 1, 2, 2] == 1
+
+
+# ---- SMILES -> graph (druggen_amd.smiles; reference src/data/dataset.py:119-160,280-316, utils.py:70-126) ----
+def test_smiles_parser_known_molecules():
+    from druggen_amd import smiles as sm
+    atoms, arom, bonds = sm.parse_smiles("c1ccccc1")
+    assert atoms == [6] * 6 and all(arom) and len(bonds) == 6 and {t for _, _, t in bonds} == {sm.AROMATIC}
+    atoms, _, bonds = sm.parse_smiles("CC(=O)O")
+    assert atoms == [6, 6, 8, 8] and sorted(bonds) == [(0, 1, sm.SINGLE), (1, 2, sm.DOUBLE), (1, 3, sm.SINGLE)]
+    # biphenyl: the inter-ring bond is written '-' and stays single; nitrile triple bond; %nn closure
+    _, _, bonds = sm.parse_smiles("c1ccccc1-c1ccccc1")
+    assert sum(t == sm.SINGLE for _, _, t in bonds) == 1 and sum(t == sm.AROMATIC for _, _, t in bonds) == 12
+    assert (0, 1, sm.TRIPLE) in sm.parse_smiles("N#CC")[2]
+    assert len(sm.parse_smiles("C%12CCCCC%12")[2]) == 6
+    # bracket atoms: charge, H count, chirality; two-letter halogens; ring bond given at the closing digit
+    atoms, arom, _ = sm.parse_smiles("[NH3+]C[C@H](Cl)c1cc[nH]c1Br")
+    assert atoms == [7, 6, 6, 17, 6, 6, 6, 7, 6, 35] and arom[7] and not arom[0]
+    assert (0, 5, sm.DOUBLE) in sm.parse_smiles("C1CCCCC=1")[2]
+    for bad in ("C(", "C1CC", "C)", "[Xx]", "C.C", "[H]C", ""):
+        with pytest.raises(sm.SmilesError):
+            sm.parse_smiles(bad)
+
+
+def test_smiles_encoders_and_graph_layout():
+    from druggen_amd import smiles as sm
+    pool = ["CCO", "c1ccccc1Cl", "N#CC", "not a smiles", "C" * 50]
+    atom_enc, atom_dec, bond_enc, bond_dec, kept, max_len = sm.build_encoders(pool, max_atom=45)
+    assert kept == pool[:3] and max_len == 7
+    assert atom_enc == {0: 0, 6: 1, 7: 2, 8: 3, 17: 4} and atom_dec[4] == 17        # PAD first, then sorted Z
+    assert bond_enc == {0: 0, sm.SINGLE: 1, sm.TRIPLE: 2, sm.AROMATIC: 3}            # no DOUBLE seen -> labels shift
+    g = sm.molecule_graph("CCO", atom_enc, bond_enc, 5)
+    assert g.num_atoms == 3 and g.x.shape == (5, 5)
+    assert g.x.argmax(-1).tolist() == [1, 1, 3, 0, 0]                                 # padded with PAD rows
+    assert g.edge_index.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]] and g.edge_attr.tolist() == [1, 1, 1, 1]
+    assert sm.molecule_graph("C=C", atom_enc, bond_enc, 5) is None                    # bond type not in the encoder
+    assert sm.molecule_graph("CCCCCC", atom_enc, bond_enc, 5) is None                 # too many atoms
+    assert sm.molecule_graph("C", atom_enc, bond_enc, 5) is None                      # an atom without bonds
+    batch = sm.collate([g, sm.molecule_graph("N#CC", atom_enc, bond_enc, 5)])
+    assert batch.x.shape == (10, 5) and batch.batch.tolist() == [0] * 5 + [1] * 5
+    assert batch.edge_index[:, 4:].tolist() == [[5, 6, 6, 7], [6, 5, 7, 6]] and batch.edge_attr.tolist()[4:] == [2, 2, 1, 1]
+
+
+def test_smiles_sample_matches_oracle_densify():
+    """collate -> reference-style load_molecules (numpy restatement) gives the dense batches of the golden case."""
+    import cases
+    from druggen_amd import smiles as sm
+    from oracle import aux_oracle
+    case = cases.CASES["chembl_b4"]
+    (a, x), _ = cases.smiles_batches(case)
+    rows = [ln.strip().split(",") for ln in open(os.path.join(os.path.dirname(cases.__file__), "chembl_like_smiles.csv"))
+            if ln.strip() and not ln.startswith("#")][1:]
+    graphs = [sm.molecule_graph(r[2], cases.CHEMBL_ATOM_ENCODER, cases.CHEMBL_BOND_ENCODER, 45) for r in rows if r[0] == "mol"]
+    batch = sm.collate(graphs)
+    _, a2, x2 = aux_oracle.load_molecules(batch.edge_index.numpy(), batch.edge_attr.numpy(), batch.x.numpy(),
+                                          batch.batch.numpy(), b_dim=5, batch_size=4)
+    assert np.array_equal(a2, a) and np.array_equal(x2, x)
+    assert [g.num_atoms for g in graphs] == [39, 29, 29, 34]
+    assert (a[..., 1:].sum((1, 2, 3)) == 2 * np.array([43, 33, 32, 38])).all()      # each bond appears twice
