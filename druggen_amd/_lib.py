@@ -42,6 +42,8 @@ SIGNATURES = {
     "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
     "dg_embed_sym_packed_floats": (c_size_t, []),
     "dg_embed_sym_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dg_embed_sym_dgrad_packed_floats": (c_size_t, []),
+    "dg_embed_sym_pack_dgrad": (c_int, [_P, _P, _P]),
     "dg_embed_sym_pack": (c_int, [_P, _P, _P]),
     "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
     "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 6 + [_P]),

@@ -386,6 +386,33 @@ extern "C" int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t str
     return check_launch("dg_embed_sym_pack");
 }
 
+// Input-gradient operand of layer 2 in fp32 MFMA fragment order (independent of the row-GEMM mode):
+// P[(t*16 + q)*64 + lane] = { W2[64h + 4q + j][32t + n] }_j for the 2 output slabs t of dh1 = dz2 . W2.
+__global__ void embed_pack_dgrad_kernel(const float* __restrict__ w2, float* __restrict__ p, int H, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each: (t, q, lane)
+    const int n_tiles = (H + 31) / 32;
+    if (idx >= n_tiles * 16 * 64) return;
+    const int lane = idx & 63, q = (idx >> 6) & 15, t = idx >> 10;
+    const int n = 32 * t + (lane & 31);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 64 * (lane >> 5) + 4 * q + j;
+        v[j] = (k < C && n < H) ? w2[static_cast<size_t>(k) * H + n] : 0.f;
+    }
+    st4(p + static_cast<size_t>(idx) * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+extern "C" size_t dg_embed_sym_dgrad_packed_floats(void) { return static_cast<size_t>(kHid / 32) * 16 * 64 * 4; }
+
+extern "C" int dg_embed_sym_pack_dgrad(const float* w2, float* packed, dg_stream_t stream_) {
+    if (!w2 || !packed) return fail(DG_E_ARG, "dg_embed_sym_pack_dgrad: null pointer");
+    const int total = (kHid / 32) * 16 * 64;
+    hipLaunchKernelGGL(embed_pack_dgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       w2, packed, kHid, kC);
+    return check_launch("dg_embed_sym_pack_dgrad");
+}
+
 extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
                                 const float* b2, float* out, int B, int N, int E, int H, int C, int act,
                                 dg_stream_t stream_) {

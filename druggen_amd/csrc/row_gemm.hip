@@ -23,6 +23,9 @@
 //     normalises whole rows (32 lanes x float4, 5-step butterflies) and stores full 512 B rows.
 #include "common.h"
 
+#include <cstring>
+#include <type_traits>
+
 namespace dg {
 namespace {
 
@@ -71,11 +74,24 @@ struct Epilogue {
     int relu;
 };
 
-// 32-lane butterfly (lanes l and l^m for m = 1..16 stay inside one half-wave)
+// Sum over the 32 lanes of a half-wave, result in every lane.  DPP adds inside each 16-lane row
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), then the two row totals of the half-wave are
+// read as scalars: no LDS-crossbar round trips (a __shfl_xor butterfly is five dependent ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_sum_step(float x) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true);
+    return x + __int_as_float(moved);
+}
 __device__ __forceinline__ float half_sum(float x) {
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) x += __shfl_xor(x, m, 64);
-    return x;
+    x = dpp_sum_step<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_sum_step<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_sum_step<0x141>(x);   // row_half_mirror
+    x = dpp_sum_step<0x140>(x);   // row_mirror: every lane holds its 16-lane row total
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
 }
 
 // Persistent row-GEMM workgroup.
@@ -350,14 +366,383 @@ __global__ __launch_bounds__(NG * MG * 256, MINW) void row_gemm_kernel(const flo
     }
 }
 
+
+// =====================================================================================================
+// bf16x6 row GEMM: fp32 operands split three ways into bf16 (a = a1 + a2 + a3, 8 mantissa bits each),
+// the six cross products with i + j <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// The dropped terms are <= 2^-23 |a b|, and every kept product is exact, so the result is as accurate
+// as an fp32 FMA chain (measured against fp64: rms 1.9e-8 / max 1.0e-7 of sum|a b| at K = 128, versus
+// 2.4e-8 / 1.6e-7 for v_mfma_f32_32x32x2_f32 -- scripts/ubench/mfma_bf16_layout.hip and
+// tests/test_hip_kernels.py) while the MFMA time drops to 6/16 of the fp32 pipe's: the GEMMs stop being
+// MFMA-bound and run at the HBM roof of their activation streams.
+//
+//   * packed weights: for output slab t (32 columns), k-step ks (16 k) and plane p the B fragment of
+//     lane (n = lane & 31, kg = lane >> 5) is the 8 bf16 { B[ks*16 + 8 kg + j][32 t + n] }_j.
+//   * workgroup = 4 waves, wave w = slab w of a 128-column group (blockIdx.y), 64-row tiles, 2 workgroups
+//     per CU.  A tile chunks (64 x 128 fp32) go HBM -> registers (prefetched one chunk ahead) -> split ->
+//     three bf16 planes in LDS (272-byte row pitch: conflict-free ds_read_b128 fragments).
+//   * K = 384 is three chunks accumulated into the same accumulators; the B fragments of a chunk (96
+//     VGPRs) are re-read from L2 while the next chunk is being split.
+//   * N = 384 is three column groups (gridDim.y): the groups of one tile sequence share an XCD
+//     (gridDim.x is a multiple of 8), so two of the three reads of an A tile hit L2.
+// LDS-DMA with a scalar chunk base and a per-lane 32-bit byte offset (3 instructions per 1 KiB piece)
+__device__ __forceinline__ void dma16_saddr(const float* base, unsigned lane_off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(base), "s"(lds_addr)
+                 : "memory", "m0");
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kX6Pitch = 272;                 // bytes per LDS row of one bf16 plane (128 k): conflict-free b128 reads
+constexpr int kX6Plane = kTR * kX6Pitch;      // one plane of a 64-row chunk
+constexpr int kX6Buf = 3 * kX6Plane;          // three planes (also holds the 64 x 128 fp32 exchange tile)
+constexpr int kX6Lds = 2 * kX6Buf;            // double-buffered
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(h);
+    m = static_cast<__bf16>(r1);
+    l = static_cast<__bf16>(r1 - static_cast<float>(m));
+}
+
+__global__ void pack_weight_x6_kernel(const float* __restrict__ w, bf16x8* __restrict__ p, int rows, int cols, int mode,
+                                      int n_tiles, int k_steps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one (slab, k-step, lane)
+    if (idx >= n_tiles * k_steps * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % k_steps, t = (idx >> 6) / k_steps;
+    const int n = 32 * t + (lane & 31);
+    bf16x8 out[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * 16 + 8 * (lane >> 5) + j;
+        float v;
+        if (mode == 0) v = (n < rows && k < cols) ? w[static_cast<size_t>(n) * cols + k] : 0.f;
+        else v = (k < rows && n < cols) ? w[static_cast<size_t>(k) * cols + n] : 0.f;
+        __bf16 h, m, l;
+        split3(v, h, m, l);
+        out[0][j] = h;
+        out[1][j] = m;
+        out[2][j] = l;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) p[(static_cast<size_t>(t * k_steps + ks) * 3 + pl) * 64 + lane] = out[pl];
+}
+
+// exact three-way split of a float4 into bf16 planes by truncation: h = top 16 bits of x,
+// m = top 16 bits of (x - h), l = top 16 bits of (x - h - m); every remainder is exact and
+// h + m + l covers all 24 significand bits.  v_perm_b32 packs the high halves of a pair.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned a0 = __float_as_uint(x[2 * i]), a1 = __float_as_uint(x[2 * i + 1]);
+        h[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        const float r0 = x[2 * i] - __uint_as_float(a0 & 0xFFFF0000u);
+        const float r1 = x[2 * i + 1] - __uint_as_float(a1 & 0xFFFF0000u);
+        const unsigned b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        m[i] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(b0 & 0xFFFF0000u);
+        const float s1 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+        l[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+
+// Workgroup program: 8 waves, one workgroup per CU, persistent over 64-row tiles.
+//   waves 4..7  producers: stream A chunks (64 rows x 128 k fp32) HBM -> registers (three chunks deep,
+//               96 KiB in flight per CU) -> split -> three bf16 planes in LDS (double-buffered);
+//   waves 0..3  consumers: wave w = 32-column slab w of the current 128-column group: 6 MFMAs per
+//               (k-step, 32-row block) on fragments read from the planes, then the epilogue.
+// One barrier per chunk separates "planes[c] written" from "planes[c] read".  K = 384: three chunks per
+// tile accumulate into the same registers; N = 384: the three column groups of a tile run back to back on
+// the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
+// per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
+template <int KC, int NG, bool EXCH>
+__global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __restrict__ a, const bf16x8* __restrict__ packed,
+                                                             float* __restrict__ y, int64_t R, Epilogue ep) {
+    constexpr int K = KC * 128, KS = KC * 8, N = 128 * NG, UPT = KC * NG;
+    static_assert(KC == 1 || NG == 1, "either the contraction or the output is chunked, not both");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* lds = smem_raw;                              // planes[2][3][64 rows][272 B]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    if (static_cast<int64_t>(blockIdx.x) >= tiles) return;
+    const int64_t my_tiles = (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t nchunks = my_tiles * KC;
+    const int64_t padded = (nchunks + 2) / 3 * 3;      // the producers run whole groups of three iterations
+    auto tile_of = [&](int64_t chunk) { return blockIdx.x + (chunk / KC) * gridDim.x; };
+
+    if (w >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = threadIdx.x - 256;
+        float4 pf[3][8];
+        // Straight-line on purpose (chunk indices are clamped instead of guarded): with branches around
+        // the loads hipcc can no longer count how many younger loads may stay in flight and drains
+        // the whole queue (vmcnt(0)) before every split, which serialises the stream with HBM latency.
+        auto fetch = [&](float4 (&set)[8], int64_t chunk) {
+            if (chunk > nchunks - 1) chunk = nchunks - 1;
+            const int64_t r0 = tile_of(chunk) * kTR;
+            const int kc = static_cast<int>(chunk % KC);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int L = pt + 256 * i;
+                int64_t row = r0 + (L >> 5);
+                if (row > R - 1) row = R - 1;
+                set[i] = ld4(a + row * K + kc * 128 + (L & 31) * 4);
+            }
+        };
+        auto write = [&](const float4 (&set)[8], int64_t chunk) {   // chunks past the end land in the idle buffer
+            char* pl = lds + (chunk & 1) * kX6Buf;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
+                u32x2 h, m, l;
+                split4(set[i], h, m, l);
+                *reinterpret_cast<u32x2*>(pl + 0 * kX6Plane + r * kX6Pitch + c4 * 8) = h;
+                *reinterpret_cast<u32x2*>(pl + 1 * kX6Plane + r * kX6Pitch + c4 * 8) = m;
+                *reinterpret_cast<u32x2*>(pl + 2 * kX6Plane + r * kX6Pitch + c4 * 8) = l;
+            }
+        };
+        auto end_of_iteration = [&](int64_t c) {
+            if (EXCH && c % KC == KC - 1 && c < nchunks) {   // the consumers' exchange epilogue: two more barriers
+                __syncthreads();
+                __syncthreads();
+            }
+            __syncthreads();
+        };
+        fetch(pf[0], 0);
+        fetch(pf[1], 1);
+        fetch(pf[2], 2);
+        write(pf[0], 0);
+        fetch(pf[0], 3);
+        __syncthreads();
+        for (int64_t c = 0; c < padded; c += 3) {
+            // iteration c writes chunk c + 1 (the consumers are on chunk c) and refills its register set
+            write(pf[1], c + 1);
+            fetch(pf[1], c + 4);
+            end_of_iteration(c);
+            write(pf[2], c + 2);
+            fetch(pf[2], c + 5);
+            end_of_iteration(c + 1);
+            write(pf[0], c + 3);
+            fetch(pf[0], c + 6);
+            end_of_iteration(c + 2);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const unsigned relu_sel = ep.relu ? 0xFFFFFFFFu : 0u;
+    // B fragments of the current unit in two halves (k-steps 0-3 and 4-7, 48 VGPRs each).  When the
+    // unit changes (K = 384 or N = 384) the halves form a ring: half 1 of this unit is requested from L2
+    // at the start of the unit, half 0 of the next unit after the first four k-steps.
+    bf16x8 bset[2][3][4];
+    auto load_b = [&](bf16x8 (&bfr)[3][4], int g, int kc, int h) {
+        const bf16x8* wp = packed + static_cast<size_t>(4 * g + w) * KS * 3 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[p][ks] = wp[((kc * 8 + 4 * h + ks) * 3 + p) * 64];
+    };
+    float bias_g[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bias_g[g] = ep.bias ? ep.bias[128 * g + 32 * w + col] : 0.f;
+    float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
+    f32x16 acc[2];
+    // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
+    // contraction is complete; `bnext` receives the B fragments of the following unit meanwhile
+    auto unit = [&](int64_t ti, int kc, int g) {
+        const int64_t chunk = ti * KC + kc;
+        const int64_t tix = blockIdx.x + ti * gridDim.x;
+        const int64_t r0 = tix * kTR;
+        if (UPT > 1) load_b(bset[1], g, kc, 1);
+        if (kc == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        }
+        if (EXCH && kc == KC - 1 && ep.residual) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int64_t rrow = r0 + w * 16 + it * 2 + half;
+                if (rrow > R - 1) rrow = R - 1;
+                res[it] = ld4(ep.residual + rrow * 128 + col * 4);
+            }
+        }
+        const char* pl = lds + (chunk & 1) * kX6Buf;
+        // fragments of step ks + 1 are requested before the MFMAs of step ks; consecutive MFMAs alternate
+        // between the two row blocks (independent accumulators)
+        bf16x8 af[2][2][3];
+        auto frags = [&](int ks, bf16x8 (&dst)[2][3]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    dst[m][p] = *reinterpret_cast<const bf16x8*>(pl + p * kX6Plane + (32 * m + col) * kX6Pitch +
+                                                                 (ks * 16 + 8 * half) * 2);
+        };
+        frags(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) frags(ks + 1, af[(ks + 1) & 1]);
+            if (UPT > 1 && ks == 4) {   // half 0 is consumed: request the next unit's (same tile or next)
+                const int u = kc * NG + g;
+                load_b(bset[0], NG > 1 ? (u + 1) % UPT : 0, KC > 1 ? (u + 1) % UPT : 0, 0);
+            }
+            const bf16x8(&f)[2][3] = af[ks & 1];
+            const bf16x8(&bfr)[3][4] = bset[ks >> 2];
+            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[m][TA[t]], bfr[TB[t]][ks & 3], acc[m], 0, 0, 0);
+        }
+        if (!EXCH && kc == KC - 1) {
+            // direct epilogue of column group g from the accumulator layout
+            constexpr bool BITS = NG == 3;   // ReLU bit masks in / out: only the fc1-shaped launches use them
+            const int n = 128 * g + 32 * w + col;
+            const float bias = bias_g[g];
+            const size_t bix = (static_cast<size_t>(tix) * (4 * NG) + 4 * g + w) * 64 + lane;
+            unsigned bits = 0xFFFFFFFFu, newbits = 0;
+            if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
+            float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
+            float out[2][16];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float v = acc[m][reg] + bias;
+                    if (BITS) {
+                        newbits |= (v > 0.f ? 1u : 0u) << (16 * m + reg);
+                        v = __uint_as_float((__float_as_uint(fmaxf(v, 0.f)) & relu_sel) | (__float_as_uint(v) & ~relu_sel));
+                        v = (bits >> (16 * m + reg)) & 1u ? v : 0.f;
+                    } else if (ep.relu) {
+                        v = fmaxf(v, 0.f);
+                    }
+                    out[m][reg] = v;
+                }
+            // one uniform branch for the tail tile: per-store predicates would put every store in its own
+            // block and hipcc then drains the queue (vmcnt(0)) in front of each of them
+            if (r0 + kTR <= R) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) yb[(32 * m + (reg & 3) + 8 * (reg >> 2)) * N] = out[m][reg];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2);
+                        if (r0 + rr + 4 * half < R) yb[rr * N] = out[m][reg];
+                    }
+            }
+            if (BITS && ep.relu_bits) ep.relu_bits[bix] = newbits;
+        }
+        if (EXCH && kc == KC - 1) {
+            // exchange through the consumed planes so that each half-wave finalises whole 512-byte rows
+            float* ex = reinterpret_cast<float*>(lds + (chunk & 1) * kX6Buf);
+            const float bias = bias_g[0];
+            __syncthreads();   // every consumer has finished its fragment reads
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    float v = acc[m][reg] + bias;
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    ex[rr * 128 + 32 * w + col] = v;
+                }
+            __syncthreads();
+            // rows of this wave: w * 16 + it * 2 + half.  `CHECK` only for the tail tile (uniform branch)
+            auto finish_rows = [&](auto check_tag) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                float* yrow = y + (r0 + w * 16 + half) * 128 + col * 4;
+                float* prow = ep.pre ? ep.pre + (r0 + w * 16 + half) * 128 + col * 4 : nullptr;
+                float4 gam = f4(0.f), bet = f4(0.f);
+                if (ep.gamma) {
+                    gam = ld4(ep.gamma + col * 4);
+                    bet = ld4(ep.beta + col * 4);
+                }
+                // all results of the tile are computed into distinct registers first and stored afterwards:
+                // a store-data register that is rewritten while its store is in flight costs a vmcnt(0)
+                float4 yv[8], pv[8];
+                float mu8[8], rs8[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rr = w * 16 + it * 2 + half;
+                    float4 v = ld4(ex + rr * 128 + col * 4);
+                    if (ep.residual) v += res[it];
+                    pv[it] = v;
+                    if (ep.gamma) {
+                        const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+                        const float4 d = v - f4(mu);
+                        const float var = half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+                        const float rs = rsqrtf(var + ep.eps);
+                        v = fma4(rs * d, gam, bet);
+                        mu8[it] = mu;
+                        rs8[it] = rs;
+                    }
+                    yv[it] = v;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rr = w * 16 + it * 2 + half;
+                    if (!CHECK || r0 + rr < R) {
+                        st4(yrow + it * 256, yv[it]);
+                        if (prow && ep.gamma) st4(prow + it * 256, pv[it]);
+                    }
+                }
+                if (ep.gamma && col == 0) {   // one divergent block per tile for the row statistics
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int rr = w * 16 + it * 2 + half;
+                        if (!CHECK || r0 + rr < R) {
+                            ep.mean[r0 + rr] = mu8[it];
+                            ep.rstd[r0 + rr] = rs8[it];
+                        }
+                    }
+                }
+            };
+            if (r0 + kTR <= R) finish_rows(std::false_type{});
+            else finish_rows(std::true_type{});
+        }
+        if (g == NG - 1) __syncthreads();   // end of this chunk's iteration
+    };
+    load_b(bset[0], 0, 0, 0);
+    if (UPT == 1) load_b(bset[1], 0, 0, 1);
+    __syncthreads();   // chunk 0 is in planes[0]
+    for (int64_t ti = 0; ti < my_tiles; ++ti) {
+        if constexpr (UPT == 1) {
+            unit(ti, 0, 0);
+        } else {   // rolled on purpose: three inlined copies let hipcc hoist loads across units and spill
+#pragma unroll 1
+            for (int u = 0; u < UPT; ++u) unit(ti, KC > 1 ? u : 0, NG > 1 ? u : 0);
+        }
+    }
+    for (int64_t c = nchunks; c < padded; ++c) __syncthreads();   // match the producers' padded iterations
+}
+
 }  // namespace
 }  // namespace dg
 
 using namespace dg;
 
+// DG_ROW_GEMM=mfma32 selects the v_mfma_f32_32x32x2_f32 kernels (A/B comparisons); default: bf16x6.
+static bool use_x6() {
+    static const bool on = !(getenv("DG_ROW_GEMM") && strcmp(getenv("DG_ROW_GEMM"), "mfma32") == 0);
+    return on;
+}
+
 extern "C" size_t dg_row_gemm_packed_floats(int n_out, int k_contract) {
     if (n_out < 1 || k_contract < 1) return 0;
     const size_t nt = (n_out + 31) / 32, kc = (k_contract + 127) / 128;
+    if (use_x6()) return nt * kc * 8 * 3 * 64 * 4;   // [slab][k-step][plane][lane] x 8 bf16
     return nt * kc * 16 * 64 * 4;
 }
 
@@ -366,6 +751,13 @@ extern "C" int dg_row_gemm_pack(const float* w, float* packed, int rows, int col
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
+    if (use_x6()) {
+        const int total6 = nt * kc * 8 * 64;
+        hipLaunchKernelGGL(pack_weight_x6_kernel, dim3((total6 + 255) / 256), dim3(256), 0,
+                           static_cast<hipStream_t>(stream_), w, reinterpret_cast<bf16x8*>(packed), rows, cols, mode, nt,
+                           kc * 8);
+        return check_launch("dg_row_gemm_pack");
+    }
     const int total = nt * kc * 16 * 64;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), w,
                        packed, rows, cols, mode, nt, kc);
@@ -394,10 +786,35 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
     if ((mask_bits || relu_bits_out) && K != 128)
         return fail(DG_E_ARG, "dg_row_gemm: bit masks need K == 128");
     if (exch && N != 128) return fail(DG_E_ARG, "dg_row_gemm: residual / LayerNorm epilogues need N == 128");
+    if (use_x6() && (mask_bits || relu_bits_out) && N != 384)
+        return fail(DG_E_ARG, "dg_row_gemm: bit masks need the 128 -> 384 shape");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Epilogue ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
     ProfScope prof(DG_K_ROW_GEMM, stream);
+    if (use_x6()) {
+        const int ng = N / 128;
+        const int64_t tiles = (R + kTR - 1) / kTR;
+        int seqs = 256;                             // one 8-wave workgroup per CU
+        if (tiles < seqs) seqs = static_cast<int>(tiles);
+        (void)ng;
+#define LAUNCH6(KC_, NG_, EX_)                                                                                     \
+    {                                                                                                              \
+        static const hipError_t attr6 =                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_kernel<KC_, NG_, EX_>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds);                               \
+        (void)attr6;                                                                                               \
+        hipLaunchKernelGGL((row_gemm_x6_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kX6Lds, stream, a,           \
+                           reinterpret_cast<const bf16x8*>(packed), y, R, ep);                                     \
+    }
+        if (K == 128 && N == 384) LAUNCH6(1, 3, false)
+        else if (K == 128 && exch) LAUNCH6(1, 1, true)
+        else if (K == 128) LAUNCH6(1, 1, false)
+        else if (exch) LAUNCH6(3, 1, true)
+        else LAUNCH6(3, 1, false)
+#undef LAUNCH6
+        return check_launch("dg_row_gemm");
+    }
 #define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_) LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, false)
 #define LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, XP_)                                               \
     {                                                                                                              \

@@ -925,16 +925,18 @@ _ACT_FNS = {"relu": torch.relu, "leaky": lambda t: torch.nn.functional.leaky_rel
 _embed_pack_cache = {}
 
 
-def _embed_packed_w2(w2):
-    key = id(w2)
+def _embed_packed_w2(w2, dgrad: bool = False):
+    key = (id(w2), dgrad)
     hit = _embed_pack_cache.get(key)
     if hit is not None and hit[0]() is w2 and hit[1] == w2._version and hit[3] == w2.data_ptr():
         return hit[2]
     lib = _lib.load()
-    packed = torch.empty(int(lib.dg_embed_sym_packed_floats()), dtype=torch.float32, device=w2.device)
+    n_floats = lib.dg_embed_sym_dgrad_packed_floats() if dgrad else lib.dg_embed_sym_packed_floats()
+    packed = torch.empty(int(n_floats), dtype=torch.float32, device=w2.device)
     wd = _c(w2.detach())
     with _dev(w2):
-        _lib.check(lib.dg_embed_sym_pack(_lib.ptr(wd), _lib.ptr(packed), _lib.stream_of(w2)), "dg_embed_sym_pack")
+        pack = lib.dg_embed_sym_pack_dgrad if dgrad else lib.dg_embed_sym_pack
+        _lib.check(pack(_lib.ptr(wd), _lib.ptr(packed), _lib.stream_of(w2)), "dg_embed_sym_pack")
     _embed_pack_cache[key] = (weakref.ref(w2), w2._version, packed, w2.data_ptr())
     return packed
 
@@ -979,7 +981,7 @@ class _EmbedSym(Function):
         with _dev(a):
             ws = _scratch(a, need, "embed")
             _lib.check(lib.dg_embed_sym_bwd(_lib.ptr(a), _lib.ptr(_c(w1)), _lib.ptr(_c(b1)),
-                                            _lib.ptr(_embed_packed_w2(w2)), _lib.ptr(packed_weight(w2, 1)),
+                                            _lib.ptr(_embed_packed_w2(w2)), _lib.ptr(_embed_packed_w2(w2, True)),
                                             _lib.ptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
                                             _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
                                             _ACT_IDS[act], _lib.stream_of(a)), "dg_embed_sym_bwd")

@@ -183,6 +183,9 @@ int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits
 size_t dg_embed_sym_packed_floats(void);
 size_t dg_embed_sym_workspace_bytes(int B, int N);
 int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream);
+/* Layer-2 weight as the input-gradient operand (dh = dz2 . W2) in fp32 MFMA fragment order, for _bwd. */
+size_t dg_embed_sym_dgrad_packed_floats(void);
+int dg_embed_sym_pack_dgrad(const float* w2, float* packed, dg_stream_t stream);
 int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed, const float* b2,
                      float* out, int B, int N, int E, int H, int C, int act, dg_stream_t stream);
 int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const float* w2_packed,

@@ -16,6 +16,7 @@ def timeit(fn, iters=20, warm=3):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(20_000_000)   # let the host run ahead: the events then time the GPU, not the launch path
     s.record()
     for _ in range(iters):
         fn()
