@@ -249,6 +249,32 @@ def test_row_gemm_forward_and_dgrad_modes(R, K, N):
     assert _rel(y, a @ w2) < TOL
 
 
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (384, 128)])
+def test_row_gemm_split_bf16_is_fp32_class_accurate(K, N):
+    """The row GEMM splits fp32 operands three ways into bf16 and runs six MFMA cross products with fp32
+    accumulation.  That is not a reduced-precision GEMM: measured against fp64, its element-wise error
+    (relative to sum_k |a_k w_k|, the natural scale of a dot product) must be at the level of an fp32
+    GEMM of the same data -- torch's fp32 matmul here -- and five orders of magnitude below bf16."""
+    from druggen_amd import functional as dgf
+    R = 4096
+    a = _gen((R, K), 11)
+    w = _gen((N, K), 12) * 0.1
+    ad, wd = a.float().cuda(), w.float().cuda()
+    want = a @ w.t()
+    scale = a.abs() @ w.abs().t()
+    def err(y):
+        e = (y.double().cpu() - want).abs() / scale
+        return e.max().item(), e.pow(2).mean().sqrt().item()
+    mine_max, mine_rms = err(dgf.row_gemm(ad, dgf.packed_weight(wd, 0), K, N))
+    torch.backends.cuda.matmul.allow_tf32 = False
+    ref_max, ref_rms = err(ad @ wd.t())
+    bf_max, bf_rms = err((ad.bfloat16() @ wd.bfloat16().t()).float())
+    print(f"K={K} N={N}: row_gemm max {mine_max:.2e} rms {mine_rms:.2e} | fp32 matmul max {ref_max:.2e} rms {ref_rms:.2e}"
+          f" | bf16 matmul rms {bf_rms:.2e}")
+    assert mine_rms < 1.5 * ref_rms and mine_max < 2.0 * ref_max
+    assert mine_rms < 1e-7 and bf_rms > 1e3 * mine_rms
+
+
 @pytest.mark.parametrize("R", [5, 64, 1000, 2025 * 7])
 def test_row_gemm_fused_epilogues(R):
     from druggen_amd import functional as dgf
