@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 WORKLOAD = dict(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
 
 
@@ -187,10 +188,18 @@ def main():
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                                  "share_of_step": ms * 1e-3 / detail_elapsed}
                 fl = dgf.traffic_flops(name)
-                if fl:          # MFMA-bound kernels: fp32 matrix-core roofline
+                if fl:          # GEMM-shaped kernels: fp32-equivalent flop rate next to the byte rate
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                    kernels[name].update({"bound": "mfma", "achieved_TFLOPs": tf,
-                                          "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TFLOPS})
+                    if name == "row_gemm" and os.environ.get("DG_ROW_GEMM") != "mfma32":
+                        # bf16x6-split MFMA: 6 bf16 MFMAs per fp32 product -> the matrix pipe is no longer
+                        # the roof, the activation stream (HBM) is
+                        kernels[name].update({"bound": "hbm", "achieved_TFLOPs_fp32_equivalent": tf,
+                                              "mfma": "6x v_mfma_f32_32x32x16_bf16 per k16 step (3-way bf16 split, "
+                                                      "fp32 accumulate)",
+                                              "mfma_fp32_equivalent_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS / 6.0})
+                    else:
+                        kernels[name].update({"bound": "mfma", "achieved_TFLOPs": tf,
+                                              "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TFLOPS})
                 else:
                     kernels[name]["bound"] = "hbm"
         (n_f, ms_f), bytes_f = attn_stats["attn_fwd"]
@@ -219,7 +228,11 @@ def main():
             "config": {"workload": "BASELINE configs[1]: DrugGEN default 4-layer/8-head dim128 mlp_ratio3, N=45, E=5, "
                                    "M=13, fp32, full WGAN-GP step (train.py:351-384) incl. gradient penalty + 2x AdamW",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "vertexes": w["vertexes"], "depth": w["depth"], "hip_graph_replay": bool(args.graph and world == 1)},
+                       "vertexes": w["vertexes"], "depth": w["depth"], "hip_graph_replay": bool(args.graph and world == 1),
+                       "row_gemm": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if os.environ.get("DG_ROW_GEMM") == "mfma32" else
+                                    "fp32 in/out, operands split 3-way into bf16, 6 MFMA cross products, fp32 accumulate: "
+                                    "error vs fp64 at or below an fp32 GEMM's (tests/test_hip_kernels.py::"
+                                    "test_row_gemm_split_bf16_is_fp32_class_accurate)")},
             "roofline": {"kernel": "attn_core_fwd", "bound": "hbm", "achieved": dom.get("achieved_GBps"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic,
