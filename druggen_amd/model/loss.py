@@ -26,6 +26,10 @@ def gradient_penalty(discriminator, real_node, real_edge, fake_node, fake_edge, 
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
 
 
+def _has_active_dropout(module) -> bool:
+    return any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in module.modules())
+
+
 def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, mol_annot, batch_size, device,
                        lambda_gp, *, eps=None, generator_outputs=None):
     """Reference loss.py:52-72 -> (node, edge, d_loss).
@@ -33,13 +37,23 @@ def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, 
     The generator output only enters detached, so its forward runs without
     recording a graph (the reference records one it never uses).  ``generator_outputs``
     may carry the 4-tuple of an earlier ``generator(mol_adj, mol_annot)`` call to reuse."""
-    prediction_real = -torch.mean(discriminator(drug_adj, drug_annot))
     if generator_outputs is None:
         with torch.no_grad():
             generator_outputs = generator(mol_adj, mol_annot)
     node, edge, node_sample, edge_sample = generator_outputs
     node_sample, edge_sample = node_sample.detach(), edge_sample.detach()
-    prediction_fake = torch.mean(discriminator(edge_sample, node_sample))
+    if (drug_adj.shape == edge_sample.shape and drug_annot.shape == node_sample.shape
+            and not (discriminator.training and _has_active_dropout(discriminator))):
+        # D(real) and D(fake) as one pass over the concatenated batch: every molecule is processed
+        # independently (no cross-sample op in D), so the logits are the reference's; half the launches,
+        # and each weight gradient is accumulated once instead of twice.
+        logits = discriminator(torch.cat([drug_adj, edge_sample]), torch.cat([drug_annot, node_sample]))
+        n_real = drug_adj.shape[0]
+        prediction_real = -torch.mean(logits[:n_real])
+        prediction_fake = torch.mean(logits[n_real:])
+    else:
+        prediction_real = -torch.mean(discriminator(drug_adj, drug_annot))
+        prediction_fake = torch.mean(discriminator(edge_sample, node_sample))
     gp = gradient_penalty(discriminator, drug_annot, drug_adj, node_sample, edge_sample, batch_size, device, eps=eps)
     return node, edge, prediction_fake + prediction_real + lambda_gp * gp
 
