@@ -293,7 +293,7 @@ bool ln_geometry(int C, LnGeom* g) {
 int ln_grid(int64_t R, int G) {
     const int64_t rpb = kBlock / G;
     int64_t passes = (R + rpb - 1) / rpb;
-    const int64_t cap = 2048;  // ~8 blocks per CU, grid-stride beyond
+    static const int64_t cap = getenv("DG_LN_GRID_CAP") ? atoll(getenv("DG_LN_GRID_CAP")) : 1024;  // ~4 blocks per CU (fewer dgamma/dbeta partials to finish), grid-stride beyond
     return static_cast<int>(passes < cap ? (passes < 1 ? 1 : passes) : cap);
 }
 

@@ -146,11 +146,21 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
 // out[i] = sum_s part[s][i] in a fixed order.  Block = 16 partial-groups x 16 float4 columns:
 // group g sums partials g, g+16, ... (independent 16 B loads, unrolled), then the 16 group
 // sums are added in order through LDS.
+// Two outputs in one launch (dW and db): blocks [0, blocks_a) reduce `part`, the rest `part_b`.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t n4,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, int blocks_a,
+                                                          const float* __restrict__ part_b, int64_t n4_b,
+                                                          float* __restrict__ out_b) {
     __shared__ float4 red[16][17];
     const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + c;
+    int64_t blk = blockIdx.x;
+    if (blk >= blocks_a) {   // block-uniform
+        blk -= blocks_a;
+        part = part_b;
+        n4 = n4_b;
+        out = out_b;
+    }
+    const int64_t i = blk * 16 + c;
     float4 s = f4(0.f);
     if (i < n4) {
 #pragma unroll 8
@@ -375,10 +385,8 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
 #undef LAUNCH_M
 #undef LAUNCH
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((n4 + 15) / 16)), dim3(256), 0, stream,
-                       part_w, S, n4, dw);
-    if (db)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N / 4 + 15) / 16), dim3(256), 0, stream, part_b, S,
-                           static_cast<int64_t>(N / 4), db);
+    const int blocks_w = static_cast<int>((n4 + 15) / 16), blocks_b = db ? (N / 4 + 15) / 16 : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks_w + blocks_b), dim3(256), 0, stream, part_w, S, n4, dw, blocks_w,
+                       part_b, static_cast<int64_t>(N / 4), db);
     return check_launch("dg_linear_wgrad");
 }

@@ -68,6 +68,11 @@ def ln():
     print(f"ln fwd: {t:.1f} us {4 * R * C * 3 / t / 1e3:.0f} GB/s")
     t2 = timeit(lambda: torch.nn.functional.layer_norm(a + r, (C,), g, b))
     print(f"torch add+ln fwd: {t2:.1f} us")
+    pre = a + r
+    mean, rstd = pre.mean(1), (pre.var(1, unbiased=False) + 1e-5).rsqrt()
+    dy = torch.randn(R, C, device="cuda")
+    t = timeit(lambda: dgf._ln_bwd_rows(pre, g, mean, rstd, dy))
+    print(f"ln bwd (+finish): {t:.1f} us {4 * R * C * 3 / t / 1e3:.0f} GB/s")
     t3 = timeit(lambda: a.clone())
     print(f"torch copy 265MB: {t3:.1f} us  {2 * 4 * R * C / t3 / 1e3:.0f} GB/s")
 
