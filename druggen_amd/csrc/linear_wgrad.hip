@@ -16,6 +16,8 @@
 // Split-K partials are reduced by a second kernel in a fixed order.
 #include "common.h"
 
+#include <cstring>
+
 namespace dg {
 namespace {
 
@@ -34,7 +36,32 @@ __device__ __forceinline__ void stage_tile(const float* g, float* l, int W, int 
     }
 }
 
-template <int NT, int KT, int WN, int WK, int TR, bool MASK>
+// exact three-way bf16 split of 8 fp32 values (see row_gemm.hip: h + m + l covers all 24 significand
+// bits; the six cross products with i + j <= 4 on v_mfma_f32_32x32x16_bf16 are as accurate as fp32 FMAs)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a0 = __float_as_uint(x[2 * i]), a1 = __float_as_uint(x[2 * i + 1]);
+        hp[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        const float r0 = x[2 * i] - __uint_as_float(a0 & 0xFFFF0000u);
+        const float r1 = x[2 * i + 1] - __uint_as_float(a1 & 0xFFFF0000u);
+        const unsigned b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        mp[i] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(b0 & 0xFFFF0000u);
+        const float s1 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+        lp[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    h = __builtin_bit_cast(bf16x8, hp);
+    m = __builtin_bit_cast(bf16x8, mp);
+    l = __builtin_bit_cast(bf16x8, lp);
+}
+
+// X6: operands split into bf16 planes in registers, 6 MFMAs per 16-row step and tile pair instead of 8
+// fp32 MFMAs (6/16 of the matrix time per flop); same LDS traffic (one ds_read_b32 per operand row).
+template <int NT, int KT, int WN, int WK, int TR, bool MASK, bool X6 = false>
 __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restrict__ dy,
                                                            const float* __restrict__ dymask,
                                                            const float* __restrict__ x,
@@ -89,6 +116,38 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
         const float* ldy = lds + buf * BUF;
         const float* lx = ldy + TR * N;
         const int half = lane >> 5, col = lane & 31;
+        if constexpr (X6) {
+#pragma unroll
+            for (int s16 = 0; s16 < TR / 16; ++s16) {
+                bf16x8 af[TN][3], bfg[TK][3];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = (16 * s16 + 8 * half + j) * N + (wn * TN + i) * 32 + col;
+                        v[j] = ldy[o];
+                        if (MASK) v[j] = lx[TR * K + o] > 0.f ? v[j] : 0.f;
+                    }
+                    split8(v, af[i][0], af[i][1], af[i][2]);
+                }
+#pragma unroll
+                for (int j2 = 0; j2 < TK; ++j2) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = lx[(16 * s16 + 8 * half + j) * K + (wk * TK + j2) * 32 + col];
+                    split8(v, bfg[j2][0], bfg[j2][1], bfg[j2][2]);
+                }
+                constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j2 = 0; j2 < TK; ++j2)
+                            acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t]], bfg[j2][TB[t]], acc[i][j2], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < TR / 2; ++ks) {
             float a[TN], b[TK];
@@ -351,15 +410,21 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(DG_K_LINEAR_WGRAD, stream);
-#define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                                                     \
+    static const bool x6 = !(getenv("DG_WGRAD") && strcmp(getenv("DG_WGRAD"), "mfma32") == 0);   // bf16x6 split by default
+#define LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, X_)                                                                 \
     {                                                                                                            \
         constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * 4;                                  \
         static const hipError_t attr =                                                                           \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_>),        \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>),    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                          \
         (void)attr;                                                                                              \
-        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_>), dim3(S), dim3(WN_* WK_ * 64), lds_bytes,  \
-                           stream, dy, dy_mask, x, part_w, part_b, R, tpb);                                      \
+        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>), dim3(S), dim3(WN_* WK_ * 64),         \
+                           lds_bytes, stream, dy, dy_mask, x, part_w, part_b, R, tpb);                           \
+    }
+#define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                 \
+    {                                                                        \
+        if (x6 && (TR_) % 16 == 0) LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, true) \
+        else LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, false)                     \
     }
 #define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                   \
     if (p.nt == NT_ && p.kt == KT_) {                                     \
@@ -383,6 +448,7 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
     LAUNCH(3, 1, 3, 1, 32)
     LAUNCH(1, 3, 1, 3, 32)
 #undef LAUNCH_M
+#undef LAUNCH_X
 #undef LAUNCH
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;
     const int blocks_w = static_cast<int>((n4 + 15) / 16), blocks_b = db ? (N / 4 + 15) / 16 : 0;
