@@ -472,6 +472,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     if (static_cast<int64_t>(blockIdx.x) >= tiles) return;
     const int64_t my_tiles = (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t nchunks = my_tiles * KC;
+    // Workgroups walk the three k-chunks / column groups of a tile in rotated orders (blockIdx % 3): at any
+    // moment a third of the CUs streams each group's B fragments from L2 instead of all CUs the same 96 KiB.
+    const int rot = static_cast<int>(blockIdx.x % 3);
     const int64_t padded = (nchunks + 2) / 3 * 3;      // the producers run whole groups of three iterations
     auto tile_of = [&](int64_t chunk) { return blockIdx.x + (chunk / KC) * gridDim.x; };
 
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
         auto fetch = [&](float4 (&set)[8], int64_t chunk) {
             if (chunk > nchunks - 1) chunk = nchunks - 1;
             const int64_t r0 = tile_of(chunk) * kTR;
-            const int kc = static_cast<int>(chunk % KC);
+            const int kc = KC == 1 ? 0 : (static_cast<int>(chunk % KC) + rot) % KC;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int L = pt + 256 * i;
@@ -554,11 +557,13 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     f32x16 acc[2];
     // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
     // contraction is complete; `bnext` receives the B fragments of the following unit meanwhile
-    auto unit = [&](int64_t ti, int kc, int g) {
-        const int64_t chunk = ti * KC + kc;
+    auto unit = [&](int64_t ti, int pos_kc, int pos_g) {   // positions within the tile; values are rotated
+        const int kc = pos_kc, kcv = KC > 1 ? (pos_kc + rot) % KC : 0;
+        const int g = NG > 1 ? (pos_g + rot) % NG : 0;
+        const int64_t chunk = ti * KC + pos_kc;
         const int64_t tix = blockIdx.x + ti * gridDim.x;
         const int64_t r0 = tix * kTR;
-        if (UPT > 1) load_b(bset[1], g, kc, 1);
+        if (UPT > 1) load_b(bset[1], g, kcv, 1);
         if (kc == 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -590,8 +595,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
         for (int ks = 0; ks < 8; ++ks) {
             if (ks + 1 < 8) frags(ks + 1, af[(ks + 1) & 1]);
             if (UPT > 1 && ks == 4) {   // half 0 is consumed: request the next unit's (same tile or next)
-                const int u = kc * NG + g;
-                load_b(bset[0], NG > 1 ? (u + 1) % UPT : 0, KC > 1 ? (u + 1) % UPT : 0, 0);
+                const int un = (pos_kc * NG + pos_g + 1) % UPT;   // next position: same tile, or the next tile's first
+                load_b(bset[0], NG > 1 ? (un + rot) % NG : 0, KC > 1 ? (un + rot) % KC : 0, 0);
             }
             const bf16x8(&f)[2][3] = af[ks & 1];
             const bf16x8(&bfr)[3][4] = bset[ks >> 2];
@@ -712,9 +717,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
             if (r0 + kTR <= R) finish_rows(std::false_type{});
             else finish_rows(std::true_type{});
         }
-        if (g == NG - 1) __syncthreads();   // end of this chunk's iteration
+        if (pos_g == NG - 1) __syncthreads();   // end of this chunk's iteration
     };
-    load_b(bset[0], 0, 0, 0);
+    load_b(bset[0], NG > 1 ? rot : 0, KC > 1 ? rot : 0, 0);
     if (UPT == 1) load_b(bset[1], 0, 0, 1);
     __syncthreads();   // chunk 0 is in planes[0]
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
