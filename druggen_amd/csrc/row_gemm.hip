@@ -458,10 +458,15 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 // tile accumulate into the same registers; N = 384: the three column groups of a tile run back to back on
 // the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
 // per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
-template <int KC, int NG, bool EXCH>
+template <int KC, int NG, bool EXCH, int NC = 4>
 __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __restrict__ a, const bf16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
-    constexpr int K = KC * 128, KS = KC * 8, N = 128 * NG, UPT = KC * NG;
+    // NC = 6 (N = 384 only): six consumer waves = six resident 32-column slabs (one 192-column half of the
+    // output per blockIdx.y), two producer waves; no B-fragment stream from L2, the A tile is read twice.
+    constexpr int NM = 8 - NC, PFN = 2048 / (64 * NM);   // producer waves, float4 per producer thread and chunk
+    constexpr int K = KC * 128, KS = KC * 8, N = NC == 6 ? 384 : 128 * NG, UPT = KC * NG;
+    constexpr int SLABS = NC == 6 ? 12 : 4 * NG;   // 32-column slabs of the whole output (bit-mask layout)
+    static_assert(NC == 4 || (NC == 6 && KC == 1 && NG == 1 && !EXCH), "6 consumers: resident-B 128 -> 384 only");
     static_assert(KC == 1 || NG == 1, "either the contraction or the output is chunked, not both");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* lds = smem_raw;                              // planes[2][3][64 rows][272 B]
@@ -478,30 +483,30 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     const int64_t padded = (nchunks + 2) / 3 * 3;      // the producers run whole groups of three iterations
     auto tile_of = [&](int64_t chunk) { return blockIdx.x + (chunk / KC) * gridDim.x; };
 
-    if (w >= 4) {
+    if (w >= NC) {
         // ------------------------------------------------------------------ producers
-        const int pt = threadIdx.x - 256;
-        float4 pf[3][8];
+        const int pt = threadIdx.x - 64 * NC;
+        float4 pf[3][PFN];
         // Straight-line on purpose (chunk indices are clamped instead of guarded): with branches around
         // the loads hipcc can no longer count how many younger loads may stay in flight and drains
         // the whole queue (vmcnt(0)) before every split, which serialises the stream with HBM latency.
-        auto fetch = [&](float4 (&set)[8], int64_t chunk) {
+        auto fetch = [&](float4 (&set)[PFN], int64_t chunk) {
             if (chunk > nchunks - 1) chunk = nchunks - 1;
             const int64_t r0 = tile_of(chunk) * kTR;
             const int kc = KC == 1 ? 0 : (static_cast<int>(chunk % KC) + rot) % KC;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int L = pt + 256 * i;
+            for (int i = 0; i < PFN; ++i) {
+                const int L = pt + 64 * NM * i;
                 int64_t row = r0 + (L >> 5);
                 if (row > R - 1) row = R - 1;
                 set[i] = ld4(a + row * K + kc * 128 + (L & 31) * 4);
             }
         };
-        auto write = [&](const float4 (&set)[8], int64_t chunk) {   // chunks past the end land in the idle buffer
+        auto write = [&](const float4 (&set)[PFN], int64_t chunk) {   // chunks past the end land in the idle buffer
             char* pl = lds + (chunk & 1) * kX6Buf;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
+            for (int i = 0; i < PFN; ++i) {
+                const int L = pt + 64 * NM * i, r = L >> 5, c4 = L & 31;
                 u32x2 h, m, l;
                 split4(set[i], h, m, l);
                 *reinterpret_cast<u32x2*>(pl + 0 * kX6Plane + r * kX6Pitch + c4 * 8) = h;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     // at the start of the unit, half 0 of the next unit after the first four k-steps.
     bf16x8 bset[2][3][4];
     auto load_b = [&](bf16x8 (&bfr)[3][4], int g, int kc, int h) {
-        const bf16x8* wp = packed + static_cast<size_t>(4 * g + w) * KS * 3 * 64 + lane;
+        const bf16x8* wp = packed + static_cast<size_t>(NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) * KS * 3 * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     };
     float bias_g[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) bias_g[g] = ep.bias ? ep.bias[128 * g + 32 * w + col] : 0.f;
+    for (int g = 0; g < NG; ++g) bias_g[g] = ep.bias ? ep.bias[32 * (NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) + col] : 0.f;
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
     f32x16 acc[2];
     // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
@@ -609,10 +614,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
         }
         if (!EXCH && kc == KC - 1) {
             // direct epilogue of column group g from the accumulator layout
-            constexpr bool BITS = NG == 3;   // ReLU bit masks in / out: only the fc1-shaped launches use them
-            const int n = 128 * g + 32 * w + col;
+            constexpr bool BITS = NG == 3 || NC == 6;   // ReLU bit masks in / out: only the fc1-shaped launches use them
+            const int slab = NC == 6 ? 6 * static_cast<int>(blockIdx.y) + w : 4 * g + w;
+            const int n = 32 * slab + col;
             const float bias = bias_g[g];
-            const size_t bix = (static_cast<size_t>(tix) * (4 * NG) + 4 * g + w) * 64 + lane;
+            const size_t bix = (static_cast<size_t>(tix) * SLABS + slab) * 64 + lane;
             unsigned bits = 0xFFFFFFFFu, newbits = 0;
             if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
             float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
@@ -812,7 +818,15 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
         hipLaunchKernelGGL((row_gemm_x6_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kX6Lds, stream, a,           \
                            reinterpret_cast<const bf16x8*>(packed), y, R, ep);                                     \
     }
-        if (K == 128 && N == 384) LAUNCH6(1, 3, false)
+        static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
+        if (K == 128 && N == 384 && split_n) {   // two 192-column halves, B resident in six consumer waves
+            static const hipError_t attr66 = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&row_gemm_x6_kernel<1, 1, false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                kX6Lds);
+            (void)attr66;
+            hipLaunchKernelGGL((row_gemm_x6_kernel<1, 1, false, 6>), dim3(seqs, 2), dim3(512), kX6Lds, stream, a,
+                               reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+        } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
         else if (K == 128) LAUNCH6(1, 1, false)
         else if (exch) LAUNCH6(3, 1, true)
