@@ -739,6 +739,284 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     for (int64_t c = nchunks; c < padded; ++c) __syncthreads();   // match the producers' padded iterations
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// K = 384 -> N = 128 (fc2 forward, fc1 input gradient): the contraction is three 128-wide chunks whose B
+// fragments cannot all be resident (3 x 96 VGPRs), and re-reading 96 KiB from L2 for every 64-row unit
+// bounds the MFMA phase (every CU pulls the same bytes: ~15-19 TB/s in aggregate).  This program
+//   * walks two tiles at a time, position major -- (t0,0) (t1,0) (t0,1) (t1,1) (t0,2) (t1,2) -- so one set
+//     of B fragments serves two units (two accumulator sets);
+//   * refills the fragments by hand: the load of a k-step's registers is issued right after their last
+//     MFMA in the second unit of a position, the first unit of the next position waits per k-step with the
+//     exact in-order count (3 (7 - ks) younger loads) -- the consumers issue no other VMEM operation;
+//   * keeps every global access in waves 4..7: A chunks HBM -> registers (three deep) -> split -> bf16
+//     planes, and the finished tile's epilogue (exchange tile in LDS -> residual / LayerNorm -> 512-byte
+//     row stores).  Their loop is one straight line per tile pair so that hipcc can count loads in flight.
+// Barriers: B(c) ends every chunk; A(c) precedes the exchange-tile write of a chunk that completes a tile.
+__device__ __forceinline__ void load_b128_async(bf16x8& dst, const bf16x8* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_b_refill(bf16x8& b0, bf16x8& b1, bf16x8& b2) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b0), "+v"(b1), "+v"(b2) : "n"(N));
+}
+
+template <bool EXCH>
+__global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* __restrict__ a, const bf16x8* __restrict__ packed,
+                                                                  float* __restrict__ y, int64_t R, Epilogue ep) {
+    constexpr int KC = 3, K = 384, KS = 24;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* lds = smem_raw;                                          // planes[2][3][64 rows][272 B]
+    float* ex = reinterpret_cast<float*>(smem_raw + 2 * kX6Buf);   // exchange tile [64][128] fp32
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    if (static_cast<int64_t>(blockIdx.x) >= tiles) return;
+    const int ntl = static_cast<int>((tiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int npairs = ntl / 2, nchunks = 3 * ntl;
+    const int rot = static_cast<int>(blockIdx.x % 3);   // rotated chunk order per workgroup (spreads the L2 stream)
+    auto tile_row0 = [&](int ti) { return (blockIdx.x + static_cast<int64_t>(ti) * gridDim.x) * kTR; };
+    auto chunk_map = [&](int c, int& ti, int& pos) {
+        if (c < 6 * npairs) {
+            const int p = c / 6, r = c - 6 * p;
+            pos = r >> 1;
+            ti = 2 * p + (r & 1);
+        } else {
+            pos = c - 6 * npairs;
+            ti = ntl - 1;
+        }
+    };
+
+    if (w >= 4) {
+        // ---------------------------------------------------------------------- movers
+        const int pw = w - 4, pt = threadIdx.x - 256;
+        float4 pf[3][8];
+        auto fetch = [&](float4 (&set)[8], int c) {
+            if (c > nchunks - 1) c = nchunks - 1;
+            int ti, pos;
+            chunk_map(c, ti, pos);
+            const int64_t r0 = tile_row0(ti);
+            const int kc = (pos + rot) % KC;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int L = pt + 256 * i;
+                int64_t row = r0 + (L >> 5);
+                if (row > R - 1) row = R - 1;
+                set[i] = ld4(a + row * K + kc * 128 + (L & 31) * 4);
+            }
+        };
+        auto write = [&](const float4 (&set)[8], int c) {   // chunks past the end land in the idle buffer
+            char* pl = lds + (c & 1) * kX6Buf;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
+                u32x2 h, m, l;
+                split4(set[i], h, m, l);
+                *reinterpret_cast<u32x2*>(pl + 0 * kX6Plane + r * kX6Pitch + c4 * 8) = h;
+                *reinterpret_cast<u32x2*>(pl + 1 * kX6Plane + r * kX6Pitch + c4 * 8) = m;
+                *reinterpret_cast<u32x2*>(pl + 2 * kX6Plane + r * kX6Pitch + c4 * 8) = l;
+            }
+        };
+        float4 res[8];   // residual rows of the tile being finished: pw * 16 + it * 2 + half
+        auto fetch_residual = [&](int ti) {
+            if (!EXCH || !ep.residual) return;
+            const int64_t r0 = tile_row0(ti);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int64_t rrow = r0 + pw * 16 + it * 2 + half;
+                if (rrow > R - 1) rrow = R - 1;
+                res[it] = ld4(ep.residual + rrow * 128 + col * 4);
+            }
+        };
+        auto store_tile = [&](int ti) {   // exchange tile -> residual / LayerNorm -> global rows
+            const int64_t r0 = tile_row0(ti);
+            const bool full = r0 + kTR <= R;
+            float* yrow = y + (r0 + pw * 16 + half) * 128 + col * 4;
+            float4 gam = f4(0.f), bet = f4(0.f);
+            if (EXCH && ep.gamma) {
+                gam = ld4(ep.gamma + col * 4);
+                bet = ld4(ep.beta + col * 4);
+            }
+            // two groups of four rows (register budget); inside a group every result has its own registers and
+            // the stores follow the arithmetic
+#pragma unroll
+            for (int hg = 0; hg < 2; ++hg) {
+                float4 yv[4], pv[4];
+                float mu4[4], rs4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int it = 4 * hg + j, rr = pw * 16 + it * 2 + half;
+                    float4 v = ld4(ex + rr * 128 + col * 4);
+                    if (EXCH && ep.residual) v += res[it];
+                    pv[j] = v;
+                    if (EXCH && ep.gamma) {
+                        const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+                        const float4 d = v - f4(mu);
+                        const float var = half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+                        const float rs = rsqrtf(var + ep.eps);
+                        v = fma4(rs * d, gam, bet);
+                        mu4[j] = mu;
+                        rs4[j] = rs;
+                    }
+                    yv[j] = v;
+                }
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = 4 * hg + j;
+                        st4(yrow + it * 256, yv[j]);
+                        if (EXCH && ep.pre && ep.gamma) st4(ep.pre + (r0 + pw * 16 + it * 2 + half) * 128 + col * 4, pv[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = 4 * hg + j, rr = pw * 16 + it * 2 + half;
+                        if (r0 + rr < R) {
+                            st4(yrow + it * 256, yv[j]);
+                            if (EXCH && ep.pre && ep.gamma) st4(ep.pre + (r0 + rr) * 128 + col * 4, pv[j]);
+                        }
+                    }
+                }
+                if (EXCH && ep.gamma && col == 0) {   // one divergent block per group for the row statistics
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rr = pw * 16 + (4 * hg + j) * 2 + half;
+                        if (r0 + rr < R) {
+                            ep.mean[r0 + rr] = mu4[j];
+                            ep.rstd[r0 + rr] = rs4[j];
+                        }
+                    }
+                }
+            }
+        };
+        fetch(pf[0], 0);
+        fetch(pf[1], 1);
+        fetch(pf[2], 2);
+        write(pf[0], 0);
+        fetch(pf[0], 3);
+        __syncthreads();   // chunk 0 is in planes[0]
+        int c = 0;
+        for (int p = 0; p < npairs; ++p, c += 6) {
+            const int t0 = 2 * p, t1 = 2 * p + 1;
+            write(pf[1], c + 1); fetch(pf[1], c + 4); __syncthreads();                              // (t0, 0)
+            write(pf[2], c + 2); fetch(pf[2], c + 5); __syncthreads();                              // (t1, 0)
+            write(pf[0], c + 3); fetch(pf[0], c + 6); __syncthreads();                              // (t0, 1)
+            write(pf[1], c + 4); fetch(pf[1], c + 7); fetch_residual(t0); __syncthreads();          // (t1, 1)
+            write(pf[2], c + 5); fetch(pf[2], c + 8); __syncthreads(); __syncthreads();             // (t0, 2): A, B
+            store_tile(t0);
+            fetch_residual(t1);
+            write(pf[0], c + 6); fetch(pf[0], c + 9); __syncthreads(); __syncthreads();             // (t1, 2): A, B
+            store_tile(t1);
+        }
+        if (ntl & 1) {
+            const int t = ntl - 1;
+            write(pf[1], c + 1); fetch(pf[1], c + 4); __syncthreads();                              // (t, 0)
+            write(pf[2], c + 2); fetch(pf[2], c + 5); fetch_residual(t); __syncthreads();           // (t, 1)
+            write(pf[0], c + 3); __syncthreads(); __syncthreads();                                  // (t, 2): A, B
+            store_tile(t);
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------------- consumers
+    bf16x8 bfr[3][8];
+    auto b_ptr = [&](int pos) { return packed + (static_cast<size_t>(w) * KS + ((pos + rot) % KC) * 8) * 3 * 64 + lane; };
+    {
+        const bf16x8* b0 = b_ptr(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[p][ks] = b0[(ks * 3 + p) * 64];
+    }
+    const float bias = ep.bias ? ep.bias[32 * w + col] : 0.f;
+    f32x16 accs[2][2];
+    int chunk = 0;
+    __syncthreads();   // chunk 0 is in planes[0]
+    auto body = [&](int pos, f32x16 (&acc)[2], auto second_tag) {
+        constexpr bool SECOND = decltype(second_tag)::value;
+        if (pos == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        }
+        const bf16x8* bnext = b_ptr((pos + 1) % KC);
+        const char* pl = lds + (chunk & 1) * kX6Buf;
+        bf16x8 af[2][2][3];
+        auto frags = [&](int ks, bf16x8 (&dst)[2][3]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    dst[m][p] = *reinterpret_cast<const bf16x8*>(pl + p * kX6Plane + (32 * m + col) * kX6Pitch +
+                                                                 (ks * 16 + 8 * half) * 2);
+        };
+        frags(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) frags(ks + 1, af[(ks + 1) & 1]);
+            if (!SECOND) {
+                switch (ks) {
+                    case 0: wait_b_refill<21>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 1: wait_b_refill<18>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 2: wait_b_refill<15>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 3: wait_b_refill<12>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 4: wait_b_refill<9>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 5: wait_b_refill<6>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 6: wait_b_refill<3>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    default: wait_b_refill<0>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                }
+            }
+            const bf16x8(&f)[2][3] = af[ks & 1];
+            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[m][TA[t]], bfr[TB[t]][ks], acc[m], 0, 0, 0);
+            if (SECOND) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) load_b128_async(bfr[p][ks], bnext + (ks * 3 + p) * 64);
+            }
+        }
+        if (pos == KC - 1) {
+            __syncthreads();   // A: the movers have finished with the previous exchange tile
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    float v = acc[m][reg] + bias;
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    ex[rr * 128 + 32 * w + col] = v;
+                }
+        }
+        __syncthreads();   // B
+        ++chunk;
+    };
+    for (int p = 0; p < npairs; ++p) {
+#pragma unroll 1
+        for (int pos = 0; pos < KC; ++pos) {
+            body(pos, accs[0], std::false_type{});
+            body(pos, accs[1], std::true_type{});
+        }
+    }
+    if (ntl & 1) {
+#pragma unroll 1
+        for (int pos = 0; pos < KC; ++pos) {
+            body(pos, accs[0], std::false_type{});
+            if (pos + 1 < KC) {   // no partner tile: refill between the units
+                const bf16x8* bnext = b_ptr(pos + 1);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) load_b128_async(bfr[q][ks], bnext + (ks * 3 + q) * 64);
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace dg
 
@@ -829,7 +1107,21 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
         else if (K == 128) LAUNCH6(1, 1, false)
-        else if (exch) LAUNCH6(3, 1, true)
+        else if (!(getenv("DG_GEMM_K384") && strcmp(getenv("DG_GEMM_K384"), "stream") == 0)) {
+            constexpr int lds384 = 2 * kX6Buf + kTR * 128 * 4;
+            static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_k384_kernel<true>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds384);
+            static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_k384_kernel<false>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds384);
+            (void)a1;
+            (void)a2;
+            if (exch)
+                hipLaunchKernelGGL(row_gemm_x6_k384_kernel<true>, dim3(seqs), dim3(512), lds384, stream, a,
+                                   reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+            else
+                hipLaunchKernelGGL(row_gemm_x6_k384_kernel<false>, dim3(seqs), dim3(512), lds384, stream, a,
+                                   reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+        } else if (exch) LAUNCH6(3, 1, true)
         else LAUNCH6(3, 1, false)
 #undef LAUNCH6
         return check_launch("dg_row_gemm");
