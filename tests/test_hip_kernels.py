@@ -249,6 +249,26 @@ def test_row_gemm_forward_and_dgrad_modes(R, K, N):
     assert _rel(y, a @ w2) < TOL
 
 
+@pytest.mark.parametrize("N,K", [(128, 128), (384, 128), (128, 384)])
+def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
+    """Same claim for the weight-gradient kernel (dW = dy^T x on the bf16x6 split): its error against fp64,
+    relative to sum_r |dy x|, stays at the level of torch's fp32 matmul of the same data."""
+    from druggen_amd import functional as dgf
+    R = 8192
+    dy, x = _gen((R, N), 21), _gen((R, K), 22)
+    dyd, xd = dy.float().cuda(), x.float().cuda()
+    want = dy.t() @ x
+    scale = dy.abs().t() @ x.abs()
+    def err(w):
+        e = (w.double().cpu() - want).abs() / scale
+        return e.max().item(), e.pow(2).mean().sqrt().item()
+    mine_max, mine_rms = err(dgf._wgrad(dyd, xd, True)[0])
+    torch.backends.cuda.matmul.allow_tf32 = False
+    ref_max, ref_rms = err(dyd.t() @ xd)
+    print(f"N={N} K={K}: wgrad max {mine_max:.2e} rms {mine_rms:.2e} | fp32 matmul max {ref_max:.2e} rms {ref_rms:.2e}")
+    assert mine_rms < 1.5 * ref_rms + 2e-9 and mine_max < 2.5 * ref_max
+
+
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (384, 128)])
 def test_row_gemm_split_bf16_is_fp32_class_accurate(K, N):
     """The row GEMM splits fp32 operands three ways into bf16 and runs six MFMA cross products with fp32
