@@ -36,6 +36,12 @@ CASES = {
     # BASELINE.json configs[1] shape (N=45, L=4, E=5, M=13, dim 128) at batch 2
     "c2_b2": dict(cfg=dict(act="relu", vertexes=45, edges=5, nodes=13, dim=128, depth=4, heads=8, mlp_ratio=3),
                   batch=2, submodel="DrugGEN", seed=22, lambda_gp=10.0, full=False),
+    # dim-128 (fused-kernel) path with a non-ReLU embedding / head activation
+    "c1_tanh_b4": dict(cfg=dict(act="tanh", vertexes=9, edges=5, nodes=5, dim=128, depth=1, heads=8, mlp_ratio=3),
+                       batch=4, submodel="DrugGEN", seed=24, lambda_gp=10.0, full=False),
+    # BASELINE.json configs[4] geometry (N=90 atoms, 10 bond types) at depth 2, batch 2
+    "c5_b2": dict(cfg=dict(act="relu", vertexes=90, edges=10, nodes=13, dim=128, depth=2, heads=8, mlp_ratio=3),
+                  batch=2, submodel="NoTarget", seed=25, lambda_gp=10.0, full=False),
     # Real molecular graphs: SMILES shipped with the reference's results (tests/golden/chembl_like_smiles.csv),
     # featurised by druggen_amd.smiles with the atom / bond tables the reference's encoder construction
     # (src/data/utils.py:70-126) yields over those result files: atoms {PAD,B,C,N,O,F,P,S,Cl}, bonds
