@@ -40,20 +40,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libdruggen_hip.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + [HEADER]
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and all(os.path.getmtime(obj) > os.path.getmtime(h)
-                        for h in glob.glob(os.path.join(CSRC, "*.h")) + [HEADER])):
-            objs.append(obj)
+                and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in headers)):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-               "-c", src, "-o", obj]
+        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+                     "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    if jobs:     # one hipcc per translation unit, in parallel
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, jobs))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -454,10 +454,7 @@ extern "C" int dg_attn_core_bwd(const float* q, const float* k, const float* v, 
 #define LAUNCH_RW(LQS, JPL, RW_)                                                                               \
     {                                                                                                          \
         constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL) * 64 * 16;                                         \
-        static const hipError_t attr = hipFuncSetAttribute(                                                    \
-            reinterpret_cast<const void*>(&attn_bwd_kernel<LQS, JPL, RW_>),                                    \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                  \
-        (void)attr;                                                                                            \
+        DG_OPT_IN_LDS((&attn_bwd_kernel<LQS, JPL, RW_>), lds);                                                  \
         hipLaunchKernelGGL((attn_bwd_kernel<LQS, JPL, RW_>), grid, block, lds, stream, q, k, v, e, ws, wo, dq, \
                            dk, dv, de, N, C, alpha);                                                           \
     }
@@ -487,10 +484,7 @@ extern "C" int dg_attn_core_bwd2(const float* q, const float* k, const float* v,
 #define LAUNCH(LQS, JPL)                                                                                          \
     if (g.lqs == LQS && g.jpl == JPL) {                                                                           \
         constexpr int lds = (4 * JPL + (kRW - 1) * 2 * JPL) * 64 * 16;                                            \
-        static const hipError_t attr = hipFuncSetAttribute(                                                       \
-            reinterpret_cast<const void*>(&attn_bwd2_kernel<LQS, JPL, kRW>),                                      \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                     \
-        (void)attr;                                                                                               \
+        DG_OPT_IN_LDS((&attn_bwd2_kernel<LQS, JPL, kRW>), lds);                                                     \
         hipLaunchKernelGGL((attn_bwd2_kernel<LQS, JPL, kRW>), grid, block, lds, stream, q, k, v, e, ws, wo, tq,   \
                            tk, tv, te, gq, gk, gv, ge, gws, gwo, N, C, alpha);                                    \
     }

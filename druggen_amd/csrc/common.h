@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -15,6 +16,18 @@ namespace dg {
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+
+// ---- dynamic LDS opt-in -------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: it has to be set
+// on every device the kernel is launched on (nn.DataParallel drives several GPUs from one process),
+// and a failure must surface.  One bit per device ordinal in `done`; devices >= 64 are always re-set.
+int opt_in_dynamic_lds(std::atomic<unsigned long long>* done, const void* kernel, int bytes);
+#define DG_OPT_IN_LDS(kernel_ptr, bytes)                                                                         \
+    do {                                                                                                         \
+        static std::atomic<unsigned long long> dg_lds_done_{0};                                                  \
+        if (int dg_lds_st_ = dg::opt_in_dynamic_lds(&dg_lds_done_, reinterpret_cast<const void*>(kernel_ptr), (bytes))) \
+            return dg_lds_st_;                                                                                   \
+    } while (0)
 
 // ---- profiler (prof.hip) ----------------------------------------------------
 struct ProfScope {

@@ -449,12 +449,8 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
-    static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel<8>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    static const hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sym_bwd_kernel<16>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)attr8;
-    (void)attr16;
+    DG_OPT_IN_LDS((&embed_sym_bwd_kernel<8>), lds_bytes);
+    DG_OPT_IN_LDS((&embed_sym_bwd_kernel<16>), lds_bytes);
     ProfScope prof(DG_K_EMBED_SYM, stream);
     if (E <= 8)
         hipLaunchKernelGGL(embed_sym_bwd_kernel<8>, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,

@@ -414,10 +414,7 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
 #define LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, X_)                                                                 \
     {                                                                                                            \
         constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * 4;                                  \
-        static const hipError_t attr =                                                                           \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                          \
-        (void)attr;                                                                                              \
+        DG_OPT_IN_LDS((&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>), lds_bytes);                          \
         hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>), dim3(S), dim3(WN_* WK_ * 64),         \
                            lds_bytes, stream, dy, dy_mask, x, part_w, part_b, R, tpb);                           \
     }

@@ -1089,19 +1089,13 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
         (void)ng;
 #define LAUNCH6(KC_, NG_, EX_)                                                                                     \
     {                                                                                                              \
-        static const hipError_t attr6 =                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_kernel<KC_, NG_, EX_>),                 \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kX6Lds);                               \
-        (void)attr6;                                                                                               \
+        DG_OPT_IN_LDS((&row_gemm_x6_kernel<KC_, NG_, EX_>), kX6Lds);                               \
         hipLaunchKernelGGL((row_gemm_x6_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kX6Lds, stream, a,           \
                            reinterpret_cast<const bf16x8*>(packed), y, R, ep);                                     \
     }
         static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
         if (K == 128 && N == 384 && split_n) {   // two 192-column halves, B resident in six consumer waves
-            static const hipError_t attr66 = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&row_gemm_x6_kernel<1, 1, false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                kX6Lds);
-            (void)attr66;
+            DG_OPT_IN_LDS((&row_gemm_x6_kernel<1, 1, false, 6>), kX6Lds);
             hipLaunchKernelGGL((row_gemm_x6_kernel<1, 1, false, 6>), dim3(seqs, 2), dim3(512), kX6Lds, stream, a,
                                reinterpret_cast<const bf16x8*>(packed), y, R, ep);
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
@@ -1109,12 +1103,8 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
         else if (K == 128) LAUNCH6(1, 1, false)
         else if (!(getenv("DG_GEMM_K384") && strcmp(getenv("DG_GEMM_K384"), "stream") == 0)) {
             constexpr int lds384 = 2 * kX6Buf + kTR * 128 * 4;
-            static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_k384_kernel<true>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds384);
-            static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_gemm_x6_k384_kernel<false>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds384);
-            (void)a1;
-            (void)a2;
+            DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<true>), lds384);
+            DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<false>), lds384);
             if (exch)
                 hipLaunchKernelGGL(row_gemm_x6_k384_kernel<true>, dim3(seqs), dim3(512), lds384, stream, a,
                                    reinterpret_cast<const bf16x8*>(packed), y, R, ep);
@@ -1130,10 +1120,7 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
 #define LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, XP_)                                               \
     {                                                                                                              \
         constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4 + (XP_ ? TR_ * 128 * 4 : 0);                             \
-        static const hipError_t attr = hipFuncSetAttribute(                                                        \
-            reinterpret_cast<const void*>(&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>),           \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                                \
-        (void)attr;                                                                                                \
+        DG_OPT_IN_LDS((&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>), lds_bytes);                                                \
         const int64_t tiles = (R + TR_ - 1) / TR_;                                                                 \
         const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                          \
         hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>), dim3(grid),              \

@@ -25,6 +25,20 @@ int check_launch(const char* what) {
     return 0;
 }
 
+int opt_in_dynamic_lds(std::atomic<unsigned long long>* done, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return fail(static_cast<int>(err), "hipGetDevice: %s", hipGetErrorString(err));
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (done->load(std::memory_order_acquire) & bit)) return 0;
+    err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (err != hipSuccess)
+        return fail(static_cast<int>(err), "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) on device %d: %s", bytes,
+                    dev, hipGetErrorString(err));
+    if (bit) done->fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 // ---- profiler ---------------------------------------------------------------
 namespace {
 struct Span {

@@ -17,9 +17,13 @@ from .functional import _dev
 __all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot"]
 
 
-def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check: bool = False):
+def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check: bool = True):
     """``label2onehot(to_dense_adj(edge_index, batch, edge_attr, max_num_nodes=N), b_dim)`` for a
-    batch whose graphs are all padded to ``vertexes`` nodes (utils.py:130-137)."""
+    batch whose graphs are all padded to ``vertexes`` nodes (utils.py:130-137).
+
+    ``check=True`` (default) raises on bond labels outside ``[0, b_dim)`` like the reference's
+    ``scatter_`` does (one 4-byte device->host read per batch; the reference's loader syncs per
+    batch anyway).  Pass ``check=False`` on a path that must not synchronise."""
     if not edge_index.is_cuda:
         raise RuntimeError("druggen_amd.data runs on the GPU (no CPU fallback)")
     lib = _lib.load()

@@ -10,7 +10,6 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
-import threading
 import weakref
 
 import torch
@@ -250,7 +249,22 @@ def ln_residual(a, r, gamma, beta, eps: float = 1e-5):
 # (reference: every nn.Linear of src/model/layers.py; forward / input-gradient
 # contractions stay on the ROCm BLAS behind F.linear / matmul)
 # --------------------------------------------------------------------------
-_tls = threading.local()
+class _Flags:
+    """Process-wide (NOT thread-local) pass flags.  A backward node of a CUDA tensor runs on the
+    autograd engine's device thread, and nn.DataParallel runs every replica forward on its own thread:
+    neither sees a ``threading.local`` set by the thread that entered the context manager (round-1
+    bug: the gradient penalty's first-order pass still computed every weight gradient).  The two
+    contexts below are entered by one thread at a time (``gradient_penalty`` is synchronous), so a
+    plain counter is enough."""
+    inputs_only = 0
+    second_order = 0
+
+
+_flags = _Flags()
+
+
+def _inputs_only() -> bool:
+    return _flags.inputs_only > 0
 
 
 @contextlib.contextmanager
@@ -259,12 +273,11 @@ def inputs_only_backward():
     custom ops.  Used around the gradient penalty's first-order
     ``autograd.grad(..., inputs=[int_node, int_edge])`` (loss.py:32-39), where
     PyTorch's built-in ops skip them too but custom Functions cannot tell."""
-    prev = getattr(_tls, "inputs_only", False)
-    _tls.inputs_only = True
+    _flags.inputs_only += 1
     try:
         yield
     finally:
-        _tls.inputs_only = prev
+        _flags.inputs_only -= 1
 
 
 def _wgrad(dy2, x2, want_bias, dy_mask=None):
@@ -315,7 +328,7 @@ class _Linear(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        need_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
+        need_w = ctx.needs_input_grad[1] and not _inputs_only()
         dx, dw, db = _LinearBwd.apply(x, w, dy, ctx.has_bias and need_w, ctx.needs_input_grad[0], need_w)
         return dx, dw, db
 
@@ -342,7 +355,7 @@ class _LinearBwd(Function):
         if tdx is not None:
             tdx = _c(tdx)
             g_dy = _mm_rows(tdx, w, 0)
-            if not getattr(_tls, "inputs_only", False):
+            if not _inputs_only():
                 g_w, _ = _wgrad(dy.reshape(-1, N), tdx.reshape(-1, K), False)
         if tdw is not None:
             g_x = dy.matmul(tdw)
@@ -367,10 +380,17 @@ _weights_epoch = 0
 
 
 def bump_weights_epoch() -> None:
-    """Called by optimizers that update parameters behind autograd's back (raw kernels on a
-    flat buffer do not bump ``tensor._version``): invalidates every packed weight."""
+    """Invalidate every packed weight (both caches share this epoch).  Called by writers that change
+    parameters behind autograd's back: ``FlatAdamW.step`` (raw kernel on the flat buffer) and
+    ``GraphedGANStep`` (before capture, so that the first use after each optimizer step records its
+    pack kernel into the graph, and after every replay, which updates weights without touching
+    ``tensor._version``)."""
     global _weights_epoch
     _weights_epoch += 1
+    if len(_pack_cache) + len(_embed_pack_cache) > 8192:
+        for cache in (_pack_cache, _embed_pack_cache):
+            for k in [k for k, v in cache.items() if v[0]() is None]:
+                del cache[k]
 
 
 def packed_weight(w, mode: int):
@@ -439,16 +459,15 @@ def second_order_forward():
     (gradient penalty, loss.py:28-39): modules then build their graph from the
     twice-differentiable ops (linear / ln_residual / attn_core) instead of the
     fused first-order ones, which would have to recompute."""
-    prev = getattr(_tls, "second_order", False)
-    _tls.second_order = True
+    _flags.second_order += 1
     try:
         yield
     finally:
-        _tls.second_order = prev
+        _flags.second_order -= 1
 
 
 def in_second_order_forward() -> bool:
-    return getattr(_tls, "second_order", False)
+    return _flags.second_order > 0
 
 
 def _double_backward_fallback(composite, inputs, grad_out):
@@ -543,7 +562,7 @@ class _FFNLN(Function):
     @staticmethod
     def backward(ctx, dy, dpre):
         x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = ctx.saved_tensors
-        want_w = ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False)
+        want_w = ctx.needs_input_grad[1] and not _inputs_only()
         if dy is None:
             dy = torch.zeros_like(pre)
         dx, dw1, db1, dw2, db2, dgamma, dbeta = _FFNLNBwd.apply(x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits,
@@ -616,7 +635,7 @@ class _FFNLNBwd(Function):
         ubar = row_gemm(vbar, pw(w2, 0), H, C, residual=t)               # t + vbar W2^T
         zbar, dybar, gbar = _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, ubar)
         gw1 = gw2 = None
-        if not getattr(_tls, "inputs_only", False):
+        if not _inputs_only():
             gw1, _ = _wgrad(dh, t, False)                                  # ((u W2)*m)^T t
             gw2, _ = _wgrad(dz, vbar, False)                               # u^T ((t W1^T)*m)
         # dx depends on x only through the saved pre-LN sum z: its adjoint goes back to the forward
@@ -670,7 +689,7 @@ class _LinearLN(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = row_gemm(dz, packed_weight(w, 1), N, K).view(x.shape)
-        if ctx.needs_input_grad[1] and not getattr(_tls, "inputs_only", False):
+        if ctx.needs_input_grad[1] and not _inputs_only():
             dw, db = _wgrad(dz, _c(x).reshape(-1, K), b is not None)
         return dx, dw, db, dz.view(residual.shape), dgamma, dbeta, None
 
@@ -755,7 +774,7 @@ class _AttnBlock(Function):
             add3, aq, ak, av, ae = more
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
-        wants_w = ctx.needs_input_grad[2] and not getattr(_tls, "inputs_only", False)
+        wants_w = ctx.needs_input_grad[2] and not _inputs_only()
         outs = _AttnBlockBwd.apply(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4,
                                    q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
                                    add3, add4, aq, ak, av, ae,
@@ -858,7 +877,7 @@ class _AttnBlockBwd(Function):
         (x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4,
          dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de) = ctx.saved_tensors
         pw = packed_weight
-        with_w = not getattr(_tls, "inputs_only", False)
+        with_w = not _inputs_only()
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         RN, RE = B * N, B * N * N
         zn = lambda: torch.zeros(RN, C, dtype=torch.float32, device=q.device)
@@ -928,7 +947,8 @@ _embed_pack_cache = {}
 def _embed_packed_w2(w2, dgrad: bool = False):
     key = (id(w2), dgrad)
     hit = _embed_pack_cache.get(key)
-    if hit is not None and hit[0]() is w2 and hit[1] == w2._version and hit[3] == w2.data_ptr():
+    if (hit is not None and hit[0]() is w2 and hit[1] == w2._version and hit[3] == w2.data_ptr()
+            and hit[4] == _weights_epoch):
         return hit[2]
     lib = _lib.load()
     n_floats = lib.dg_embed_sym_dgrad_packed_floats() if dgrad else lib.dg_embed_sym_packed_floats()
@@ -937,7 +957,7 @@ def _embed_packed_w2(w2, dgrad: bool = False):
     with _dev(w2):
         pack = lib.dg_embed_sym_pack_dgrad if dgrad else lib.dg_embed_sym_pack
         _lib.check(pack(_lib.ptr(wd), _lib.ptr(packed), _lib.stream_of(w2)), "dg_embed_sym_pack")
-    _embed_pack_cache[key] = (weakref.ref(w2), w2._version, packed, w2.data_ptr())
+    _embed_pack_cache[key] = (weakref.ref(w2), w2._version, packed, w2.data_ptr(), _weights_epoch)
     return packed
 
 
@@ -987,7 +1007,7 @@ class _EmbedSym(Function):
                                             _ACT_IDS[act], _lib.stream_of(a)), "dg_embed_sym_bwd")
         _account("embed_sym", 4 * B * N * N * (E * (2 if da is not None else 1) + C),
                  2 * B * N * N * (E * H + H * C) * 3)
-        if not ctx.needs_input_grad[1] or getattr(_tls, "inputs_only", False):
+        if not ctx.needs_input_grad[1] or _inputs_only():
             dw1 = db1 = dw2 = db2 = None
         return da, dw1, db1, dw2, db2, None
 

@@ -15,7 +15,7 @@ from typing import Iterable, List, Optional
 import torch
 
 from . import _lib
-from .functional import _dev
+from .functional import _dev, bump_weights_epoch
 
 __all__ = ["FlatAdamW"]
 
@@ -99,3 +99,4 @@ class FlatAdamW:
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that
         # version-keyed caches (packed GEMM weights) notice, exactly as an in-place torch op would
         torch.autograd.graph.increment_version([self.params[i] for i in self._live])
+        bump_weights_epoch()

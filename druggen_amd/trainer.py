@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .model.loss import discriminator_loss, generator_loss
+from .functional import bump_weights_epoch
 from .optim import FlatAdamW
 
 __all__ = ["GANStep", "GraphedGANStep", "GradBucket", "broadcast_parameters"]
@@ -192,13 +193,23 @@ class GraphedGANStep:
             for _ in range(warmup):            # weights, flat optimizer state, hipFuncSetAttribute calls
                 stepper.step(*self.static)
         torch.cuda.current_stream().wait_stream(side)
+        # Packed GEMM weights are cached per (tensor, version, epoch).  Without this bump the capture
+        # below would hit the warm-up's packs for every weight that is not updated before its first
+        # use inside the step: no pack kernel would be recorded and every replay would run D's GEMMs
+        # on weights frozen at the end of warm-up.  With it, each first use records its pack kernel,
+        # so a replay re-packs from the live parameters exactly like an eager step.
+        bump_weights_epoch()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.losses = stepper.step(*self.static)
+        bump_weights_epoch()    # cache entries made during capture point into the graph's private pool
 
     def step(self, disc_edge=None, disc_node=None, gen_edge=None, gen_node=None):
         for dst, src in zip(self.static, (disc_edge, disc_node, gen_edge, gen_node)):
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
         self.graph.replay()
+        # the replay updated G and D in place without bumping tensor versions: an eager forward after
+        # it must not reuse packs keyed on the old versions
+        bump_weights_epoch()
         return self.losses
