@@ -23,7 +23,7 @@
 //     atomics and are bit-reproducible.  Row groups of one block are combined
 //     once at the end through LDS in a fixed order.
 //   * narrow models (C < 32) use fewer quads per slice (LQS) and more phases.
-#include "common.h"
+#include "bf16.h"
 
 namespace dg {
 namespace {
@@ -55,10 +55,10 @@ struct Lane {
 };
 
 // ---------------------------------------------------------------- forward ----
-template <int LQS, int JPL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, const float* __restrict__ e,
-                                                      float* __restrict__ s, float* __restrict__ o, int N, int C,
+template <typename T, int LQS, int JPL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                      const T* __restrict__ v, const T* __restrict__ e,
+                                                      T* __restrict__ s, T* __restrict__ o, int N, int C,
                                                       float alpha, int RG) {
     constexpr int QS = 1 << LQS;
     const int lane = threadIdx.x & 63;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int i = rg; i < N; i += RG) {
         const size_t row = static_cast<size_t>(b) * N + i;
         const float4 aq = alpha * ld4(q + row * C + L.c0);
-        const float* er = e + row * NC;
-        float* sr = s + row * NC;
+        const T* er = e + row * NC;
+        T* sr = s + row * NC;
         float4 sv[JPL];
 #pragma unroll
         for (int t = 0; t < JPL; ++t) sv[t] = ld4_stream(er + L.off[t]);
@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 }
 
 // --------------------------------------------------------------- backward ----
-template <int LQS, int JPL, int RW>
+template <typename T, int LQS, int JPL, int RW>
 __global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const float* __restrict__ e, const float* __restrict__ ws, const float* __restrict__ wo,
-    float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ de, int N, int C,
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+    const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
+    T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, T* __restrict__ de, int N, int C,
     float alpha) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
         asm volatile("" : "+v"(kl));         // loop instead of hoisting 2*JPL float4 into registers
         const float4 aq = alpha * ld4(q + row * C + L.c0);
         const float4 woi = ld4(wo + row * C + L.c0);
-        const float* er = e + row * NC;
-        const float* wr = ws + row * NC;
-        float* der = de + row * NC;
+        const T* er = e + row * NC;
+        const T* wr = ws + row * NC;
+        T* der = de + row * NC;
         float4 ee[JPL], wss[JPL], pe[JPL];
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
@@ -218,13 +218,13 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
 // Inputs of the first-order backward: (q,k,v,e,ws,wo); (tq,tk,tv,te) are the
 // adjoints of its outputs (dq,dk,dv,de).  See tests/kernel_math.py::attn_core_bwd2
 // for the closed form (verified against autograd in float64).
-template <int LQS, int JPL, int RW>
+template <typename T, int LQS, int JPL, int RW>
 __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const float* __restrict__ e, const float* __restrict__ ws, const float* __restrict__ wo,
-    const float* __restrict__ tq, const float* __restrict__ tk, const float* __restrict__ tv,
-    const float* __restrict__ te, float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv,
-    float* __restrict__ ge, float* __restrict__ gws, float* __restrict__ gwo, int N, int C, float alpha) {
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+    const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
+    const T* __restrict__ tq, const T* __restrict__ tk, const T* __restrict__ tv,
+    const T* __restrict__ te, T* __restrict__ gq, T* __restrict__ gk, T* __restrict__ gv,
+    T* __restrict__ ge, T* __restrict__ gws, T* __restrict__ gwo, int N, int C, float alpha) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // per-neighbour operands live in LDS (read-only, shared by the RW waves):
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
         const float4 aq = alpha * qi;
         const float4 woi = ld4(wo + row * C + L.c0);
         const float4 tqi = ld4(tq + row * C + L.c0);
-        const float* er = e + row * NC;
-        const float* wr = ws + row * NC;
-        const float* tr = te + row * NC;
+        const T* er = e + row * NC;
+        const T* wr = ws + row * NC;
+        const T* tr = te + row * NC;
         float4 ee[JPL], wss[JPL], tee[JPL], pe[JPL], sd[JPL];
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
         const float4 abar = A * inv;
         // tangent of s along t, and m = sum_j p sdot
         float4 mm = f4(0.f);
-        float* gwr = gws + row * NC;
+        T* gwr = gws + row * NC;
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             const float4 kk = kv[(0 * JPL + t) * 64 + kl];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
         PB = xor_sum4<QS>(PB);
         if (L.phase == 0 && L.cok) st4(gwo + row * C + L.c0, od);
         float4 gqa = f4(0.f);
-        float* ger = ge + row * NC;
+        T* ger = ge + row * NC;
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             const float4 kk = kv[(0 * JPL + t) * 64 + kl];
@@ -414,9 +414,10 @@ constexpr int kRW = 4;  // row groups (waves) per backward block
 
 using namespace dg;
 
-extern "C" int dg_attn_core_fwd(const float* q, const float* k, const float* v, const float* e, float* s, float* o,
-                                int B, int N, int C, float alpha, dg_stream_t stream_) {
-    if (!q || !k || !v || !e || !o) return fail(DG_E_ARG, "dg_attn_core_fwd: null pointer");  // s may be NULL
+extern "C" int dg_attn_core_fwd(const void* q_, const void* k_, const void* v_, const void* e_, void* s_, void* o_,
+                                int B, int N, int C, float alpha, int dtype, dg_stream_t stream_) {
+    if (!q_ || !k_ || !v_ || !e_ || !o_) return fail(DG_E_ARG, "dg_attn_core_fwd: null pointer");  // s may be NULL
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_attn_core_fwd: unknown dtype %d", dtype);
     Geometry g;
     if (B < 0 || !pick_geometry(N, C, &g))
         return fail(DG_E_SHAPE, "dg_attn_core_fwd: unsupported shape B=%d N=%d C=%d (need C%%4==0, C>=8, N<=96)", B, N, C);
@@ -429,19 +430,27 @@ extern "C" int dg_attn_core_fwd(const float* q, const float* k, const float* v, 
     if (RG > N) RG = N;
     dim3 grid(static_cast<unsigned>(B) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
     ProfScope prof(DG_K_ATTN_FWD, stream);
-#define LAUNCH(LQS, JPL)                                                                                          \
-    if (g.lqs == LQS && g.jpl == JPL)                                                                             \
-        hipLaunchKernelGGL((attn_fwd_kernel<LQS, JPL>), grid, block, 0, stream, q, k, v, e, s, o, N, C, alpha, RG);
+#define LAUNCH_T(T, LQS, JPL)                                                                                     \
+    hipLaunchKernelGGL((attn_fwd_kernel<T, LQS, JPL>), grid, block, 0, stream, static_cast<const T*>(q_),         \
+                       static_cast<const T*>(k_), static_cast<const T*>(v_), static_cast<const T*>(e_),          \
+                       static_cast<T*>(s_), static_cast<T*>(o_), N, C, alpha, RG);
+#define LAUNCH(LQS, JPL)                                       \
+    if (g.lqs == LQS && g.jpl == JPL) {                        \
+        if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, LQS, JPL) } \
+        else { LAUNCH_T(float, LQS, JPL) }                     \
+    }
     DG_FOR_GEOMETRY(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_T
     return check_launch("dg_attn_core_fwd");
 }
 
-extern "C" int dg_attn_core_bwd(const float* q, const float* k, const float* v, const float* e, const float* ws,
-                                const float* wo, float* dq, float* dk, float* dv, float* de, int B, int N, int C,
-                                float alpha, dg_stream_t stream_) {
-    if (!q || !k || !v || !e || !wo || !dq || !dk || !dv || !de)
+extern "C" int dg_attn_core_bwd(const void* q_, const void* k_, const void* v_, const void* e_, const void* ws_,
+                                const void* wo_, void* dq_, void* dk_, void* dv_, void* de_, int B, int N, int C,
+                                float alpha, int dtype, dg_stream_t stream_) {
+    if (!q_ || !k_ || !v_ || !e_ || !wo_ || !dq_ || !dk_ || !dv_ || !de_)
         return fail(DG_E_ARG, "dg_attn_core_bwd: null pointer");  // ws may be NULL (= zeros)
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_attn_core_bwd: unknown dtype %d", dtype);
     Geometry g;
     if (B < 0 || !pick_geometry(N, C, &g))
         return fail(DG_E_SHAPE, "dg_attn_core_bwd: unsupported shape B=%d N=%d C=%d", B, N, C);
@@ -451,12 +460,20 @@ extern "C" int dg_attn_core_bwd(const float* q, const float* k, const float* v, 
     const bool rw8 = rw_env == 8 && g.jpl <= 6;
     dim3 grid(B, g.slices), block(64 * (rw8 ? 8 : kRW));
     ProfScope prof(DG_K_ATTN_BWD, stream);
-#define LAUNCH_RW(LQS, JPL, RW_)                                                                               \
-    {                                                                                                          \
-        constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL) * 64 * 16;                                         \
-        DG_OPT_IN_LDS((&attn_bwd_kernel<LQS, JPL, RW_>), lds);                                                  \
-        hipLaunchKernelGGL((attn_bwd_kernel<LQS, JPL, RW_>), grid, block, lds, stream, q, k, v, e, ws, wo, dq, \
-                           dk, dv, de, N, C, alpha);                                                           \
+#define LAUNCH_T(T, LQS, JPL, RW_)                                                                              \
+    {                                                                                                           \
+        constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL) * 64 * 16;                                          \
+        DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_>), lds);                                                \
+        hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_>), grid, block, lds, stream,                        \
+                           static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_),     \
+                           static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_),   \
+                           static_cast<T*>(dq_), static_cast<T*>(dk_), static_cast<T*>(dv_), static_cast<T*>(de_), \
+                           N, C, alpha);                                                                        \
+    }
+#define LAUNCH_RW(LQS, JPL, RW_)                                        \
+    {                                                                   \
+        if (dtype == DG_DTYPE_BF16) LAUNCH_T(bf16_t, LQS, JPL, RW_)     \
+        else LAUNCH_T(float, LQS, JPL, RW_)                             \
     }
 #define LAUNCH(LQS, JPL)                                  \
     if (g.lqs == LQS && g.jpl == JPL) {                   \
@@ -465,15 +482,17 @@ extern "C" int dg_attn_core_bwd(const float* q, const float* k, const float* v, 
     DG_FOR_GEOMETRY(LAUNCH)
 #undef LAUNCH
 #undef LAUNCH_RW
+#undef LAUNCH_T
     return check_launch("dg_attn_core_bwd");
 }
 
-extern "C" int dg_attn_core_bwd2(const float* q, const float* k, const float* v, const float* e, const float* ws,
-                                 const float* wo, const float* tq, const float* tk, const float* tv, const float* te,
-                                 float* gq, float* gk, float* gv, float* ge, float* gws, float* gwo, int B, int N,
-                                 int C, float alpha, dg_stream_t stream_) {
-    if (!q || !k || !v || !e || !wo || !tq || !tk || !tv || !te || !gq || !gk || !gv || !ge || !gwo)  // ws, gws may be NULL
+extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_, const void* e_, const void* ws_,
+                                 const void* wo_, const void* tq_, const void* tk_, const void* tv_, const void* te_,
+                                 void* gq_, void* gk_, void* gv_, void* ge_, void* gws_, void* gwo_, int B, int N,
+                                 int C, float alpha, int dtype, dg_stream_t stream_) {
+    if (!q_ || !k_ || !v_ || !e_ || !wo_ || !tq_ || !tk_ || !tv_ || !te_ || !gq_ || !gk_ || !gv_ || !ge_ || !gwo_)  // ws, gws may be NULL
         return fail(DG_E_ARG, "dg_attn_core_bwd2: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_attn_core_bwd2: unknown dtype %d", dtype);
     Geometry g;
     if (B < 0 || !pick_geometry(N, C, &g))
         return fail(DG_E_SHAPE, "dg_attn_core_bwd2: unsupported shape B=%d N=%d C=%d", B, N, C);
@@ -481,14 +500,25 @@ extern "C" int dg_attn_core_bwd2(const float* q, const float* k, const float* v,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     dim3 grid(B, g.slices), block(64 * kRW);
     ProfScope prof(DG_K_ATTN_BWD2, stream);
-#define LAUNCH(LQS, JPL)                                                                                          \
-    if (g.lqs == LQS && g.jpl == JPL) {                                                                           \
+#define LAUNCH_T(T, LQS, JPL)                                                                                     \
+    {                                                                                                             \
         constexpr int lds = (4 * JPL + (kRW - 1) * 2 * JPL) * 64 * 16;                                            \
-        DG_OPT_IN_LDS((&attn_bwd2_kernel<LQS, JPL, kRW>), lds);                                                     \
-        hipLaunchKernelGGL((attn_bwd2_kernel<LQS, JPL, kRW>), grid, block, lds, stream, q, k, v, e, ws, wo, tq,   \
-                           tk, tv, te, gq, gk, gv, ge, gws, gwo, N, C, alpha);                                    \
+        DG_OPT_IN_LDS((&attn_bwd2_kernel<T, LQS, JPL, kRW>), lds);                                                 \
+        hipLaunchKernelGGL((attn_bwd2_kernel<T, LQS, JPL, kRW>), grid, block, lds, stream,                         \
+                           static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_),       \
+                           static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_),     \
+                           static_cast<const T*>(tq_), static_cast<const T*>(tk_), static_cast<const T*>(tv_),    \
+                           static_cast<const T*>(te_), static_cast<T*>(gq_), static_cast<T*>(gk_),                \
+                           static_cast<T*>(gv_), static_cast<T*>(ge_), static_cast<T*>(gws_), static_cast<T*>(gwo_), \
+                           N, C, alpha);                                                                          \
+    }
+#define LAUNCH(LQS, JPL)                                   \
+    if (g.lqs == LQS && g.jpl == JPL) {                    \
+        if (dtype == DG_DTYPE_BF16) LAUNCH_T(bf16_t, LQS, JPL) \
+        else LAUNCH_T(float, LQS, JPL)                     \
     }
     DG_FOR_GEOMETRY(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_T
     return check_launch("dg_attn_core_bwd2");
 }

@@ -7,7 +7,7 @@
 // butterflies over the group's lanes.  The column sums for dgamma / dbeta are
 // reduced in a fixed order (per-block partials in the workspace, then one
 // finishing kernel), so results are bit-reproducible.
-#include "common.h"
+#include "bf16.h"
 
 namespace dg {
 namespace {
@@ -42,10 +42,10 @@ __device__ __forceinline__ RowMap map_row(int64_t pass, int64_t R) {
 }
 
 // ------------------------------------------------------------------ forward --
-template <int G, int QPL>
-__global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+template <typename T, int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ r,
                                                       const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int64_t R,
                                                       int C, float eps) {
     constexpr int RPB = kBlock / G;
@@ -91,13 +91,13 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict_
 // ----------------------------------------------------------------- backward --
 // dz = rstd (u - mean(u) - xhat mean(u xhat)), u = gamma dy
 // dgamma = sum_rows dy xhat, dbeta = sum_rows dy  (block partials -> part[])
-template <int G, int QPL>
-__global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+template <typename T, int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const T* __restrict__ a, const T* __restrict__ r,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ dy, float* __restrict__ dz,
+                                                      const T* __restrict__ dy, T* __restrict__ dz,
                                                       float* __restrict__ part, int64_t R, int C,
-                                                      const float* __restrict__ dz_add) {
+                                                      const T* __restrict__ dz_add) {
     constexpr int RPB = kBlock / G;
     __shared__ float4 red[2][QPL][kBlock];
     const int64_t passes = (R + RPB - 1) / RPB;
@@ -193,13 +193,13 @@ __global__ __launch_bounds__(1024) void ln_finish_kernel(const float* __restrict
 //   gdy = gamma xdot ; ggamma = sum_rows dy xdot
 //   gz = -rstd (xhat mean(xdot u) + xdot mean(u xhat) + w mean(tz xhat)),  u = gamma dy,
 //   w = rstd (u - mean(u) - xhat mean(u xhat))
-template <int G, int QPL>
-__global__ __launch_bounds__(kBlock) void ln_bwd2_kernel(const float* __restrict__ a, const float* __restrict__ r,
+template <typename T, int G, int QPL>
+__global__ __launch_bounds__(kBlock) void ln_bwd2_kernel(const T* __restrict__ a, const T* __restrict__ r,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ dy,
-                                                       const float* __restrict__ tz, float* __restrict__ gz,
-                                                       float* __restrict__ gdy, float* __restrict__ part, int64_t R,
+                                                       const float* __restrict__ rstd, const T* __restrict__ dy,
+                                                       const T* __restrict__ tz, T* __restrict__ gz,
+                                                       T* __restrict__ gdy, float* __restrict__ part, int64_t R,
                                                        int C) {
     constexpr int RPB = kBlock / G;
     __shared__ float4 red[QPL][kBlock];
@@ -310,41 +310,50 @@ extern "C" size_t dg_ln_workspace_bytes(int64_t R, int C) {
     return static_cast<size_t>(ln_grid(R, g.G)) * 2 * C * sizeof(float);
 }
 
-extern "C" int dg_ln_residual_fwd(const float* a, const float* r, const float* gamma, const float* beta, float* y,
-                                  float* mean, float* rstd, int64_t R, int C, float eps, dg_stream_t stream_) {
+extern "C" int dg_ln_residual_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int64_t R, int C, float eps, int dtype, dg_stream_t stream_) {
     if (!a || !gamma || !beta || !y || !mean || !rstd) return fail(DG_E_ARG, "dg_ln_residual_fwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_ln_residual_fwd: unknown dtype %d", dtype);
     LnGeom g;
     if (R < 0 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_fwd: unsupported C=%d (C%%4==0, C<=1024)", C);
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int grid = ln_grid(R, g.G);
     ProfScope prof(DG_K_LN_FWD, stream);
-#define LAUNCH(GG, QQ)            \
-    if (g.G == GG && g.QPL == QQ) \
-        hipLaunchKernelGGL((ln_fwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, beta, y, mean, rstd, R, C, eps);
+#define LAUNCH_T(T, GG, QQ)                                                                                      \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
+                       static_cast<const T*>(r), gamma, beta, static_cast<T*>(y), mean, rstd, R, C, eps);
+#define LAUNCH(GG, QQ)                                          \
+    if (g.G == GG && g.QPL == QQ) {                             \
+        if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, GG, QQ) } \
+        else { LAUNCH_T(float, GG, QQ) }                        \
+    }
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_T
     return check_launch("dg_ln_residual_fwd");
 }
 
-extern "C" int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma, const float* mean,
-                                      const float* rstd, const float* dy, const float* dz_add, float* dz,
+extern "C" int dg_ln_residual_bwd_add(const void* a, const void* r, const float* gamma, const float* mean,
+                                      const float* rstd, const void* dy, const void* dz_add, void* dz,
                                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int64_t R,
-                                      int C, dg_stream_t stream_);
+                                      int C, int dtype, dg_stream_t stream_);
 
-extern "C" int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma, const float* mean,
-                                  const float* rstd, const float* dy, float* dz, float* dgamma, float* dbeta,
-                                  void* workspace, size_t workspace_bytes, int64_t R, int C, dg_stream_t stream_) {
+extern "C" int dg_ln_residual_bwd(const void* a, const void* r, const float* gamma, const float* mean,
+                                  const float* rstd, const void* dy, void* dz, float* dgamma, float* dbeta,
+                                  void* workspace, size_t workspace_bytes, int64_t R, int C, int dtype,
+                                  dg_stream_t stream_) {
     return dg_ln_residual_bwd_add(a, r, gamma, mean, rstd, dy, nullptr, dz, dgamma, dbeta, workspace, workspace_bytes,
-                                  R, C, stream_);
+                                  R, C, dtype, stream_);
 }
 
-extern "C" int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma, const float* mean,
-                                      const float* rstd, const float* dy, const float* dz_add, float* dz,
+extern "C" int dg_ln_residual_bwd_add(const void* a, const void* r, const float* gamma, const float* mean,
+                                      const float* rstd, const void* dy, const void* dz_add, void* dz,
                                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int64_t R,
-                                      int C, dg_stream_t stream_) {
+                                      int C, int dtype, dg_stream_t stream_) {
     if (!a || !gamma || !mean || !rstd || !dy || !dz || !workspace)
         return fail(DG_E_ARG, "dg_ln_residual_bwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_ln_residual_bwd: unknown dtype %d", dtype);
     LnGeom g;
     if (R < 1 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_bwd: unsupported R=%lld C=%d", (long long)R, C);
     if (workspace_bytes < dg_ln_workspace_bytes(R, C)) return fail(DG_E_WORKSPACE, "dg_ln_residual_bwd: workspace too small");
@@ -352,22 +361,30 @@ extern "C" int dg_ln_residual_bwd_add(const float* a, const float* r, const floa
     const int grid = ln_grid(R, g.G);
     float* part = static_cast<float*>(workspace);
     ProfScope prof(DG_K_LN_BWD, stream);
-#define LAUNCH(GG, QQ)            \
-    if (g.G == GG && g.QPL == QQ) \
-        hipLaunchKernelGGL((ln_bwd_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, dz, part, R, C, dz_add);
+#define LAUNCH_T(T, GG, QQ)                                                                                      \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
+                       static_cast<const T*>(r), gamma, mean, rstd, static_cast<const T*>(dy), static_cast<T*>(dz), \
+                       part, R, C, static_cast<const T*>(dz_add));
+#define LAUNCH(GG, QQ)                                          \
+    if (g.G == GG && g.QPL == QQ) {                             \
+        if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, GG, QQ) } \
+        else { LAUNCH_T(float, GG, QQ) }                        \
+    }
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_T
     if (dgamma || dbeta)
         hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, stream, part, grid, 2, C, dgamma, dbeta);
     return check_launch("dg_ln_residual_bwd");
 }
 
-extern "C" int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma, const float* mean,
-                                   const float* rstd, const float* dy, const float* tz, float* gz, float* gdy,
+extern "C" int dg_ln_residual_bwd2(const void* a, const void* r, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dy, const void* tz, void* gz, void* gdy,
                                    float* ggamma, void* workspace, size_t workspace_bytes, int64_t R, int C,
-                                   dg_stream_t stream_) {
+                                   int dtype, dg_stream_t stream_) {
     if (!a || !gamma || !mean || !rstd || !dy || !tz || !gz || !gdy || !workspace)
         return fail(DG_E_ARG, "dg_ln_residual_bwd2: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_ln_residual_bwd2: unknown dtype %d", dtype);
     LnGeom g;
     if (R < 1 || !ln_geometry(C, &g)) return fail(DG_E_SHAPE, "dg_ln_residual_bwd2: unsupported R=%lld C=%d", (long long)R, C);
     if (workspace_bytes < dg_ln_workspace_bytes(R, C)) return fail(DG_E_WORKSPACE, "dg_ln_residual_bwd2: workspace too small");
@@ -375,11 +392,18 @@ extern "C" int dg_ln_residual_bwd2(const float* a, const float* r, const float* 
     const int grid = ln_grid(R, g.G);
     float* part = static_cast<float*>(workspace);
     ProfScope prof(DG_K_LN_BWD2, stream);
-#define LAUNCH(GG, QQ)            \
-    if (g.G == GG && g.QPL == QQ) \
-        hipLaunchKernelGGL((ln_bwd2_kernel<GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, a, r, gamma, mean, rstd, dy, tz, gz, gdy, part, R, C);
+#define LAUNCH_T(T, GG, QQ)                                                                                       \
+    hipLaunchKernelGGL((ln_bwd2_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
+                       static_cast<const T*>(r), gamma, mean, rstd, static_cast<const T*>(dy),                    \
+                       static_cast<const T*>(tz), static_cast<T*>(gz), static_cast<T*>(gdy), part, R, C);
+#define LAUNCH(GG, QQ)                                          \
+    if (g.G == GG && g.QPL == QQ) {                             \
+        if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, GG, QQ) } \
+        else { LAUNCH_T(float, GG, QQ) }                        \
+    }
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_T
     if (ggamma)
         hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, 1), dim3(1024), 0, stream, part, grid, 1, C, ggamma,
                            static_cast<float*>(nullptr));
