@@ -23,30 +23,36 @@ _P = c_void_p
 SIGNATURES = {
     "dg_version": (c_int, []),
     "dg_last_error_string": (c_char_p, []),
-    "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, _P]),
-    "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, _P]),
-    "dg_attn_core_bwd2": (c_int, [_P] * 16 + [c_int, c_int, c_int, c_float, _P]),
-    "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P]),
+    "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, c_int, _P]),
+    "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_int, _P]),
+    "dg_attn_core_bwd2": (c_int, [_P] * 16 + [c_int, c_int, c_int, c_float, c_int, _P]),
+    "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_int, _P]),
     "dg_ln_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, _P]),
-    "dg_ln_residual_bwd_add": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
-    "dg_ln_residual_bwd2": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, _P]),
+    "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_ln_residual_bwd_add": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_ln_residual_bwd2": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
     "dg_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "dg_linear_wgrad": (c_int, [_P] * 5 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
-    "dg_row_gemm_packed_floats": (c_size_t, [c_int, c_int]),
-    "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "dg_row_gemm_mask_words": (c_size_t, [c_int64, c_int, c_int]),
-    "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P]),
+    "dg_linear_wgrad": (c_int, [_P] * 5 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_row_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dg_row_gemm_mask_words": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P]),
     "dg_edge_ffn_ln_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, _P]),
-    "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, c_int, _P]),
+    "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_ffn_bf16_packed_bytes": (c_size_t, []),
+    "dg_ffn_bf16_pack": (c_int, [_P, _P, _P, _P]),
+    "dg_ffn_bf16_mask_words": (c_size_t, [c_int64]),
+    "dg_ffn_bf16_workspace_bytes": (c_size_t, [c_int64]),
+    "dg_ffn_ln_fwd_bf16": (c_int, [_P] * 11 + [c_int64, c_float, _P]),
+    "dg_ffn_ln_bwd_bf16": (c_int, [_P] * 18 + [_P, c_size_t, c_int64, _P]),
     "dg_embed_sym_packed_floats": (c_size_t, []),
     "dg_embed_sym_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dg_embed_sym_dgrad_packed_floats": (c_size_t, []),
     "dg_embed_sym_pack_dgrad": (c_int, [_P, _P, _P]),
     "dg_embed_sym_pack": (c_int, [_P, _P, _P]),
-    "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
-    "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 6 + [_P]),
+    "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 7 + [_P]),
+    "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 7 + [_P]),
     "dg_densify": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dg_adamw_flat": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "dg_adamw_flat_devstep": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P]),
@@ -56,7 +62,7 @@ SIGNATURES = {
     "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8}
+KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10}
 
 _lock = threading.Lock()
 _lib = None
@@ -92,18 +98,36 @@ def check(status: int, what: str) -> None:
         raise RuntimeError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
 
 
+DTYPES = {torch.float32: 0, torch.bfloat16: 1}     # DG_DTYPE_F32 / DG_DTYPE_BF16 of include/druggen_hip.h
+
+
+def dt(t) -> int:
+    """ABI dtype code of an activation tensor."""
+    try:
+        return DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"druggen_amd kernels store activations as float32 or bfloat16; got {t.dtype}") from None
+
+
 def ptr(t):
-    """Device pointer of a contiguous float32 GPU tensor (None -> NULL)."""
+    """Device pointer of a contiguous float32 / bfloat16 GPU tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("druggen_amd kernels need GPU tensors (no CPU fallback); got device "
                            f"{t.device}")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"druggen_amd kernels are float32; got {t.dtype}")
+    if t.dtype not in DTYPES:
+        raise RuntimeError(f"druggen_amd kernels are float32 / bfloat16; got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError("druggen_amd kernels need contiguous tensors")
     return t.data_ptr()
+
+
+def fptr(t):
+    """Like ptr(), for arguments the ABI declares `float*` (parameters, statistics, weight gradients)."""
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError(f"expected a float32 tensor, got {t.dtype}")
+    return ptr(t)
 
 
 def stream_of(t) -> int:

@@ -23,26 +23,26 @@ extern "C" size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H) {
     return ln > m ? ln : m;
 }
 
-extern "C" int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const float* b1, const float* w2_packed,
-                                  const float* b2, const float* gamma, const float* beta, float* y, float* h,
-                                  unsigned* relu_bits, float* pre_ln, float* mean, float* rstd, int64_t R, int C,
-                                  int H, float eps, dg_stream_t stream) {
+extern "C" int dg_edge_ffn_ln_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed,
+                                  const float* b2, const float* gamma, const float* beta, void* y, void* h,
+                                  unsigned* relu_bits, void* pre_ln, float* mean, float* rstd, int64_t R, int C,
+                                  int H, float eps, int dtype, dg_stream_t stream) {
     if (!x || !w1_packed || !b1 || !w2_packed || !b2 || !gamma || !beta || !y || !h || !mean || !rstd)
         return fail(DG_E_ARG, "dg_edge_ffn_ln_fwd: null pointer");
     if (C != 128 || H != 384) return fail(DG_E_SHAPE, "dg_edge_ffn_ln_fwd: needs dim 128, hidden 384 (got %d, %d)", C, H);
     int st = dg_row_gemm(x, w1_packed, h, R, C, H, b1, 1, relu_bits, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         nullptr, nullptr, 0.f, stream);
+                         nullptr, nullptr, 0.f, dtype, stream);
     if (st) return st;
     return dg_row_gemm(h, w2_packed, y, R, H, C, b2, 0, nullptr, nullptr, x, gamma, beta, mean, rstd, pre_ln, eps,
-                       stream);
+                       dtype, stream);
 }
 
-extern "C" int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits, const float* pre_ln,
+extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* relu_bits, const void* pre_ln,
                                   const float* mean, const float* rstd, const float* gamma,
-                                  const float* w1_dgrad_packed, const float* w2_dgrad_packed, const float* dy,
-                                  const float* dz_add, float* dz, float* dh, float* dx, float* dgamma, float* dbeta, float* dw1,
+                                  const void* w1_dgrad_packed, const void* w2_dgrad_packed, const void* dy,
+                                  const void* dz_add, void* dz, void* dh, void* dx, float* dgamma, float* dbeta, float* dw1,
                                   float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
-                                  int64_t R, int C, int H, dg_stream_t stream) {
+                                  int64_t R, int C, int H, int dtype, dg_stream_t stream) {
     if (!x || !h || !relu_bits || !pre_ln || !mean || !rstd || !gamma || !w1_dgrad_packed || !w2_dgrad_packed ||
         !dy || !dz || !dh || !workspace)
         return fail(DG_E_ARG, "dg_edge_ffn_ln_bwd: null pointer");
@@ -50,23 +50,23 @@ extern "C" int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned
     if (workspace_bytes < dg_edge_ffn_ln_workspace_bytes(R, C, H))
         return fail(DG_E_WORKSPACE, "dg_edge_ffn_ln_bwd: workspace too small");
     int st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
-                                    workspace_bytes, R, C, stream);
+                                    workspace_bytes, R, C, dtype, stream);
     if (st) return st;
     // dh = (dz @ W2) masked by the forward's ReLU bits
     st = dg_row_gemm(dz, w2_dgrad_packed, dh, R, C, H, nullptr, 0, nullptr, relu_bits, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, 0.f, stream);
+                     nullptr, nullptr, nullptr, 0.f, dtype, stream);
     if (st) return st;
     if (dx) {   // dx = dz + dh @ W1 (residual path folded into the epilogue)
         st = dg_row_gemm(dh, w1_dgrad_packed, dx, R, H, C, nullptr, 0, nullptr, nullptr, dz, nullptr, nullptr,
-                         nullptr, nullptr, nullptr, 0.f, stream);
+                         nullptr, nullptr, nullptr, 0.f, dtype, stream);
         if (st) return st;
     }
     if (dw2) {
-        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, workspace_bytes, R, C, H, stream);
+        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, workspace_bytes, R, C, H, dtype, stream);
         if (st) return st;
     }
     if (dw1) {
-        st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, workspace, workspace_bytes, R, H, C, stream);
+        st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, workspace, workspace_bytes, R, H, C, dtype, stream);
         if (st) return st;
     }
     return 0;

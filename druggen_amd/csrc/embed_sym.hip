@@ -12,7 +12,7 @@
 // inputs) is VALU work, layer 2 (64 -> C=128) runs on v_mfma_f32_32x32x2_f32 with the packed weight
 // fragments resident in VGPRs; the hidden tile lives in LDS (XOR-swizzled, conflict-free b128
 // fragment reads).  Nothing but the inputs is saved: the backward recomputes both layers.
-#include "common.h"
+#include "bf16.h"
 
 namespace dg {
 namespace {
@@ -140,11 +140,11 @@ __device__ __forceinline__ void layer2_mfma(const float* h1, const float4 (&bf)[
     }
 }
 
-template <int EP>
+template <typename T, int EP>
 __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w1,
                                                           const float* __restrict__ b1,
                                                           const float* __restrict__ w2p,
-                                                          const float* __restrict__ b2, float* __restrict__ out,
+                                                          const float* __restrict__ b2, T* __restrict__ out,
                                                           int B, int N, int E, int act, int tiles_per_mol) {
     __shared__ int ij[kPairs][2];
     __shared__ float at[64][kMaxE];
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
             if (i < 0) continue;
             const float s = 0.5f * (act_fwd(acc0[reg] + bias2, act) + act_fwd(acc1[reg] + bias2, act));
             const int64_t base = static_cast<int64_t>(t.b) * N;
-            out[((base + i) * N + j) * kC + n] = s;
-            out[((base + j) * N + i) * kC + n] = s;
+            st1(out + ((base + i) * N + j) * kC + n, s);
+            st1(out + ((base + j) * N + i) * kC + n, s);
         }
         __syncthreads();   // LDS tiles are reused by the next iteration
     }
@@ -190,11 +190,11 @@ struct BwdPart {
     static constexpr int kW2 = 0, kB2 = kC * kHid, kW1 = kB2 + kC, kB1 = kW1 + kHid * kMaxE, kTotal = kB1 + kHid;
 };
 
-template <int EP>
+template <typename T, int EP>
 __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
-    const float* __restrict__ g, float* __restrict__ da, float* __restrict__ part, int B, int N, int E, int act,
+    const T* __restrict__ g, float* __restrict__ da, float* __restrict__ part, int B, int N, int E, int act,
     int tiles_per_mol) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* h1 = reinterpret_cast<float*>(smem_raw);                 // [64][64] swizzled
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
             float p0 = 0.f, p1 = 0.f;
             if (i >= 0) {
                 const int64_t base = static_cast<int64_t>(t.b) * N;
-                float gs = 0.5f * (g[((base + i) * N + j) * kC + n] + g[((base + j) * N + i) * kC + n]);
+                float gs = 0.5f * (ld1(g + ((base + i) * N + j) * kC + n) + ld1(g + ((base + j) * N + i) * kC + n));
                 if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
                 p0 = gs * act_grad_from_output(act_fwd(acc0[reg] + bias2, act), act);
                 p1 = gs * act_grad_from_output(act_fwd(acc1[reg] + bias2, act), act);
@@ -414,9 +414,10 @@ extern "C" int dg_embed_sym_pack_dgrad(const float* w2, float* packed, dg_stream
 }
 
 extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
-                                const float* b2, float* out, int B, int N, int E, int H, int C, int act,
+                                const float* b2, void* out, int B, int N, int E, int H, int C, int act, int dtype,
                                 dg_stream_t stream_) {
     if (!a || !w1 || !b1 || !w2_packed || !b2 || !out) return fail(DG_E_ARG, "dg_embed_sym_fwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_embed_sym_fwd: unknown dtype %d", dtype);
     if (B < 0 || !embed_shape_ok(N, E, H, C, act))
         return fail(DG_E_SHAPE, "dg_embed_sym_fwd: unsupported N=%d E=%d H=%d C=%d act=%d (need E<=16, H=64, C=128)", N, E,
                     H, C, act);
@@ -424,21 +425,25 @@ extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     ProfScope prof(DG_K_EMBED_SYM, stream);
-    if (E <= 8)
-        hipLaunchKernelGGL(embed_sym_fwd_kernel<8>, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1,
-                           w2_packed, b2, out, B, N, E, act, tpm);
-    else
-        hipLaunchKernelGGL(embed_sym_fwd_kernel<16>, dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1,
-                           w2_packed, b2, out, B, N, E, act, tpm);
+#define FWD(T, EP_)                                                                                               \
+    hipLaunchKernelGGL((embed_sym_fwd_kernel<T, EP_>), dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1, \
+                       w2_packed, b2, static_cast<T*>(out), B, N, E, act, tpm);
+    if (dtype == DG_DTYPE_BF16) {
+        if (E <= 8) { FWD(bf16_t, 8) } else { FWD(bf16_t, 16) }
+    } else {
+        if (E <= 8) { FWD(float, 8) } else { FWD(float, 16) }
+    }
+#undef FWD
     return check_launch("dg_embed_sym_fwd");
 }
 
 extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
-                                const float* w2_dgrad_packed, const float* b2, const float* g, float* da, float* dw1,
+                                const float* w2_dgrad_packed, const float* b2, const void* g, float* da, float* dw1,
                                 float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int B,
-                                int N, int E, int H, int C, int act, dg_stream_t stream_) {
+                                int N, int E, int H, int C, int act, int dtype, dg_stream_t stream_) {
     if (!a || !w1 || !b1 || !w2_packed || !w2_dgrad_packed || !b2 || !g || !dw1 || !db1 || !dw2 || !db2 || !workspace)
         return fail(DG_E_ARG, "dg_embed_sym_bwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_embed_sym_bwd: unknown dtype %d", dtype);
     if (B < 1 || !embed_shape_ok(N, E, H, C, act))
         return fail(DG_E_SHAPE, "dg_embed_sym_bwd: unsupported B=%d N=%d E=%d H=%d C=%d act=%d", B, N, E, H, C, act);
     if (workspace_bytes < dg_embed_sym_workspace_bytes(B, N))
@@ -449,15 +454,19 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
-    DG_OPT_IN_LDS((&embed_sym_bwd_kernel<8>), lds_bytes);
-    DG_OPT_IN_LDS((&embed_sym_bwd_kernel<16>), lds_bytes);
     ProfScope prof(DG_K_EMBED_SYM, stream);
-    if (E <= 8)
-        hipLaunchKernelGGL(embed_sym_bwd_kernel<8>, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
-                           w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
-    else
-        hipLaunchKernelGGL(embed_sym_bwd_kernel<16>, dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1, w2_packed,
-                           w2_dgrad_packed, b2, g, da, part, B, N, E, act, tpm);
+#define BWD(T, EP_)                                                                                               \
+    {                                                                                                             \
+        DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_>), lds_bytes);                                                \
+        hipLaunchKernelGGL((embed_sym_bwd_kernel<T, EP_>), dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1,    \
+                           w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), da, part, B, N, E, act, tpm); \
+    }
+    if (dtype == DG_DTYPE_BF16) {
+        if (E <= 8) BWD(bf16_t, 8) else BWD(bf16_t, 16)
+    } else {
+        if (E <= 8) BWD(float, 8) else BWD(float, 16)
+    }
+#undef BWD
     hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
                        BwdPart::kTotal, red);
     hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,

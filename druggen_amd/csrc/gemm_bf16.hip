@@ -1,0 +1,290 @@
+// bf16 "row GEMM" for the per-edge / per-node dense layers (reference src/model/layers.py: MHA
+// projections :111-116,127,135 and MLP.fc1/fc2 :50-53) in the bf16 configuration (BASELINE
+// configs[2]): activations bf16 in HBM, ONE v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate,
+// fp32 bias / ReLU / residual / LayerNorm arithmetic, bf16 result.
+//
+//     Y[R,N] = epilogue( A[R,K] . W'^T ),      (K, N) in {(128,128), (128,384), (384,128)}
+//     epilogue(v) = LN?( relu?(v + bias) * mask? + residual? )
+//
+// MI355X mapping (differences to the fp32 / bf16x6 kernels of row_gemm.hip)
+//   * the A tile needs no split: 64 rows x K bf16 go HBM -> LDS by LDS-DMA, double buffered, the
+//     swizzle applied on the source address (gemm_bf16.h);
+//   * 8 waves; wave (c = w & 3, g = w >> 2) owns tile rows [32 g, 32 g + 32) and output channels
+//     32 (c + 4 nc) .. + 31 of every 128-channel chunk nc.  The product is "swapped" (weights are the
+//     MFMA A operand, activations the B operand), so a lane ends up with 4 consecutive channels of ONE
+//     row: accumulators leave through an fp32 exchange tile as 16-byte slots;
+//   * weight fragments (P32 order) stay in VGPRs for the whole persistent kernel: 32 KC NC registers;
+//   * every result row is finalised by one half-wave from the exchange tile: bias, ReLU (+ 1 bit per
+//     element out / mask in), residual (8-byte bf16 loads issued before the MFMA phase), LayerNorm with
+//     DPP row sums, then 8-byte-per-lane stores = whole 256-byte rows.
+// Algorithmic bytes per launch: 2 R (K + N (1 + [residual] + [pre])).
+#include "gemm_bf16.h"
+
+namespace dg {
+
+// fp32 implementations (row_gemm.hip)
+size_t row_gemm_f32_packed_floats(int n_out, int k_contract);
+int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
+size_t row_gemm_f32_mask_words(int64_t R, int K, int N);
+int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
+                 unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
+                 const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream);
+
+namespace {
+
+// ---------------------------------------------------------------- weight packing --
+// mb_size 32: P32, 16: P16 (see gemm_bf16.h).  One thread per (m-block, k-step, lane).
+__global__ void pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ p, int rows, int cols, int mode,
+                                 int mb_size) {
+    const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+    const int kstep = 512 / mb_size;                 // contraction elements per MFMA
+    const int MB = M / mb_size, KS = K / kstep;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= MB * KS * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % KS, mb = (idx >> 6) / KS;
+    const int m = mb * mb_size + (lane & (mb_size - 1));
+    const int k0 = ks * kstep + 8 * (mb_size == 32 ? lane >> 5 : lane >> 4);
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const float v = mode == 0 ? w[static_cast<size_t>(m) * cols + k] : w[static_cast<size_t>(k) * cols + m];
+        out[j] = static_cast<__bf16>(v);
+    }
+    p[idx] = out;
+}
+
+struct EpiB {
+    const float* bias;          // [N] or null
+    const unsigned* mask_bits;  // ReLU mask written by a relu launch of the same (K, N) geometry
+    unsigned* relu_bits;        // optional output of the ReLU epilogue
+    const bf16_t* residual;     // [R,N] or null
+    const float* gamma;         // LayerNorm (N == 128) or null
+    const float* beta;
+    float* mean;
+    float* rstd;
+    bf16_t* pre;                // optional [R,N]: pre-LayerNorm sum
+    float eps;
+    int relu;
+};
+
+template <int KC, int NC>
+__global__ __launch_bounds__(512, (KC * NC == 1 ? 4 : 2)) void row_gemm_bf16_kernel(const bf16_t* __restrict__ a,
+                                                                                   const bf16x8* __restrict__ packed,
+                                                                                   bf16_t* __restrict__ y, int64_t R,
+                                                                                   EpiB ep) {
+    constexpr int K = 128 * KC, N = 128 * NC, KS = KC * 8;
+    constexpr int ABYTES = kRowsPerTile * K * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* abuf = smem;                       // [2][64][K] bf16
+    char* xch = smem + 2 * ABYTES;           // [64][N] fp32 exchange tile
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = w & 3, g = w >> 2;
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
+
+    bf16x8 wf[NC][KS];
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[nc][ks] = packed[(static_cast<size_t>(c + 4 * nc) * KS + ks) * 64 + lane];
+    float4 bias4[NC], gam = f4(0.f), bet = f4(0.f);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) bias4[nc] = ep.bias ? ld4(ep.bias + 128 * nc + 4 * col) : f4(0.f);
+    if (ep.gamma) {
+        gam = ld4(ep.gamma + 4 * col);
+        bet = ld4(ep.beta + 4 * col);
+    }
+    wait_all_vmem_visible();
+
+    int64_t tix = blockIdx.x;
+    if (tix < tiles) dma_tile_bf16<K, 8>(a, tix * kRowsPerTile, R, abuf, w, lane);
+    int buf = 0;
+    for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
+        const int64_t r0 = tix * kRowsPerTile;
+        wait_all_vmem();
+        __syncthreads();      // tile `tix` landed for every wave; exchange tile and the other buffer are free
+        // rows finalised by this wave: 8 w + 2 it + half.  Residual rows are requested before the MFMA
+        // phase; the bit masks too.
+        u32x2_t res[4][NC];
+        if (ep.residual) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int64_t row = r0 + 8 * w + 2 * it + half;
+                if (row > R - 1) row = R - 1;
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+                    res[it][nc] = *reinterpret_cast<const u32x2_t*>(ep.residual + row * N + 128 * nc + 4 * col);
+            }
+        }
+        constexpr int BW = (16 * NC + 31) / 32;       // bit-mask words per lane and tile
+        unsigned mbits[BW];
+        const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * BW;
+        if (ep.mask_bits) {
+#pragma unroll
+            for (int i = 0; i < BW; ++i) mbits[i] = ep.mask_bits[bix + i];
+        }
+        if (tix + gridDim.x < tiles)
+            dma_tile_bf16<K, 8>(a, (tix + gridDim.x) * kRowsPerTile, R, abuf + (buf ^ 1) * ABYTES, w, lane);
+
+        // ---- MFMA phase: acc[nc][m = channel][n = row] += W'[m][k] x[n][k]
+        f32x16 acc[NC];
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nc][i] = 0.f;
+        const char* at = abuf + buf * ABYTES;
+        const int arow = 32 * g + col;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(at + tile_off(arow, 16 * ks + 8 * half, K));
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc)
+                acc[nc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nc][ks], xf, acc[nc], 0, 0, 0);
+        }
+        // accumulators -> exchange tile: lane holds channels 32 (c + 4 nc) + 8 q + 4 half + {0..3} of row arow
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * (c + 4 * nc) + 8 * q + 4 * half;
+                *reinterpret_cast<float4*>(xch + xch_off(arow, ch, N)) =
+                    make_float4(acc[nc][4 * q], acc[nc][4 * q + 1], acc[nc][4 * q + 2], acc[nc][4 * q + 3]);
+            }
+        __syncthreads();
+        // ---- row phase
+        unsigned newbits[BW];
+#pragma unroll
+        for (int i = 0; i < BW; ++i) newbits[i] = 0u;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = 8 * w + 2 * it + half;
+            const int64_t row = r0 + rr;
+            const bool ok = row < R;
+            float4 v[NC];
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) {
+                v[nc] = *reinterpret_cast<const float4*>(xch + xch_off(rr, 128 * nc + 4 * col, N)) + bias4[nc];
+                const int b0 = (it * NC + nc) * 4;
+                if (ep.relu) {
+                    newbits[b0 >> 5] |= ((v[nc].x > 0.f ? 1u : 0u) | (v[nc].y > 0.f ? 2u : 0u) | (v[nc].z > 0.f ? 4u : 0u) |
+                                         (v[nc].w > 0.f ? 8u : 0u))
+                                        << (b0 & 31);
+                    v[nc] = max4(v[nc], f4(0.f));
+                }
+                if (ep.mask_bits) {
+                    const unsigned mb = mbits[b0 >> 5] >> (b0 & 31);
+                    v[nc] = make_float4(mb & 1u ? v[nc].x : 0.f, mb & 2u ? v[nc].y : 0.f, mb & 4u ? v[nc].z : 0.f,
+                                        mb & 8u ? v[nc].w : 0.f);
+                }
+                if (ep.residual) v[nc] += unpack4_bf16(res[it][nc]);
+            }
+            if (NC == 1 && ep.gamma) {
+                if (ep.pre && ok) st4(ep.pre + row * N + 4 * col, v[0]);
+                const float mu = half_wave_sum((v[0].x + v[0].y) + (v[0].z + v[0].w)) * (1.0f / 128.0f);
+                const float4 d = v[0] - f4(mu);
+                const float var = half_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
+                const float rs = rsqrtf(var + ep.eps);
+                v[0] = fma4(rs * d, gam, bet);
+                if (ok && col == 0) {
+                    ep.mean[row] = mu;
+                    ep.rstd[row] = rs;
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc) st4(y + row * N + 128 * nc + 4 * col, v[nc]);
+            }
+        }
+        if (ep.relu_bits) {
+#pragma unroll
+            for (int i = 0; i < BW; ++i) ep.relu_bits[bix + i] = newbits[i];
+        }
+    }
+}
+
+bool bf16_shape_ok(int K, int N) { return (K == 128 && (N == 128 || N == 384)) || (K == 384 && N == 128); }
+
+}  // namespace
+
+size_t row_gemm_bf16_mask_words(int64_t R, int K, int N) {
+    if (!bf16_shape_ok(K, N) || R < 1) return 0;
+    const size_t tiles = static_cast<size_t>((R + kRowsPerTile - 1) / kRowsPerTile);
+    return tiles * 512 * ((16 * (N / 128) + 31) / 32);
+}
+
+int pack_bf16(const float* w, void* packed, int rows, int cols, int mode, int mb_size, hipStream_t stream) {
+    const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+    if (M % mb_size || K % (512 / mb_size)) return fail(DG_E_SHAPE, "bf16 pack: %d x %d is not a multiple of the MFMA tile", M, K);
+    const int total = (M / mb_size) * (K / (512 / mb_size)) * 64;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w,
+                       static_cast<bf16x8*>(packed), rows, cols, mode, mb_size);
+    return check_launch("bf16 pack");
+}
+
+int row_gemm_bf16(const bf16_t* a, const void* packed, bf16_t* y, int64_t R, int K, int N, const float* bias, int relu,
+                  unsigned* relu_bits_out, const unsigned* mask_bits, const bf16_t* residual, const float* gamma,
+                  const float* beta, float* mean, float* rstd, bf16_t* pre_ln, float eps, hipStream_t stream) {
+    if (!bf16_shape_ok(K, N))
+        return fail(DG_E_SHAPE, "dg_row_gemm(bf16): unsupported K=%d N=%d (supported: 128x128, 128x384, 384x128)", K, N);
+    if (gamma && (N != 128 || !beta || !mean || !rstd))
+        return fail(DG_E_ARG, "dg_row_gemm: LayerNorm epilogue needs N == 128, beta, mean and rstd");
+    if (R == 0) return 0;
+    EpiB ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
+    const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
+    const bf16x8* pk = static_cast<const bf16x8*>(packed);
+    ProfScope prof(DG_K_ROW_GEMM, stream);
+#define LAUNCH(KC_, NC_, PER_CU_)                                                                                  \
+    {                                                                                                              \
+        constexpr int lds = 2 * kRowsPerTile * 128 * KC_ * 2 + kRowsPerTile * 128 * NC_ * 4;                       \
+        DG_OPT_IN_LDS((&row_gemm_bf16_kernel<KC_, NC_>), lds);                                                     \
+        const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                          \
+        hipLaunchKernelGGL((row_gemm_bf16_kernel<KC_, NC_>), dim3(grid), dim3(512), lds, stream, a, pk, y, R, ep); \
+    }
+    if (K == 128 && N == 128) LAUNCH(1, 1, 2)
+    else if (K == 128) LAUNCH(1, 3, 1)
+    else LAUNCH(3, 1, 1)
+#undef LAUNCH
+    return check_launch("dg_row_gemm(bf16)");
+}
+
+}  // namespace dg
+
+using namespace dg;
+
+// ---- public entry points: dispatch on dtype -------------------------------------------------------
+extern "C" size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype) {
+    if (n_out < 1 || k_contract < 1) return 0;
+    if (dtype == DG_DTYPE_BF16) return static_cast<size_t>(n_out) * k_contract * 2;
+    return row_gemm_f32_packed_floats(n_out, k_contract) * sizeof(float);
+}
+
+extern "C" int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols, int mode, int dtype,
+                                dg_stream_t stream_) {
+    if (!w || !packed) return fail(DG_E_ARG, "dg_row_gemm_pack: null pointer");
+    if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
+    if (dtype == DG_DTYPE_BF16) return pack_bf16(w, packed, rows, cols, mode, 32, static_cast<hipStream_t>(stream_));
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack: unknown dtype %d", dtype);
+    return row_gemm_f32_pack(w, static_cast<float*>(packed), rows, cols, mode, stream_);
+}
+
+extern "C" size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype) {
+    return dtype == DG_DTYPE_BF16 ? row_gemm_bf16_mask_words(R, K, N) : row_gemm_f32_mask_words(R, K, N);
+}
+
+extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N, const float* bias,
+                           int relu, unsigned* relu_bits_out, const unsigned* mask_bits, const void* residual,
+                           const float* gamma, const float* beta, float* mean, float* rstd, void* pre_ln, float eps,
+                           int dtype, dg_stream_t stream_) {
+    if (!a || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm: null pointer");
+    if (R < 0) return fail(DG_E_SHAPE, "dg_row_gemm: negative row count");
+    if (dtype == DG_DTYPE_BF16)
+        return row_gemm_bf16(static_cast<const bf16_t*>(a), packed, static_cast<bf16_t*>(y), R, K, N, bias, relu,
+                             relu_bits_out, mask_bits, static_cast<const bf16_t*>(residual), gamma, beta, mean, rstd,
+                             static_cast<bf16_t*>(pre_ln), eps, static_cast<hipStream_t>(stream_));
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm: unknown dtype %d", dtype);
+    return row_gemm_f32(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y), R, K, N,
+                        bias, relu, relu_bits_out, mask_bits, static_cast<const float*>(residual), gamma, beta, mean, rstd,
+                        static_cast<float*>(pre_ln), eps, stream_);
+}

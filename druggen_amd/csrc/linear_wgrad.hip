@@ -14,9 +14,10 @@
 // contiguous chunk, so the LDS image is lane-linear), double buffered, and
 // feeds MFMA operands with conflict-free ds_read_b32 (lane&31 walks a row).
 // Split-K partials are reduced by a second kernel in a fixed order.
-#include "common.h"
+#include "bf16.h"
 
 #include <cstring>
+#include <type_traits>
 
 namespace dg {
 namespace {
@@ -61,18 +62,20 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m
 
 // X6: operands split into bf16 planes in registers, 6 MFMAs per 16-row step and tile pair instead of 8
 // fp32 MFMAs (6/16 of the matrix time per flop); same LDS traffic (one ds_read_b32 per operand row).
-template <int NT, int KT, int WN, int WK, int TR, bool MASK, bool X6 = false>
-__global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restrict__ dy,
-                                                           const float* __restrict__ dymask,
-                                                           const float* __restrict__ x,
+template <typename T, int NT, int KT, int WN, int WK, int TR, bool MASK, bool X6 = false>
+__global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict__ dy,
+                                                           const T* __restrict__ dymask,
+                                                           const T* __restrict__ x,
                                                            float* __restrict__ part_w, float* __restrict__ part_b,
                                                            int64_t R, int tiles_per_block) {
     constexpr int N = NT * 32, K = KT * 32, THREADS = WN * WK * 64;
     constexpr int TN = NT / WN, TK = KT / WK;   // tiles per wave
+    constexpr bool BF = std::is_same<T, bf16_t>::value;
+    constexpr int EPF = BF ? 2 : 1;             // elements per 4-byte word
     static_assert(NT % WN == 0 && KT % WK == 0, "wave grid must divide the tile grid");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* lds = reinterpret_cast<float*>(smem_raw);
-    // buffers: [2][TR*(N+K)] (dy tile, x tile) or [2][TR*(2N+K)] (dy, x, mask tiles)
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    // buffers: [2][TR*(N+K)] (dy tile, x tile) or [2][TR*(2N+K)] (dy, x, mask tiles), elements of T
     constexpr int BUF = TR * (N + K + (MASK ? N : 0));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,15 +99,19 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
     auto issue = [&](int64_t t, int buf) {
         const int64_t r0 = t * TR;
         const int valid = static_cast<int>((R - r0) < TR ? (R - r0) : TR);
-        float* ldy = lds + buf * BUF;
-        float* lx = ldy + TR * N;
+        T* ldy = lds + buf * BUF;
+        T* lx = ldy + TR * N;
         if (valid < TR) {   // zero the whole buffer first (block-uniform branch)
-            for (int c = threadIdx.x; c < BUF / 4; c += THREADS) st4(ldy + c * 4, f4(0.f));
+            float* zf = reinterpret_cast<float*>(ldy);
+            for (int c = threadIdx.x; c < BUF / EPF / 4; c += THREADS) st4(zf + c * 4, f4(0.f));
             __syncthreads();
         }
-        stage_tile<THREADS>(dy + r0 * N, ldy, N, TR, valid);
-        stage_tile<THREADS>(x + r0 * K, lx, K, TR, valid);
-        if (MASK) stage_tile<THREADS>(dymask + r0 * N, lx + TR * K, N, TR, valid);
+        // a TR-row tile of a row-major matrix is one contiguous chunk: staged as 4-byte words
+        stage_tile<THREADS>(reinterpret_cast<const float*>(dy + r0 * N), reinterpret_cast<float*>(ldy), N / EPF, TR, valid);
+        stage_tile<THREADS>(reinterpret_cast<const float*>(x + r0 * K), reinterpret_cast<float*>(lx), K / EPF, TR, valid);
+        if (MASK)
+            stage_tile<THREADS>(reinterpret_cast<const float*>(dymask + r0 * N), reinterpret_cast<float*>(lx + TR * K),
+                                N / EPF, TR, valid);
     };
 
     if (t_lo < t_hi) issue(t_lo, 0);
@@ -113,9 +120,52 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
         wait_all_vmem();
         __syncthreads();                       // tile t landed for every wave; tile t-1 fully consumed
         if (t + 1 < t_hi) issue(t + 1, buf ^ 1);
-        const float* ldy = lds + buf * BUF;
-        const float* lx = ldy + TR * N;
+        const T* ldy = lds + buf * BUF;
+        const T* lx = ldy + TR * N;
         const int half = lane >> 5, col = lane & 31;
+        if constexpr (BF) {
+            // bf16 operands: the fragment of lane (column, half) is the 8 consecutive ROWS 16 s + 8 half + j of
+            // its column -- eight 2-byte LDS reads (32 lanes cover 64 contiguous bytes: conflict free), one MFMA
+            // per tile pair and 16-row step
+            const unsigned short* uy = reinterpret_cast<const unsigned short*>(ldy);
+            const unsigned short* ux = reinterpret_cast<const unsigned short*>(lx);
+#pragma unroll
+            for (int s16 = 0; s16 < TR / 16; ++s16) {
+                bf16x8 af[TN], bfg[TK];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o0 = (16 * s16 + 8 * half + 2 * j) * N + (wn * TN + i) * 32 + col;
+                        unsigned lo = uy[o0], hi = uy[o0 + N];
+                        if (MASK) {
+                            const unsigned short m0 = ux[TR * K + o0], m1 = ux[TR * K + o0 + N];
+                            // keep where the saved activation is > 0 (positive, non-zero bf16)
+                            lo = (m0 != 0 && !(m0 & 0x8000u)) ? lo : 0u;
+                            hi = (m1 != 0 && !(m1 & 0x8000u)) ? hi : 0u;
+                        }
+                        pk[j] = lo | (hi << 16);
+                    }
+                    af[i] = __builtin_bit_cast(bf16x8, pk);
+                }
+#pragma unroll
+                for (int j2 = 0; j2 < TK; ++j2) {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o0 = (16 * s16 + 8 * half + 2 * j) * K + (wk * TK + j2) * 32 + col;
+                        pk[j] = static_cast<unsigned>(ux[o0]) | (static_cast<unsigned>(ux[o0 + K]) << 16);
+                    }
+                    bfg[j2] = __builtin_bit_cast(bf16x8, pk);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j2 = 0; j2 < TK; ++j2)
+                        acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j2], acc[i][j2], 0, 0, 0);
+            }
+        } else
         if constexpr (X6) {
 #pragma unroll
             for (int s16 = 0; s16 < TR / 16; ++s16) {
@@ -172,7 +222,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
 #pragma unroll 8
                 for (int r = 0; r < TR / H; ++r) {
                     const int o = (h * (TR / H) + r) * N + c;
-                    s += (MASK && !(lx[TR * K + o] > 0.f)) ? 0.f : ldy[o];
+                    s += (MASK && !(ld1(lx + TR * K + o) > 0.f)) ? 0.f : ld1(ldy + o);
                 }
                 bacc += s;
             }
@@ -193,7 +243,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const float* __restr
     if (part_b) {
         // combine the two row halves in a fixed order through LDS
         __syncthreads();
-        float* red = lds;
+        float* red = reinterpret_cast<float*>(smem_raw);
         if (threadIdx.x < N * H) red[threadIdx.x] = bacc;
         __syncthreads();
         if (threadIdx.x < N)
@@ -239,8 +289,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // dW[n][k] = sum_r dy[r][n] x[r][k] with N = 5 / 13: no MFMA tile to fill, the kernel is a coalesced
 // stream over x (512 B rows) with N float4 accumulators per lane; dy[r][.] is a broadcast load.
 // Thread = (row phase, k quad); row phases are combined through LDS in a fixed order.
-template <int NMAX>
-__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ part_w, float* __restrict__ part_b,
                                                          int64_t R, int N, int K, int64_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -261,10 +311,10 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
     if (rp < phases) {
         for (int64_t r = r_lo + rp; r < r_hi; r += phases) {
             const float4 xv = ld4(x + r * K + kq * 4);
-            const float* dr = dy + r * N;
+            const T* dr = dy + r * N;
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
-                const float d = n < N ? dr[n] : 0.f;
+                const float d = n < N ? ld1(dr + n) : 0.f;
                 acc[n] = fma4(f4(d), xv, acc[n]);
                 bsum[n] += d;
             }
@@ -359,6 +409,15 @@ int wgrad_blocks(int64_t R, const WgradPlan& p, int* tiles_per_block) {
 }  // namespace
 }  // namespace dg
 
+namespace dg {
+// out[i] = sum_s part[s][i] over float4 columns, fixed order (shared with ffn_bf16.hip)
+void launch_splitk_reduce(const float* part, int S, int64_t n4, float* out, hipStream_t stream) {
+    const int blocks = static_cast<int>((n4 + 15) / 16);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, S, n4, out, blocks,
+                       static_cast<const float*>(nullptr), static_cast<int64_t>(0), static_cast<float*>(nullptr));
+}
+}  // namespace dg
+
 using namespace dg;
 
 extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
@@ -370,11 +429,14 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
-extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db, void* workspace,
-                               size_t workspace_bytes, int64_t R, int N, int K, dg_stream_t stream_) {
-    if (!dy || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
+extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void* x_, float* dw, float* db,
+                               void* workspace, size_t workspace_bytes, int64_t R, int N, int K, int dtype,
+                               dg_stream_t stream_) {
+    if (!dy_ || !x_ || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_linear_wgrad: unknown dtype %d", dtype);
+    const bool bf = dtype == DG_DTYPE_BF16;
     if (R >= 1 && skinny_ok(N, K)) {
-        if (dy_mask) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask is not supported for N <= 16");
+        if (dy_mask_) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask is not supported for N <= 16");
         if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
             return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
         hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -386,12 +448,15 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
         float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
         const int KQ = K / 4, phases = 256 / KQ;
         ProfScope prof(DG_K_LINEAR_WGRAD, stream);
-        if (N <= 8)
-            hipLaunchKernelGGL((skinny_wgrad_kernel<8>), dim3(S), dim3(256), phases * 8 * KQ * 16, stream, dy, x, part_w,
-                               part_b, R, N, K, rpb);
-        else
-            hipLaunchKernelGGL((skinny_wgrad_kernel<16>), dim3(S), dim3(256), phases * 16 * KQ * 16, stream, dy, x,
-                               part_w, part_b, R, N, K, rpb);
+#define SKINNY(T, NM)                                                                                             \
+    hipLaunchKernelGGL((skinny_wgrad_kernel<T, NM>), dim3(S), dim3(256), phases * NM * KQ * 16, stream,           \
+                       static_cast<const T*>(dy_), static_cast<const T*>(x_), part_w, part_b, R, N, K, rpb);
+        if (N <= 8) {
+            if (bf) { SKINNY(bf16_t, 8) } else { SKINNY(float, 8) }
+        } else {
+            if (bf) { SKINNY(bf16_t, 16) } else { SKINNY(float, 16) }
+        }
+#undef SKINNY
         const int64_t nw = static_cast<int64_t>(N) * K;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + 255) / 256)), dim3(256), 0, stream,
                            part_w, S, nw, dw);
@@ -411,21 +476,23 @@ extern "C" int dg_linear_wgrad(const float* dy, const float* dy_mask, const floa
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(DG_K_LINEAR_WGRAD, stream);
     static const bool x6 = !(getenv("DG_WGRAD") && strcmp(getenv("DG_WGRAD"), "mfma32") == 0);   // bf16x6 split by default
-#define LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, X_)                                                                 \
+#define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \
     {                                                                                                            \
-        constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * 4;                                  \
-        DG_OPT_IN_LDS((&wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>), lds_bytes);                          \
-        hipLaunchKernelGGL((wgrad_kernel<NT_, KT_, WN_, WK_, TR_, M_, X_>), dim3(S), dim3(WN_* WK_ * 64),         \
-                           lds_bytes, stream, dy, dy_mask, x, part_w, part_b, R, tpb);                           \
+        constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * static_cast<int>(sizeof(T));        \
+        DG_OPT_IN_LDS((&wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_>), lds_bytes);                            \
+        hipLaunchKernelGGL((wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_>), dim3(S), dim3(WN_* WK_ * 64),      \
+                           lds_bytes, stream, static_cast<const T*>(dy_), static_cast<const T*>(dy_mask_),       \
+                           static_cast<const T*>(x_), part_w, part_b, R, tpb);                                   \
     }
-#define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                 \
-    {                                                                        \
-        if (x6 && (TR_) % 16 == 0) LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, true) \
-        else LAUNCH_X(NT_, KT_, WN_, WK_, TR_, M_, false)                     \
+#define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                            \
+    {                                                                                   \
+        if (bf) LAUNCH_X(bf16_t, NT_, KT_, WN_, WK_, TR_, M_, false)                     \
+        else if (x6 && (TR_) % 16 == 0) LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, true)    \
+        else LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, false)                         \
     }
 #define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                   \
     if (p.nt == NT_ && p.kt == KT_) {                                     \
-        if (dy_mask) LAUNCH_M(NT_, KT_, WN_, WK_, TR_, true)              \
+        if (dy_mask_) LAUNCH_M(NT_, KT_, WN_, WK_, TR_, true)             \
         else LAUNCH_M(NT_, KT_, WN_, WK_, TR_, false)                     \
     }
     if (big_tiles) {

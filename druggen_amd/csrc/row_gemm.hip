@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
 }  // namespace
 }  // namespace dg
 
-using namespace dg;
+namespace dg {
 
 // DG_ROW_GEMM=mfma32 selects the v_mfma_f32_32x32x2_f32 kernels (A/B comparisons); default: bf16x6.
 static bool use_x6() {
@@ -1028,14 +1028,14 @@ static bool use_x6() {
     return on;
 }
 
-extern "C" size_t dg_row_gemm_packed_floats(int n_out, int k_contract) {
+size_t row_gemm_f32_packed_floats(int n_out, int k_contract) {
     if (n_out < 1 || k_contract < 1) return 0;
     const size_t nt = (n_out + 31) / 32, kc = (k_contract + 127) / 128;
     if (use_x6()) return nt * kc * 8 * 3 * 64 * 4;   // [slab][k-step][plane][lane] x 8 bf16
     return nt * kc * 16 * 64 * 4;
 }
 
-extern "C" int dg_row_gemm_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream_) {
+int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream_) {
     if (!w || !packed) return fail(DG_E_ARG, "dg_row_gemm_pack: null pointer");
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
@@ -1053,14 +1053,14 @@ extern "C" int dg_row_gemm_pack(const float* w, float* packed, int rows, int col
     return check_launch("dg_row_gemm_pack");
 }
 
-extern "C" size_t dg_row_gemm_mask_words(int64_t R, int K, int N) {
+size_t row_gemm_f32_mask_words(int64_t R, int K, int N) {
     // geometry of the direct-epilogue kernels (see the launch table in dg_row_gemm)
     if (K == 128 && N == 384) return static_cast<size_t>((R + 31) / 32) * 12 * 64;
     if (K == 128 && N == 128) return static_cast<size_t>((R + 63) / 64) * 8 * 64;   // upper bound over variants
     return 0;
 }
 
-extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias,
+int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias,
                            int relu, unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual,
                            const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
                            float eps, dg_stream_t stream_) {
@@ -1142,3 +1142,5 @@ extern "C" int dg_row_gemm(const float* a, const float* packed, float* y, int64_
 #undef LAUNCHX
     return check_launch("dg_row_gemm");
 }
+
+}  // namespace dg

@@ -19,7 +19,8 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 __all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
-           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops"]
+           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops",
+           "set_activation_dtype", "activation_dtype", "activations"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -75,8 +76,8 @@ class _AttnCore(Function):
         o = torch.empty_like(q)
         with _dev(q):
             _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
-                                            _lib.ptr(o), B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_fwd")
-        _account("attn_fwd", 4 * B * ((2 if need_s else 1) * N * N * C + 4 * N * C))
+                                            _lib.ptr(o), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_fwd")
+        _account("attn_fwd", q.element_size() * B * ((2 if need_s else 1) * N * N * C + 4 * N * C))
         ctx.save_for_backward(q, k, v, e)
         ctx.alpha = alpha
         ctx.set_materialize_grads(False)
@@ -108,8 +109,8 @@ class _AttnCoreBwd(Function):
         with _dev(q):
             _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws),
                                             _lib.ptr(wo), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de),
-                                            B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd")
-        _account("attn_bwd", 4 * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
+                                            B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_bwd")
+        _account("attn_bwd", q.element_size() * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
         ctx.save_for_backward(q, k, v, e, ws, wo)
         ctx.alpha = alpha
         return dq, dk, dv, de
@@ -129,9 +130,9 @@ class _AttnCoreBwd(Function):
             _lib.check(lib.dg_attn_core_bwd2(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws),
                                              _lib.ptr(wo), _lib.ptr(tq), _lib.ptr(tk), _lib.ptr(tv), _lib.ptr(te),
                                              _lib.ptr(gq), _lib.ptr(gk), _lib.ptr(gv), _lib.ptr(ge), _lib.ptr(gws),
-                                             _lib.ptr(gwo), B, N, C, ctx.alpha, _lib.stream_of(q)),
+                                             _lib.ptr(gwo), B, N, C, ctx.alpha, _lib.dt(q), _lib.stream_of(q)),
                        "dg_attn_core_bwd2")
-        _account("attn_bwd2", 4 * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
+        _account("attn_bwd2", q.element_size() * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
         return gq, gk, gv, ge, gws, gwo, None
 
 
@@ -179,10 +180,10 @@ class _LNResidual(Function):
         mean = torch.empty(R, dtype=torch.float32, device=a.device)
         rstd = torch.empty(R, dtype=torch.float32, device=a.device)
         with _dev(a):
-            _lib.check(lib.dg_ln_residual_fwd(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(_c(beta)),
+            _lib.check(lib.dg_ln_residual_fwd(_lib.ptr(a), _lib.ptr(r), _lib.fptr(_c(gamma)), _lib.fptr(_c(beta)),
                                               _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), R, C, eps,
-                                              _lib.stream_of(a)), "dg_ln_residual_fwd")
-        _account("ln_fwd", 4 * R * C * (3 if r is not None else 2))
+                                              _lib.dt(a), _lib.stream_of(a)), "dg_ln_residual_fwd")
+        _account("ln_fwd", a.element_size() * R * C * (3 if r is not None else 2))
         ctx.save_for_backward(a, r, gamma, mean, rstd)
         return y
 
@@ -196,7 +197,7 @@ class _LNResidual(Function):
 class _LNResidualBwd(Function):
     @staticmethod
     def forward(ctx, a, r, gamma, mean, rstd, dy):
-        dy = _c(dy)
+        dy = _c(dy if dy.dtype == a.dtype else dy.to(a.dtype))
         C = a.shape[-1]
         R = a.numel() // C
         lib = _lib.load()
@@ -204,11 +205,11 @@ class _LNResidualBwd(Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         with _dev(a):
             ws, need = _workspace(a, R, C)
-            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(mean),
+            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(a), _lib.ptr(r), _lib.fptr(_c(gamma)), _lib.ptr(mean),
                                               _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(dz), _lib.ptr(dgamma),
-                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, C, _lib.stream_of(a)),
-                       "dg_ln_residual_bwd")
-        _account("ln_bwd", 4 * R * C * (4 if r is not None else 3))
+                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, C, _lib.dt(a),
+                                              _lib.stream_of(a)), "dg_ln_residual_bwd")
+        _account("ln_bwd", a.element_size() * R * C * (4 if r is not None else 3))
         ctx.save_for_backward(a, r, gamma, mean, rstd, dy)
         ctx.set_materialize_grads(False)
         return dz, dgamma, dbeta
@@ -231,11 +232,11 @@ class _LNResidualBwd(Function):
         ggamma = torch.empty_like(gamma)
         with _dev(a):
             ws, need = _workspace(a, R, C)
-            _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(a), _lib.ptr(r), _lib.ptr(_c(gamma)), _lib.ptr(mean),
+            _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(a), _lib.ptr(r), _lib.fptr(_c(gamma)), _lib.ptr(mean),
                                                _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(tz), _lib.ptr(gz),
                                                _lib.ptr(gdy), _lib.ptr(ggamma), ws.data_ptr(), ws.numel(), R, C,
-                                               _lib.stream_of(a)), "dg_ln_residual_bwd2")
-        _account("ln_bwd2", 4 * R * C * (6 if r is not None else 5))
+                                               _lib.dt(a), _lib.stream_of(a)), "dg_ln_residual_bwd2")
+        _account("ln_bwd2", a.element_size() * R * C * (6 if r is not None else 5))
         return gz, (gz if r is not None else None), ggamma, None, None, gdy
 
 
@@ -249,6 +250,41 @@ def ln_residual(a, r, gamma, beta, eps: float = 1e-5):
 # (reference: every nn.Linear of src/model/layers.py; forward / input-gradient
 # contractions stay on the ROCm BLAS behind F.linear / matmul)
 # --------------------------------------------------------------------------
+_ACT_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32,
+               "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def _as_act_dtype(dtype):
+    dtype = _ACT_DTYPES.get(dtype, dtype) if isinstance(dtype, str) else dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"activation dtype must be torch.float32 or torch.bfloat16, got {dtype!r}")
+    return dtype
+
+
+def set_activation_dtype(dtype) -> None:
+    """Storage type of the encoder activations produced by Generator / Discriminator from now on:
+    ``torch.float32`` (BASELINE configs[1], default) or ``torch.bfloat16`` (configs[2]: every
+    [B,N,N,C] / [B,N,C] activation and activation gradient lives in HBM as bf16, one bf16 MFMA per
+    product, fp32 accumulation, fp32 softmax / LayerNorm statistics, fp32 parameters, optimizer
+    state and weight gradients).  Model inputs and outputs (one-hot graphs, logits) stay float32."""
+    _flags.act_dtype = _as_act_dtype(dtype)
+
+
+def activation_dtype():
+    return _flags.act_dtype
+
+
+@contextlib.contextmanager
+def activations(dtype):
+    """``with activations(torch.bfloat16): ...`` -- scoped form of ``set_activation_dtype``."""
+    prev = _flags.act_dtype
+    _flags.act_dtype = _as_act_dtype(dtype)
+    try:
+        yield
+    finally:
+        _flags.act_dtype = prev
+
+
 class _Flags:
     """Process-wide (NOT thread-local) pass flags.  A backward node of a CUDA tensor runs on the
     autograd engine's device thread, and nn.DataParallel runs every replica forward on its own thread:
@@ -258,6 +294,7 @@ class _Flags:
     plain counter is enough."""
     inputs_only = 0
     second_order = 0
+    act_dtype = torch.float32
 
 
 _flags = _Flags()
@@ -281,7 +318,10 @@ def inputs_only_backward():
 
 
 def _wgrad(dy2, x2, want_bias, dy_mask=None):
-    """dW [N,K] = dy2^T x2, db [N] = column sums of dy2 (or None)."""
+    """dW [N,K] = dy2^T x2, db [N] = column sums of dy2 (or None); float32 results for float32 or
+    bfloat16 operands."""
+    if dy2.dtype != x2.dtype:      # e.g. fp32 logit gradients against bf16 activations (readout layers)
+        dy2 = dy2.to(x2.dtype)
     R, N = dy2.shape
     K = x2.shape[1]
     lib = _lib.load()
@@ -290,29 +330,34 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None):
         # few INPUT features (embedding layer 1, Linear(5 -> 64), reference models.py:57): the same
         # streaming kernel with the operands swapped gives dW^T
         dwt, _ = _wgrad(x2, dy2, False)
-        return dwt.t().contiguous(), (dy2.sum(0) if want_bias else None)
+        return dwt.t().contiguous(), (dy2.float().sum(0) if want_bias else None)
     if need == 0:      # shape outside the kernel's table: library GEMM on the same device
+        dyf, xf = dy2.float(), x2.float()
         if dy_mask is not None:
-            dy2 = dy2 * (dy_mask > 0)
-        return dy2.t().mm(x2), (dy2.sum(0) if want_bias else None)
+            dyf = dyf * (dy_mask > 0)
+        return dyf.t().mm(xf), (dyf.sum(0) if want_bias else None)
     dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
     db = torch.empty(N, dtype=torch.float32, device=dy2.device) if want_bias else None
     with _dev(dy2):
         ws = _scratch(dy2, need, "wgrad")
         _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
-                                       ws.numel(), R, N, K, _lib.stream_of(dy2)), "dg_linear_wgrad")
-    _account("linear_wgrad", 4 * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
+                                       ws.numel(), R, N, K, _lib.dt(dy2), _lib.stream_of(dy2)), "dg_linear_wgrad")
+    _account("linear_wgrad", dy2.element_size() * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
     return dw, db
 
 
 def _mm_rows(a, w, mode, bias=None):
     """a @ w^T (mode 0) or a @ w (mode 1) over the rows of ``a`` on dg_row_gemm when the shape is one
-    of its three, else on the ROCm BLAS (tiny / odd layers: embedding, readout, discriminator head)."""
+    of its three, else on the ROCm BLAS (tiny / odd layers: embedding, readout, discriminator head).
+    The result has ``a``'s dtype (float32 or bfloat16 activations; parameters are float32)."""
     rows, cols = w.shape
     K, N = (cols, rows) if mode == 0 else (rows, cols)
-    if a.is_cuda and a.dtype == torch.float32 and row_gemm_supported(K, N):
-        out = row_gemm(_c(a).reshape(-1, K), packed_weight(w, mode), K, N, bias=bias)
+    if a.is_cuda and a.dtype in _lib.DTYPES and row_gemm_supported(K, N):
+        out = row_gemm(_c(a).reshape(-1, K), packed_weight(w, mode, a.dtype), K, N, bias=bias)
         return out.view(*a.shape[:-1], N)
+    if a.dtype != w.dtype:
+        w = w.to(a.dtype)
+        bias = None if bias is None else bias.to(a.dtype)
     if mode == 0:
         return torch.nn.functional.linear(a, w, bias)
     return a.matmul(w)
@@ -393,10 +438,11 @@ def bump_weights_epoch() -> None:
                 del cache[k]
 
 
-def packed_weight(w, mode: int):
+def packed_weight(w, mode: int, dtype=torch.float32):
     """MFMA-fragment-ordered copy of an nn.Linear weight (mode 0: forward, 1: input
-    gradient), cached per (storage, version): re-packed only after an optimizer step."""
-    key = (id(w), mode)
+    gradient) for activations of ``dtype``, cached per (storage, version): re-packed only after an
+    optimizer step."""
+    key = (id(w), mode, dtype)
     hit = _pack_cache.get(key)
     if (hit is not None and hit[0]() is w and hit[1] == w._version and hit[3] == w.data_ptr()
             and hit[4] == _weights_epoch):
@@ -407,10 +453,11 @@ def packed_weight(w, mode: int):
     lib = _lib.load()
     rows, cols = w.shape
     n_out, k = (rows, cols) if mode == 0 else (cols, rows)
-    packed = torch.empty(int(lib.dg_row_gemm_packed_floats(n_out, k)), dtype=torch.float32, device=w.device)
+    code = _lib.DTYPES[dtype]
+    packed = torch.empty(int(lib.dg_row_gemm_packed_bytes(n_out, k, code)), dtype=torch.uint8, device=w.device)
     wd = _c(w.detach())
     with _dev(w):
-        _lib.check(lib.dg_row_gemm_pack(_lib.ptr(wd), _lib.ptr(packed), rows, cols, mode, _lib.stream_of(w)),
+        _lib.check(lib.dg_row_gemm_pack(_lib.fptr(wd), packed.data_ptr(), rows, cols, mode, code, _lib.stream_of(w)),
                    "dg_row_gemm_pack")
     _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr(), _weights_epoch)
     return packed
@@ -424,27 +471,31 @@ def row_gemm(a2, packed, K, N, bias=None, relu=False, want_relu_bits=False, mask
              want_pre=False):
     """y = epi(a2 @ B): see include/druggen_hip.h.  ``ln=(gamma, beta, eps)`` selects the LayerNorm
     epilogue and returns (y, mean, rstd[, pre]); ``want_relu_bits`` additionally returns the packed
-    ReLU mask (y, bits) that a later input-gradient launch of the same geometry takes as ``mask_bits``."""
+    ReLU mask (y, bits) that a later input-gradient launch of the same geometry takes as ``mask_bits``.
+    ``a2`` (and ``residual``) may be float32 or bfloat16; y / pre have the same dtype."""
     R = a2.shape[0]
     lib = _lib.load()
-    y = torch.empty(R, N, dtype=torch.float32, device=a2.device)
+    adt, code, es = a2.dtype, _lib.dt(a2), a2.element_size()
+    y = torch.empty(R, N, dtype=adt, device=a2.device)
     mean = rstd = gamma = beta = pre = bits = None
     eps = 0.0
     if ln is not None and want_pre:
-        pre = torch.empty(R, N, dtype=torch.float32, device=a2.device)
+        pre = torch.empty(R, N, dtype=adt, device=a2.device)
     if ln is not None:
         gamma, beta, eps = ln
         mean = torch.empty(R, dtype=torch.float32, device=a2.device)
         rstd = torch.empty(R, dtype=torch.float32, device=a2.device)
     if want_relu_bits:
-        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, K, N)), dtype=torch.int32, device=a2.device)
+        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, K, N, code)), dtype=torch.int32, device=a2.device)
+    if residual is not None and residual.dtype != adt:
+        residual = residual.to(adt)
     with _dev(a2):
-        _lib.check(lib.dg_row_gemm(_lib.ptr(a2), _lib.ptr(packed), _lib.ptr(y), R, K, N, _lib.ptr(bias),
+        _lib.check(lib.dg_row_gemm(_lib.ptr(a2), packed.data_ptr(), _lib.ptr(y), R, K, N, _lib.fptr(bias),
                                    1 if relu else 0, None if bits is None else bits.data_ptr(),
                                    None if mask_bits is None else mask_bits.data_ptr(), _lib.ptr(residual),
-                                   _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
-                                   float(eps), _lib.stream_of(a2)), "dg_row_gemm")
-    _account("row_gemm", 4 * R * (K + N * (1 + (residual is not None))), 2 * R * K * N)
+                                   _lib.fptr(gamma), _lib.fptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
+                                   float(eps), code, _lib.stream_of(a2)), "dg_row_gemm")
+    _account("row_gemm", es * R * (K + N * (1 + (residual is not None))), 2 * R * K * N)
     if ln is not None:
         return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
     return (y, bits) if want_relu_bits else y
@@ -485,7 +536,7 @@ def _double_backward_fallback(composite, inputs, grad_out):
 
 def _fusable(x, w):
     N, K = w.shape
-    return x.is_cuda and x.dtype == torch.float32 and row_gemm_supported(K, N)
+    return x.is_cuda and x.dtype in _lib.DTYPES and row_gemm_supported(K, N)
 
 
 def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None):
@@ -496,11 +547,11 @@ def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None):
     dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
     with _dev(pre):
         ws, _ = _workspace(pre, R, N)
-        _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean),
+        _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(pre), None, _lib.fptr(_c(gamma)), _lib.ptr(mean),
                                               _lib.ptr(rstd), _lib.ptr(dy2), _lib.ptr(dz_add), _lib.ptr(dz),
                                               _lib.ptr(dgamma), _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, N,
-                                              _lib.stream_of(pre)), "dg_ln_residual_bwd")
-    _account("ln_bwd", 4 * R * N * (4 if dz_add is not None else 3))
+                                              _lib.dt(pre), _lib.stream_of(pre)), "dg_ln_residual_bwd")
+    _account("ln_bwd", pre.element_size() * R * N * (4 if dz_add is not None else 3))
     return dz, dgamma, dbeta
 
 
@@ -512,12 +563,18 @@ def _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, tz):
     ggamma = torch.empty_like(gamma)
     with _dev(pre):
         ws, _ = _workspace(pre, R, N)
-        _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(pre), None, _lib.ptr(_c(gamma)), _lib.ptr(mean), _lib.ptr(rstd),
+        _lib.check(lib.dg_ln_residual_bwd2(_lib.ptr(pre), None, _lib.fptr(_c(gamma)), _lib.ptr(mean), _lib.ptr(rstd),
                                            _lib.ptr(dy2), _lib.ptr(tz), _lib.ptr(gz), _lib.ptr(gdy), _lib.ptr(ggamma),
-                                           ws.data_ptr(), ws.numel(), R, N, _lib.stream_of(pre)),
+                                           ws.data_ptr(), ws.numel(), R, N, _lib.dt(pre), _lib.stream_of(pre)),
                    "dg_ln_residual_bwd2")
-    _account("ln_bwd2", 4 * R * N * 5)
+    _account("ln_bwd2", pre.element_size() * R * N * 5)
     return gz, gdy, ggamma
+
+
+def _fused_ffn_enabled() -> bool:
+    """DG_FFN_BF16=unfused keeps the bf16 feed-forward on the two-launch row-GEMM path (A/B measurements)."""
+    import os
+    return os.environ.get("DG_FFN_BF16", "fused") != "unfused"
 
 
 def _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps):
@@ -538,19 +595,20 @@ class _FFNLN(Function):
         R = x2.shape[0]
         lib = _lib.load()
         dev = x2.device
-        y = torch.empty(R, C, dtype=torch.float32, device=dev)
-        h = torch.empty(R, H, dtype=torch.float32, device=dev)
-        pre = torch.empty(R, C, dtype=torch.float32, device=dev)
+        adt, code, es = x2.dtype, _lib.dt(x2), x2.element_size()
+        y = torch.empty(R, C, dtype=adt, device=dev)
+        h = torch.empty(R, H, dtype=adt, device=dev)
+        pre = torch.empty(R, C, dtype=adt, device=dev)
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
-        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H)), dtype=torch.int32, device=dev)
+        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev)
         with _dev(x2):
-            _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), _lib.ptr(packed_weight(w1, 0)), _lib.ptr(_c(b1)),
-                                              _lib.ptr(packed_weight(w2, 0)), _lib.ptr(_c(b2)), _lib.ptr(_c(gamma)),
-                                              _lib.ptr(_c(beta)), _lib.ptr(y), _lib.ptr(h), bits.data_ptr(),
-                                              _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps,
+            _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), packed_weight(w1, 0, adt).data_ptr(), _lib.fptr(_c(b1)),
+                                              packed_weight(w2, 0, adt).data_ptr(), _lib.fptr(_c(b2)), _lib.fptr(_c(gamma)),
+                                              _lib.fptr(_c(beta)), _lib.ptr(y), _lib.ptr(h), bits.data_ptr(),
+                                              _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
                                               _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
-        _account("row_gemm", 4 * R * (C + H) + 4 * R * (H + 2 * C), 4 * R * C * H)
+        _account("row_gemm", es * R * (C + H) + es * R * (H + 2 * C), 4 * R * C * H)
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         ctx.set_materialize_grads(False)
@@ -584,11 +642,12 @@ class _FFNLNBwd(Function):
         R = pre.shape[0]
         lib = _lib.load()
         dev = pre.device
-        dy2 = _c(dy).reshape(-1, C)
+        adt, code, es = pre.dtype, _lib.dt(pre), pre.element_size()
+        dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
         x2 = _c(x).reshape(-1, C)
-        dz = torch.empty(R, C, dtype=torch.float32, device=dev)
-        dh = torch.empty(R, H, dtype=torch.float32, device=dev)
-        dx = torch.empty(R, C, dtype=torch.float32, device=dev) if want_x else None
+        dz = torch.empty(R, C, dtype=adt, device=dev)
+        dh = torch.empty(R, H, dtype=adt, device=dev)
+        dx = torch.empty(R, C, dtype=adt, device=dev) if want_x else None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
@@ -600,18 +659,18 @@ class _FFNLNBwd(Function):
         with _dev(pre):
             ws = _scratch(pre, need, "ffn")
             _lib.check(lib.dg_edge_ffn_ln_bwd(_lib.ptr(x2), _lib.ptr(h), bits.data_ptr(), _lib.ptr(pre), _lib.ptr(mean),
-                                              _lib.ptr(rstd), _lib.ptr(_c(gamma)), _lib.ptr(packed_weight(w1, 1)),
-                                              _lib.ptr(packed_weight(w2, 1)), _lib.ptr(dy2),
+                                              _lib.ptr(rstd), _lib.fptr(_c(gamma)), packed_weight(w1, 1, adt).data_ptr(),
+                                              packed_weight(w2, 1, adt).data_ptr(), _lib.ptr(dy2),
                                               _lib.ptr(None if dz_add is None else _c(dz_add)), _lib.ptr(dz),
                                               _lib.ptr(dh), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                               _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
-                                              ws.data_ptr(), ws.numel(), R, C, H, _lib.stream_of(pre)),
+                                              ws.data_ptr(), ws.numel(), R, C, H, code, _lib.stream_of(pre)),
                        "dg_edge_ffn_ln_bwd")
-        _account("ln_bwd", 4 * R * C * 3)
-        _account("row_gemm", 4 * R * (C + H) + (4 * R * (H + 2 * C) if dx is not None else 0),
+        _account("ln_bwd", es * R * C * 3)
+        _account("row_gemm", es * R * (C + H) + (es * R * (H + 2 * C) if dx is not None else 0),
                  2 * R * C * H * (2 if dx is not None else 1))
         if want_w:
-            _account("linear_wgrad", 8 * R * (C + H), 4 * R * C * H)
+            _account("linear_wgrad", 2 * es * R * (C + H), 4 * R * C * H)
         ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)
         ctx.had_add = dz_add is not None
         ctx.set_materialize_grads(False)
@@ -629,8 +688,9 @@ class _FFNLNBwd(Function):
             raise RuntimeError("ffn_ln: third-order differentiation is not implemented")
         x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh = ctx.saved_tensors
         H, C = w1.shape
-        t = _c(t_dx).reshape(-1, C)
-        pw = packed_weight
+        adt = pre.dtype
+        t = _c(t_dx if t_dx.dtype == adt else t_dx.to(adt)).reshape(-1, C)
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
         vbar = row_gemm(t, pw(w1, 0), C, H, mask_bits=bits)              # (t W1^T) * m
         ubar = row_gemm(vbar, pw(w2, 0), H, C, residual=t)               # t + vbar W2^T
         zbar, dybar, gbar = _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, ubar)
@@ -644,14 +704,111 @@ class _FFNLNBwd(Function):
         return None, gw1, None, gw2, None, gbar, None, None, None, zbar, None, dybar.view_as(t_dx), None, None, None
 
 
+_ffn_pack_cache = {}
+
+
+def _ffn_packed_bf16(w1, w2):
+    """The four bf16 fragment-order copies of (fc1.weight, fc2.weight) the fused bf16 feed-forward kernels keep
+    in registers (dg_ffn_bf16_pack), cached like ``packed_weight``."""
+    key = (id(w1), id(w2))
+    hit = _ffn_pack_cache.get(key)
+    if (hit is not None and hit[0]() is w1 and hit[1]() is w2 and hit[2] == (w1._version, w2._version)
+            and hit[4] == (w1.data_ptr(), w2.data_ptr()) and hit[5] == _weights_epoch):
+        return hit[3]
+    if len(_ffn_pack_cache) > 1024:
+        for k in [k for k, v in _ffn_pack_cache.items() if v[0]() is None or v[1]() is None]:
+            del _ffn_pack_cache[k]
+    lib = _lib.load()
+    packed = torch.empty(int(lib.dg_ffn_bf16_packed_bytes()), dtype=torch.uint8, device=w1.device)
+    with _dev(w1):
+        _lib.check(lib.dg_ffn_bf16_pack(_lib.fptr(_c(w1.detach())), _lib.fptr(_c(w2.detach())), packed.data_ptr(),
+                                        _lib.stream_of(w1)), "dg_ffn_bf16_pack")
+    _ffn_pack_cache[key] = (weakref.ref(w1), weakref.ref(w2), (w1._version, w2._version), packed,
+                            (w1.data_ptr(), w2.data_ptr()), _weights_epoch)
+    return packed
+
+
+class _FFNLNFusedBF16(Function):
+    """LN(x + fc2(relu(fc1 x))) on the fused bf16 kernels (csrc/ffn_bf16.hip): the [R, 384] hidden tensor stays
+    in LDS, the backward recomputes it (saved: pre-LayerNorm sum, mean / rstd, one ReLU bit per hidden element).
+    First order only -- graphs that will be differentiated twice are built from ``_FFNLN`` (``ffn_ln`` below);
+    if somebody differentiates this node twice anyway it falls back to the composite."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        R = x2.shape[0]
+        lib = _lib.load()
+        dev = x2.device
+        record = any(ctx.needs_input_grad)
+        y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        pre = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if record else None
+        bits = torch.empty(int(lib.dg_ffn_bf16_mask_words(R)), dtype=torch.int32, device=dev) if record else None
+        with _dev(x2):
+            _lib.check(lib.dg_ffn_ln_fwd_bf16(_lib.ptr(x2), _ffn_packed_bf16(w1, w2).data_ptr(), _lib.fptr(_c(b1)),
+                                              _lib.fptr(_c(b2)), _lib.fptr(_c(gamma)), _lib.fptr(_c(beta)), _lib.ptr(y),
+                                              _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd),
+                                              None if bits is None else bits.data_ptr(), R, eps, _lib.stream_of(x2)),
+                       "dg_ffn_ln_fwd_bf16")
+        _account("ffn", 2 * R * C * (3 if record else 2) + (48 * R if record else 0), 4 * R * C * 3 * C)
+        if record:
+            ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, pre, mean, rstd, bits)
+        ctx.eps = eps
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, gamma, beta, pre, mean, rstd, bits = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            eps = ctx.eps
+            return _double_backward_fallback(lambda *t: _composite_ffn_ln(*t, eps), (x, w1, b1, w2, b2, gamma, beta),
+                                             dy) + (None,)
+        C, H = w1.shape[1], w1.shape[0]
+        x2 = _c(x).reshape(-1, C)
+        R = x2.shape[0]
+        lib = _lib.load()
+        dev = x2.device
+        dy2 = _c(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)).reshape(-1, C)
+        want_x = ctx.needs_input_grad[0]
+        want_w = ctx.needs_input_grad[1] and not _inputs_only()
+        dz = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if want_x else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dw1 = db1 = dw2 = db2 = bits2 = None
+        if want_w:
+            dw1, db1 = torch.empty_like(w1), torch.empty(H, dtype=torch.float32, device=dev)
+            dw2, db2 = torch.empty_like(w2), torch.empty(C, dtype=torch.float32, device=dev)
+            bits2 = torch.empty_like(bits)
+        need = int(lib.dg_ffn_bf16_workspace_bytes(R))
+        with _dev(x2):
+            ws = _scratch(x2, need, "ffn16")
+            _lib.check(lib.dg_ffn_ln_bwd_bf16(_lib.ptr(x2), _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), bits.data_ptr(),
+                                              _lib.fptr(_c(gamma)), _ffn_packed_bf16(w1, w2).data_ptr(), _lib.fptr(_c(b1)),
+                                              _lib.ptr(dy2), _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                              _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
+                                              None if bits2 is None else bits2.data_ptr(), ws.data_ptr(), ws.numel(), R,
+                                              _lib.stream_of(x2)), "dg_ffn_ln_bwd_bf16")
+        _account("ffn", 2 * R * C * (4 if want_x else 3) + 48 * R, 4 * R * C * H if want_x else 2 * R * C * H)
+        if want_w:
+            _account("ffn_wgrad", 2 * (2 * R * C * 2 + 48 * R), 8 * R * C * H)
+        if not ctx.needs_input_grad[5] or _inputs_only():
+            dgamma = dbeta = None
+        return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta, None
+
+
 def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):
     """LayerNorm(x + fc2(relu(fc1(x)))) with everything elementwise fused into the GEMM
     epilogues (dim 128, hidden 384); other shapes / second-order graphs use the composite."""
     H, C = w1.shape
-    ok = (x.is_cuda and x.dtype == torch.float32 and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
+    ok = (x.is_cuda and x.dtype in _lib.DTYPES and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
           and b1 is not None and b2 is not None)
     if not ok:
         return _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, float(eps))
+    if x.dtype == torch.bfloat16 and not in_second_order_forward() and _fused_ffn_enabled():
+        return _FFNLNFusedBF16.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
     return _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))[0]
 
 
@@ -670,7 +827,7 @@ class _LinearLN(Function):
         N, K = w.shape
         x2 = _c(x).reshape(-1, K)
         r2 = _c(residual).reshape(-1, N)
-        y, mean, rstd, pre = row_gemm(x2, packed_weight(w, 0), K, N, bias=b, residual=r2,
+        y, mean, rstd, pre = row_gemm(x2, packed_weight(w, 0, x2.dtype), K, N, bias=b, residual=r2,
                                       ln=(_c(gamma), _c(beta), eps), want_pre=True)
         ctx.save_for_backward(x, w, b, residual, gamma, beta, mean, rstd, pre)
         ctx.eps = eps
@@ -685,10 +842,10 @@ class _LinearLN(Function):
                                           (x, w, b, residual, gamma, beta), dy)
             return g + (None,)
         N, K = w.shape
-        dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy).reshape(-1, N))
+        dz, dgamma, dbeta = _ln_bwd_rows(pre, gamma, mean, rstd, _c(dy if dy.dtype == pre.dtype else dy.to(pre.dtype)).reshape(-1, N))
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = row_gemm(dz, packed_weight(w, 1), N, K).view(x.shape)
+            dx = row_gemm(dz, packed_weight(w, 1, dz.dtype), N, K).view(x.shape)
         if ctx.needs_input_grad[1] and not _inputs_only():
             dw, db = _wgrad(dz, _c(x).reshape(-1, K), b is not None)
         return dx, dw, db, dz.view(residual.shape), dgamma, dbeta, None
@@ -728,7 +885,8 @@ class _AttnBlock(Function):
                 need_edge):
         B, N, C = x1.shape
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
-        pw = packed_weight
+        adt = x1f.dtype
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
         q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
         k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
         v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
@@ -738,8 +896,8 @@ class _AttnBlock(Function):
         o = torch.empty_like(q)
         with _dev(q):
             _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
-                                            _lib.ptr(o), B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_fwd")
-        _account("attn_fwd", 4 * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
+                                            _lib.ptr(o), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_fwd")
+        _account("attn_fwd", q.element_size() * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
         x2, mean3, rstd3, pre3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3),
                                           want_pre=True)
         outs = [x2.view(B, N, C)]
@@ -792,8 +950,8 @@ def _attn_bwd_launch(q, k, v, e, ws, wo, alpha):
     with _dev(q):
         _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws), _lib.ptr(wo),
                                         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), B, N, C, alpha,
-                                        _lib.stream_of(q)), "dg_attn_core_bwd")
-    _account("attn_bwd", 4 * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
+                                        _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_bwd")
+    _account("attn_bwd", q.element_size() * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
     return dq, dk, dv, de
 
 
@@ -807,8 +965,8 @@ def _attn_bwd2_launch(q, k, v, e, ws, wo, tq, tk, tv, te, alpha):
         _lib.check(lib.dg_attn_core_bwd2(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws), _lib.ptr(wo),
                                          _lib.ptr(tq), _lib.ptr(tk), _lib.ptr(tv), _lib.ptr(te), _lib.ptr(gq),
                                          _lib.ptr(gk), _lib.ptr(gv), _lib.ptr(ge), _lib.ptr(gws), _lib.ptr(gwo),
-                                         B, N, C, alpha, _lib.stream_of(q)), "dg_attn_core_bwd2")
-    _account("attn_bwd2", 4 * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
+                                         B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_bwd2")
+    _account("attn_bwd2", q.element_size() * B * ((5 if ws is not None else 3) * N * N * C + 11 * N * C))
     return gq, gk, gv, ge, gws, gwo
 
 
@@ -826,15 +984,17 @@ class _AttnBlockBwd(Function):
                 mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
                 alpha, need_edge, want_x, want_y, wants_w):
         B, N, C = x1.shape
-        pw = packed_weight
+        adt = q.dtype
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
+        cast = lambda t: t if t.dtype == adt else t.to(adt)
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
-        dx2f = _c(dx2).reshape(-1, C)
-        cadd = lambda t: None if t is None else _c(t).reshape(-1, C)
+        dx2f = _c(cast(dx2)).reshape(-1, C)
+        cadd = lambda t: None if t is None else _c(cast(t)).reshape(-1, C)
         dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3))
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
-            dy2f = _c(dy2).reshape(-1, C)
+            dy2f = _c(cast(dy2)).reshape(-1, C)
             dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4))
             ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
@@ -876,13 +1036,15 @@ class _AttnBlockBwd(Function):
         alpha, need_edge, (B, N, C), dx2_shape, dy2_shape = ctx.cfg
         (x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4,
          dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de) = ctx.saved_tensors
-        pw = packed_weight
+        adt = q.dtype
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
+        cast = lambda t: t if t.dtype == adt else t.to(adt)
         with_w = not _inputs_only()
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         RN, RE = B * N, B * N * N
-        zn = lambda: torch.zeros(RN, C, dtype=torch.float32, device=q.device)
-        t1f = _c(t1).reshape(-1, C) if t1 is not None else zn()
-        tyf = _c(ty).reshape(-1, C) if ty is not None else torch.zeros(RE, C, dtype=torch.float32, device=q.device)
+        zn = lambda: torch.zeros(RN, C, dtype=adt, device=q.device)
+        t1f = _c(cast(t1)).reshape(-1, C) if t1 is not None else zn()
+        tyf = _c(cast(ty)).reshape(-1, C) if ty is not None else torch.zeros(RE, C, dtype=adt, device=q.device)
         dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
         # adjoints of dq, dk, dv, de (dx1 = dz3 + dq Wq + dk Wk + dv Wv ; dy = dz4 + de We)
         tq = row_gemm(t1f, pw(wq, 0), C, C)
@@ -925,7 +1087,7 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
     args = (x1, y, attn.q.weight, attn.q.bias, attn.k.weight, attn.k.bias, attn.v.weight, attn.v.bias,
             attn.e.weight, attn.e.bias, attn.out_e.weight, attn.out_e.bias, attn.out_n.weight, attn.out_n.bias,
             ln3.weight, ln3.bias, ln4.weight, ln4.bias)
-    fused = (x1.is_cuda and x1.dtype == torch.float32 and C == 128 and x1.dim() == 3
+    fused = (x1.is_cuda and x1.dtype in _lib.DTYPES and y.dtype == x1.dtype and C == 128 and x1.dim() == 3
              and all(t is not None for t in args))
     if not fused:
         out = _composite_attn_block(*args, alpha, ln3.eps, ln4.eps, need_edge)
@@ -970,19 +1132,20 @@ def _composite_embed_sym(a, w1, b1, w2, b2, act):
 
 class _EmbedSym(Function):
     @staticmethod
-    def forward(ctx, a, w1, b1, w2, b2, act):
+    def forward(ctx, a, w1, b1, w2, b2, act, out_dtype):
         a = _c(a)
         B, N, _, E = a.shape
         H, C = w1.shape[0], w2.shape[0]
         lib = _lib.load()
-        out = torch.empty(B, N, N, C, dtype=torch.float32, device=a.device)
+        out = torch.empty(B, N, N, C, dtype=out_dtype, device=a.device)
         with _dev(a):
-            _lib.check(lib.dg_embed_sym_fwd(_lib.ptr(a), _lib.ptr(_c(w1)), _lib.ptr(_c(b1)), _lib.ptr(_embed_packed_w2(w2)),
-                                            _lib.ptr(_c(b2)), _lib.ptr(out), B, N, E, H, C, _ACT_IDS[act],
-                                            _lib.stream_of(a)), "dg_embed_sym_fwd")
-        _account("embed_sym", 4 * B * N * N * (E + C), 2 * B * N * N * (E * H + H * C))
+            _lib.check(lib.dg_embed_sym_fwd(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)), _lib.fptr(_embed_packed_w2(w2)),
+                                            _lib.fptr(_c(b2)), _lib.ptr(out), B, N, E, H, C, _ACT_IDS[act],
+                                            _lib.dt(out), _lib.stream_of(a)), "dg_embed_sym_fwd")
+        _account("embed_sym", B * N * N * (4 * E + out.element_size() * C), 2 * B * N * N * (E * H + H * C))
         ctx.save_for_backward(a, w1, b1, w2, b2)
         ctx.act = act
+        ctx.out_dtype = out_dtype
         return out
 
     @staticmethod
@@ -990,34 +1153,36 @@ class _EmbedSym(Function):
         a, w1, b1, w2, b2 = ctx.saved_tensors
         act = ctx.act
         if torch.is_grad_enabled():
-            return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act), (a, w1, b1, w2, b2), g) + (None,)
+            odt = ctx.out_dtype
+            return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act).to(odt), (a, w1, b1, w2, b2), g) + (None, None)
         B, N, _, E = a.shape
         H, C = w1.shape[0], w2.shape[0]
         lib = _lib.load()
-        g = _c(g)
+        g = _c(g if g.dtype == ctx.out_dtype else g.to(ctx.out_dtype))
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
         need = int(lib.dg_embed_sym_workspace_bytes(B, N))
         with _dev(a):
             ws = _scratch(a, need, "embed")
-            _lib.check(lib.dg_embed_sym_bwd(_lib.ptr(a), _lib.ptr(_c(w1)), _lib.ptr(_c(b1)),
-                                            _lib.ptr(_embed_packed_w2(w2)), _lib.ptr(_embed_packed_w2(w2, True)),
-                                            _lib.ptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
+            _lib.check(lib.dg_embed_sym_bwd(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)),
+                                            _lib.fptr(_embed_packed_w2(w2)), _lib.fptr(_embed_packed_w2(w2, True)),
+                                            _lib.fptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
                                             _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
-                                            _ACT_IDS[act], _lib.stream_of(a)), "dg_embed_sym_bwd")
-        _account("embed_sym", 4 * B * N * N * (E * (2 if da is not None else 1) + C),
+                                            _ACT_IDS[act], _lib.dt(g), _lib.stream_of(a)), "dg_embed_sym_bwd")
+        _account("embed_sym", B * N * N * (4 * E * (2 if da is not None else 1) + g.element_size() * C),
                  2 * B * N * N * (E * H + H * C) * 3)
         if not ctx.needs_input_grad[1] or _inputs_only():
             dw1 = db1 = dw2 = db2 = None
-        return da, dw1, db1, dw2, db2, None
+        return da, dw1, db1, dw2, db2, None, None
 
 
-def embed_sym(a, w1, b1, w2, b2, act: str):
+def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
     """(f(a) + f(a)^T(i<->j)) / 2 with f = act(W2 act(W1 a + b1) + b2): the edge embedding MLP and the
-    symmetrisation of Generator / Discriminator in one kernel per direction (hidden 64, dim 128)."""
+    symmetrisation of Generator / Discriminator in one kernel per direction (hidden 64, dim 128).
+    The input graph ``a`` is float32; the [B,N,N,dim] result is stored as ``out_dtype``."""
     ok = (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape[1] == a.shape[2] and act in _ACT_IDS
           and a.shape[-1] <= 16 and tuple(w1.shape) == (64, a.shape[-1]) and tuple(w2.shape) == (128, 64)
           and b1 is not None and b2 is not None)
     if not ok or in_second_order_forward():
-        return _composite_embed_sym(a, w1, b1, w2, b2, act)
-    return _EmbedSym.apply(a, w1, b1, w2, b2, act)
+        return _composite_embed_sym(a, w1, b1, w2, b2, act).to(out_dtype)
+    return _EmbedSym.apply(a, w1, b1, w2, b2, act, out_dtype)

@@ -44,14 +44,17 @@ class _Trunk(nn.Module):
         if not z_e.is_cuda:
             raise RuntimeError("druggen_amd modules run on MI355X only (no CPU fallback): move the model and "
                                "its inputs to a GPU device")
+        adt = dgf.activation_dtype()      # storage of the encoder activations (float32, or bfloat16: configs[2])
         node = self._embed(self.node_layers, z_n)
+        if node.dtype != adt:
+            node = node.to(adt)
         el = self.edge_layers
         if self._act_name is not None and not (self.training and self.dropout > 0.0):
             # Linear(E,64) - act - Linear(64,dim) - act - symmetrise: one kernel (dg_embed_sym_fwd)
-            edge = dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name)
+            edge = dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
         else:
             edge = self._embed(el, z_e)
-            edge = (edge + edge.permute(0, 2, 1, 3)) / 2
+            edge = ((edge + edge.permute(0, 2, 1, 3)) / 2).to(adt)
         return self.TransformerEncoder(node, edge, need_edge)
 
 
@@ -67,8 +70,9 @@ class Generator(_Trunk):
 
     def forward(self, z_e, z_n):
         node, edge = self._encode(z_e, z_n, True)
-        node_sample = dgf.linear(node, self.readout_n.weight, self.readout_n.bias)
-        edge_sample = dgf.linear(edge, self.readout_e.weight, self.readout_e.bias)
+        # logits are float32 in every activation mode (they are the model's outputs and D's inputs)
+        node_sample = dgf.linear(node.float(), self.readout_n.weight, self.readout_n.bias)
+        edge_sample = dgf.linear(edge.float(), self.readout_e.weight, self.readout_e.bias)
         return node, edge, node_sample, edge_sample
 
 
@@ -85,7 +89,7 @@ class Discriminator(_Trunk):
 
     def forward(self, z_e, z_n):
         node, _ = self._encode(z_e, z_n, False)
-        return self.node_mlp(node.reshape(node.shape[0], -1))
+        return self.node_mlp(node.reshape(node.shape[0], -1).float())
 
 
 class simple_disc(nn.Module):

@@ -9,8 +9,13 @@
  * is that binding.
  *
  * Conventions
- *  - every pointer is a DEVICE pointer to contiguous float32, channel-last;
- *    the caller (PyTorch) owns all memory, kernels never allocate or retain;
+ *  - every pointer is a DEVICE pointer to a contiguous, channel-last tensor; the
+ *    caller (PyTorch) owns all memory, kernels never allocate or retain;
+ *  - `dtype` (DG_DTYPE_F32 / DG_DTYPE_BF16) is the storage type of the ACTIVATION
+ *    tensors of a call (the `void*` arguments): BASELINE configs[1] runs fp32,
+ *    configs[2] keeps every [B,N,N,C] / [B,N,C] activation and activation gradient
+ *    in bf16 in HBM.  Parameters, biases, LayerNorm statistics, weight gradients
+ *    and all in-register arithmetic / MFMA accumulation are float32 in both modes;
  *  - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream);
  *    calls only enqueue work and return, there is no implicit synchronisation;
  *  - return value 0 = success, negative = library error (DG_E_*), positive =
@@ -32,7 +37,9 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 100            /* 0.1.0 */
+#define DG_VERSION 200            /* 0.2.0 */
+#define DG_DTYPE_F32  0
+#define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */
@@ -48,63 +55,63 @@ const char* dg_last_error_string(void);
  * q,k,v,o: [B,N,C]   e,s: [B,N,N,C]   alpha = 1/sqrt(C/heads).
  * `s` is the tensor the reference feeds to out_e (line 127); pass NULL to skip
  * writing it (Discriminator's last block never reads it, models.py:202-207).      */
-int dg_attn_core_fwd(const float* q, const float* k, const float* v, const float* e,
-                     float* s, float* o, int B, int N, int C, float alpha, dg_stream_t stream);
+int dg_attn_core_fwd(const void* q, const void* k, const void* v, const void* e,
+                     void* s, void* o, int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
 
 /* First-order backward of the core (what autograd runs for lines 119-134).
  * ws = dL/ds [B,N,N,C], wo = dL/do [B,N,C]  ->  dq,dk,dv [B,N,C], de [B,N,N,C].
  * Recomputes s and p from (q,k,e); nothing but the inputs is saved.
  * ws may be NULL (treated as zeros).                                              */
-int dg_attn_core_bwd(const float* q, const float* k, const float* v, const float* e,
-                     const float* ws, const float* wo,
-                     float* dq, float* dk, float* dv, float* de,
-                     int B, int N, int C, float alpha, dg_stream_t stream);
+int dg_attn_core_bwd(const void* q, const void* k, const void* v, const void* e,
+                     const void* ws, const void* wo,
+                     void* dq, void* dk, void* dv, void* de,
+                     int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
 
 /* Second-order: backward of dg_attn_core_bwd, needed by the WGAN-GP gradient
  * penalty (src/model/loss.py:32-39 create_graph=True, train.py:367).
  * (tq,tk,tv,te) are the adjoints of (dq,dk,dv,de).  Outputs are the adjoints of
  * the six inputs of dg_attn_core_bwd: gq,gk,gv [B,N,C], ge [B,N,N,C],
  * gws [B,N,N,C], gwo [B,N,C].  ws and gws may be NULL.                           */
-int dg_attn_core_bwd2(const float* q, const float* k, const float* v, const float* e,
-                      const float* ws, const float* wo,
-                      const float* tq, const float* tk, const float* tv, const float* te,
-                      float* gq, float* gk, float* gv, float* ge, float* gws, float* gwo,
-                      int B, int N, int C, float alpha, dg_stream_t stream);
+int dg_attn_core_bwd2(const void* q, const void* k, const void* v, const void* e,
+                      const void* ws, const void* wo,
+                      const void* tq, const void* tk, const void* tv, const void* te,
+                      void* gq, void* gk, void* gv, void* ge, void* gws, void* gwo,
+                      int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
 
 /* ---- residual + LayerNorm: src/model/layers.py:185-192 ----------------------
  *   y = LayerNorm(a + r) * gamma + beta, eps = 1e-5, over the last dim C.
  * r may be NULL (ln1, layers.py:185).  a, r, y: [R,C]; mean, rstd: [R] (saved
  * for the backward).                                                              */
-int dg_ln_residual_fwd(const float* a, const float* r, const float* gamma, const float* beta,
-                       float* y, float* mean, float* rstd, int64_t R, int C, float eps,
-                       dg_stream_t stream);
+int dg_ln_residual_fwd(const void* a, const void* r, const float* gamma, const float* beta,
+                       void* y, float* mean, float* rstd, int64_t R, int C, float eps,
+                       int dtype, dg_stream_t stream);
 
 /* Workspace (bytes) for the column reductions of the two calls below. */
 size_t dg_ln_workspace_bytes(int64_t R, int C);
 
 /* dy [R,C] -> dz [R,C] (gradient of both a and r), dgamma [C], dbeta [C].       */
-int dg_ln_residual_bwd(const float* a, const float* r, const float* gamma,
-                       const float* mean, const float* rstd, const float* dy,
-                       float* dz, float* dgamma, float* dbeta,
+int dg_ln_residual_bwd(const void* a, const void* r, const float* gamma,
+                       const float* mean, const float* rstd, const void* dy,
+                       void* dz, float* dgamma, float* dbeta,
                        void* workspace, size_t workspace_bytes,
-                       int64_t R, int C, dg_stream_t stream);
+                       int64_t R, int C, int dtype, dg_stream_t stream);
 
 /* Same, with dz += dz_add (nullable): a second gradient source of the pre-LayerNorm sum
  * (the second-order pass of the gradient penalty) joins inside the kernel.             */
-int dg_ln_residual_bwd_add(const float* a, const float* r, const float* gamma,
-                           const float* mean, const float* rstd, const float* dy, const float* dz_add,
-                           float* dz, float* dgamma, float* dbeta,
+int dg_ln_residual_bwd_add(const void* a, const void* r, const float* gamma,
+                           const float* mean, const float* rstd, const void* dy, const void* dz_add,
+                           void* dz, float* dgamma, float* dbeta,
                            void* workspace, size_t workspace_bytes,
-                           int64_t R, int C, dg_stream_t stream);
+                           int64_t R, int C, int dtype, dg_stream_t stream);
 
 /* Backward of dg_ln_residual_bwd w.r.t. the adjoint tz of dz (the gradient
  * penalty differentiates the first backward w.r.t. inputs only):
  * -> gz [R,C] (adjoint of a and r), gdy [R,C] (adjoint of dy), ggamma [C].       */
-int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
-                        const float* mean, const float* rstd, const float* dy, const float* tz,
-                        float* gz, float* gdy, float* ggamma,
+int dg_ln_residual_bwd2(const void* a, const void* r, const float* gamma,
+                        const float* mean, const float* rstd, const void* dy, const void* tz,
+                        void* gz, void* gdy, float* ggamma,
                         void* workspace, size_t workspace_bytes,
-                        int64_t R, int C, dg_stream_t stream);
+                        int64_t R, int C, int dtype, dg_stream_t stream);
 
 /* ---- Linear weight/bias gradient over the edge rows ---------------------------
  * What autograd runs as mm(dy.t(), x) and sum(dy, 0) for every nn.Linear of
@@ -112,16 +119,18 @@ int dg_ln_residual_bwd2(const float* a, const float* r, const float* gamma,
  * and again in the gradient-penalty double backward (src/model/loss.py:32-39):
  *   dw[n][k] = sum_r dy[r][n] x[r][k]   (dw: [N,K], nn.Linear layout)
  *   db[n]    = sum_r dy[r][n]           (db may be NULL)
- * dy: [R,N], x: [R,K].  fp32 MFMA, split over the rows, fixed-order reduction.
+ * dy: [R,N], x: [R,K] (dtype), dw/db float32.  fp32: operands split 3-way into bf16, six MFMA
+ * cross products (fp32-class accuracy); bf16: one v_mfma_f32_32x32x16_bf16 per product.  Split
+ * over the rows, fixed-order reduction (bit-reproducible).
  * dy_mask (nullable, [R,N]): use dy * (dy_mask > 0), i.e. the ReLU backward of
  * MLP.fc1 (layers.py:51) folded into the operand load.
  * Supported (N,K): multiples of 32 from the table in csrc/linear_wgrad.hip
  * (128x128, 384x128, 128x384, 128x64, ...), plus N <= 16 with K % 4 == 0 (readout
  * layers, models.py:67-68: a streaming VALU kernel); others return DG_E_SHAPE.   */
 size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K);
-int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float* dw, float* db,
+int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* dw, float* db,
                     void* workspace, size_t workspace_bytes,
-                    int64_t R, int N, int K, dg_stream_t stream);
+                    int64_t R, int N, int K, int dtype, dg_stream_t stream);
 
 /* ---- fp32-MFMA row GEMM with fused epilogues ------------------------------------
  * The dense layers applied to every edge / node row: MHA projections
@@ -140,14 +149,18 @@ int dg_linear_wgrad(const float* dy, const float* dy_mask, const float* x, float
  * mask_bits and zeroes the masked outputs (reference: threshold_backward of
  * layers.py:51).  LayerNorm epilogue (gamma != NULL; layers.py:187-192) needs
  * N == 128, writes mean/rstd [R] and, if pre_ln != NULL, the pre-LayerNorm sum.   */
-size_t dg_row_gemm_packed_floats(int n_out, int k_contract);
-int dg_row_gemm_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
-size_t dg_row_gemm_mask_words(int64_t R, int K, int N);
-int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K, int N,
+size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype);
+int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols, int mode, int dtype, dg_stream_t stream);
+size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype);
+int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N,
                 const float* bias, int relu, unsigned* relu_bits_out, const unsigned* mask_bits,
-                const float* residual,
-                const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
-                float eps, dg_stream_t stream);
+                const void* residual,
+                const float* gamma, const float* beta, float* mean, float* rstd, void* pre_ln,
+                float eps, int dtype, dg_stream_t stream);
+/* dtype = DG_DTYPE_BF16 (csrc/gemm_bf16.hip): a, y, residual, pre_ln are bf16; the packed weight is the
+ * bf16 fragment-order copy made by dg_row_gemm_pack(..., DG_DTYPE_BF16, ...); one MFMA per product,
+ * fp32 accumulate and epilogue arithmetic.  Bit masks are available for every shape in this mode (the
+ * layout is private to the (K, N, dtype) triple: only pass a mask to a launch of the same triple).   */
 
 /* ---- feed-forward half of an Encoder_Block: src/model/layers.py:191-192 + MLP (:40-54) ----
  *   y = LayerNorm(x + fc2(relu(fc1(x)))) * gamma + beta      (dim C = 128, hidden H = 384)
@@ -160,17 +173,42 @@ int dg_row_gemm(const float* a, const float* packed, float* y, int64_t R, int K,
  * dh [R,H] (scratch the caller owns), dx (nullable), dgamma, dbeta,
  * dw1 [H,C], db1, dw2 [C,H], db2 (dw1/dw2 nullable = skip the weight gradients).             */
 size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H);
-int dg_edge_ffn_ln_fwd(const float* x, const float* w1_packed, const float* b1, const float* w2_packed,
+int dg_edge_ffn_ln_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed,
                        const float* b2, const float* gamma, const float* beta,
-                       float* y, float* h, unsigned* relu_bits, float* pre_ln, float* mean, float* rstd,
-                       int64_t R, int C, int H, float eps, dg_stream_t stream);
-int dg_edge_ffn_ln_bwd(const float* x, const float* h, const unsigned* relu_bits, const float* pre_ln,
+                       void* y, void* h, unsigned* relu_bits, void* pre_ln, float* mean, float* rstd,
+                       int64_t R, int C, int H, float eps, int dtype, dg_stream_t stream);
+int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* relu_bits, const void* pre_ln,
                        const float* mean, const float* rstd, const float* gamma,
-                       const float* w1_dgrad_packed, const float* w2_dgrad_packed, const float* dy,
-                       const float* dz_add,
-                       float* dz, float* dh, float* dx, float* dgamma, float* dbeta,
+                       const void* w1_dgrad_packed, const void* w2_dgrad_packed, const void* dy,
+                       const void* dz_add,
+                       void* dz, void* dh, void* dx, float* dgamma, float* dbeta,
                        float* dw1, float* db1, float* dw2, float* db2,
-                       void* workspace, size_t workspace_bytes, int64_t R, int C, int H, dg_stream_t stream);
+                       void* workspace, size_t workspace_bytes, int64_t R, int C, int H, int dtype,
+                       dg_stream_t stream);
+
+/* ---- the same feed-forward half as FUSED kernels, bf16 configuration only (csrc/ffn_bf16.hip) ----
+ *   y = LayerNorm(x + fc2(relu(fc1(x)))) * gamma + beta,  C = 128, H = 384, all activations bf16.
+ * The [R,384] hidden tensor never reaches HBM: per 64-row tile it lives in LDS; the backward
+ * recomputes it.  `packed` holds the four bf16 fragment-order copies of (W1 [384,128], W2 [128,384])
+ * made by dg_ffn_bf16_pack (dg_ffn_bf16_packed_bytes() bytes).  The forward saves pre_ln [R,128] bf16,
+ * mean / rstd [R] and one ReLU-mask bit per hidden element (dg_ffn_bf16_mask_words(R) uint32 words);
+ * pre_ln and relu_bits may be NULL when no backward will follow.
+ * _bwd: dy [R,128] -> dz [R,128] (scratch the caller owns: LayerNorm input gradient, bf16), dx (nullable),
+ * dgamma, dbeta, and -- when dw1 != NULL -- dw1 [384,128], db1, dw2 [128,384], db2 (float32);
+ * bits_scratch: dg_ffn_bf16_mask_words(R) words of scratch, needed with the weight gradients.
+ * First order only: the gradient penalty's twice-differentiated pass uses dg_edge_ffn_ln_fwd/_bwd.   */
+size_t dg_ffn_bf16_packed_bytes(void);
+int dg_ffn_bf16_pack(const float* w1, const float* w2, void* packed, dg_stream_t stream);
+size_t dg_ffn_bf16_mask_words(int64_t R);
+size_t dg_ffn_bf16_workspace_bytes(int64_t R);
+int dg_ffn_ln_fwd_bf16(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,
+                       const float* beta, void* y, void* pre_ln, float* mean, float* rstd, unsigned* relu_bits,
+                       int64_t R, float eps, dg_stream_t stream);
+int dg_ffn_ln_bwd_bf16(const void* x, const void* pre_ln, const float* mean, const float* rstd,
+                       const unsigned* relu_bits, const float* gamma, const void* packed, const float* b1,
+                       const void* dy, void* dz, void* dx, float* dgamma, float* dbeta,
+                       float* dw1, float* db1, float* dw2, float* db2, unsigned* bits_scratch,
+                       void* workspace, size_t workspace_bytes, int64_t R, dg_stream_t stream);
 
 /* ---- edge embedding + symmetrisation: src/model/models.py:57-61,92-94 (Generator) and
  * :159-163,197-199 (Discriminator) ---------------------------------------------------
@@ -187,12 +225,14 @@ int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream);
 size_t dg_embed_sym_dgrad_packed_floats(void);
 int dg_embed_sym_pack_dgrad(const float* w2, float* packed, dg_stream_t stream);
 int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1, const float* w2_packed, const float* b2,
-                     float* out, int B, int N, int E, int H, int C, int act, dg_stream_t stream);
+                     void* out, int B, int N, int E, int H, int C, int act, int dtype, dg_stream_t stream);
 int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const float* w2_packed,
-                     const float* w2_dgrad_packed, const float* b2, const float* g,
+                     const float* w2_dgrad_packed, const float* b2, const void* g,
                      float* da, float* dw1, float* db1, float* dw2, float* db2,
                      void* workspace, size_t workspace_bytes,
-                     int B, int N, int E, int H, int C, int act, dg_stream_t stream);
+                     int B, int N, int E, int H, int C, int act, int dtype, dg_stream_t stream);
+/* dtype: storage of `out` / `g` (the [B,N,N,128] edge tensor); the one-hot input `a`, its gradient and
+ * the parameters stay float32.                                                                       */
 
 /* ---- the steps either side of the path -------------------
  * dg_densify: reference src/data/utils.py:128-137 -- PyG to_dense_adj (scatter-ADD
@@ -233,6 +273,8 @@ enum {
     DG_K_LINEAR_WGRAD = 6,
     DG_K_ROW_GEMM = 7,
     DG_K_EMBED_SYM = 8,
+    DG_K_FFN = 9,          /* fused bf16 feed-forward kernels: forward, dx */
+    DG_K_FFN_WGRAD = 10,   /* fused bf16 feed-forward weight-gradient kernels */
     DG_K_COUNT = 16
 };
 int dg_prof_enable(int mask);

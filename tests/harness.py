@@ -69,10 +69,10 @@ def compare_scalar(got, want, rtol, what):
     assert abs(got - want) <= rtol * max(1.0, abs(want)), f"{what}: got {got!r} want {want!r}"
 
 
-def compare_grad_table(case, fixture, tag, group, table, rtol, name_map=None):
-    """Compare {name: tensor|None} against the fixture group (full tensors or
-    summaries).  Tolerance model (hard part 4): per tensor
-    ||got - want|| <= rtol * max(||want||, ||all grads|| / sqrt(n_tensors))."""
+def grad_table_errors(case, fixture, tag, group, table):
+    """Per-tensor relative errors of {name: tensor|None} against the fixture group (full tensors or
+    summaries), sorted worst first.  Error model (hard part 4): per tensor
+    ||got - want|| / max(||want||, ||all grads|| / sqrt(n_tensors))."""
     want_none = set(json.loads(str(fixture[f"{tag}/{group.split('.')[0]}.none_grads"]))) if group.endswith("grad") else set()
     names = list(table.keys())
     got_none = {k for k, v in table.items() if v is None}
@@ -92,7 +92,7 @@ def compare_grad_table(case, fixture, tag, group, table, rtol, name_map=None):
     else:
         total = np.sqrt(sum(float(w[0] ** 2) for w in wants.values()))
     floor = total / np.sqrt(max(1, len(wants)))
-    worst = (0.0, None)
+    errs = []
     for k in wants:
         if full:
             err = np.linalg.norm((gots[k] - wants[k]).reshape(-1))
@@ -102,11 +102,17 @@ def compare_grad_table(case, fixture, tag, group, table, rtol, name_map=None):
             # tensor with n elements have magnitude ~ norm * sqrt(n)/sqrt(3)/sqrt(n) ~ norm
             err = np.abs(gots[k] - wants[k]).max()
             scale = max(wants[k][0], floor)
-        r = err / scale if scale > 0 else err
-        if r > worst[0]:
-            worst = (r, k)
+        errs.append((float(err / scale if scale > 0 else err), k))
+    errs.sort(reverse=True)
+    return errs
+
+
+def compare_grad_table(case, fixture, tag, group, table, rtol, name_map=None):
+    """Assert every tensor of the table within ``rtol`` (see grad_table_errors); returns the worst."""
+    errs = grad_table_errors(case, fixture, tag, group, table)
+    for r, k in errs:
         assert r <= rtol, f"{group}/{k}: rel err {r:.3e} > {rtol:.1e}"
-    return worst
+    return errs[0] if errs else (0.0, None)
 
 
 def compare_step(case, fixture, tag, res, rtol_loss, rtol_grad, rtol_delta=None):

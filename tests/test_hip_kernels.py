@@ -102,13 +102,13 @@ def test_attn_core_rejects_unsupported_shapes():
     lib = _lib().load()
     x = torch.zeros(4, device="cuda")
     st = lib.dg_attn_core_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
-                              1, 200, 128, 0.25, None)
+                              1, 200, 128, 0.25, 0, None)
     assert st == -1 and b"unsupported shape" in lib.dg_last_error_string()
     st = lib.dg_attn_core_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
-                              1, 9, 6, 0.25, None)
+                              1, 9, 6, 0.25, 0, None)
     assert st == -1
     st = lib.dg_attn_core_fwd(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
-                              1, 9, 8, 0.25, None)
+                              1, 9, 8, 0.25, 0, None)
     assert st == -2
 
 

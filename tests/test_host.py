@@ -28,14 +28,14 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dg_version() == 100
+    assert lib.dg_version() == 200
     assert lib.dg_last_error_string() is not None
 
 
 def test_argument_validation_needs_no_gpu():
     from druggen_amd import _lib
     lib = _lib.load()
-    assert lib.dg_attn_core_fwd(None, None, None, None, None, None, 1, 9, 128, 0.25, None) == -2
+    assert lib.dg_attn_core_fwd(None, None, None, None, None, None, 1, 9, 128, 0.25, 0, None) == -2
     assert b"null pointer" in lib.dg_last_error_string()
     assert lib.dg_ln_workspace_bytes(518400, 128) > 0
     assert lib.dg_ln_workspace_bytes(10, 6) == 0           # C % 4 != 0 -> unsupported
