@@ -39,6 +39,14 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 WORKLOAD = dict(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
+# BASELINE.json configs -> (workload overrides, batch per GPU, activation dtype, description)
+CONFIGS = {
+    "c2": (dict(), 256, "f32", "BASELINE configs[1]: DrugGEN default 4-layer/8-head dim128 mlp_ratio3, N=45, E=5, M=13, fp32"),
+    "c3": (dict(), 2048, "bf16", "BASELINE configs[2]: same model, bf16 activations (MFMA QKV/FFN path), batch 2048"),
+    "c4": (dict(), 2048, "f32", "BASELINE configs[3]: DrugGEN default, batch 2048 per GPU (data parallel over the node's GPUs)"),
+    "c5": (dict(vertexes=90, edges=10, depth=8), 64, "f32",
+           "BASELINE configs[4]: deep variant, 8-layer encoder, N=90, E=10, global batch 512 = 64 per GPU on 8 GPUs"),
+}
 
 
 def parse():
@@ -46,21 +54,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configuration (c2 = configs[1] is the headline the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=0, help="molecules per GPU (0 = the configuration's)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
+                    help="storage of the encoder activations (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (single GPU)")
     ap.add_argument("--vertexes", type=int, default=0, help="override N (parity-case shapes; not the headline)")
     ap.add_argument("--depth", type=int, default=0, help="override L")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(32, logical cores)")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's own setting (train.py:16: 5 threads)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int, threads: int = 0):
-    """Oracle GAN step on the host CPU: c2 shape, reduced batch (bounded sample)."""
+def _cpu_gan_step_rate(workload, batch, threads, max_steps=3, budget_s=8.0):
+    """molecules/s of the oracle's GAN step (torch CPU restatement of src/model + train.py:351-384)."""
     from oracle import druggen_oracle as orc
     from druggen_amd import synth
-    cfg = orc.NetConfig(**WORKLOAD)
+    cfg = orc.NetConfig(**workload)
     torch.manual_seed(0)
     G = orc.OracleNet("G", cfg, {k: torch.from_numpy(v) for k, v in
                                  synth.fill_parameters(orc.generator_schema(cfg), 1, 1.0).items()})
@@ -72,17 +84,37 @@ def cpu_baseline(batch: int, threads: int = 0):
     ee, en = synth.interpolation_eps(batch, 1234)
     t = lambda v: torch.from_numpy(v)
     args = (t(da), t(dx), t(a), t(x), 10.0, t(ee), t(en))
-    threads = threads or min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     orc.gan_step(G, D, g_opt, d_opt, *args)          # warm-up
     steps, t0 = 0, time.perf_counter()
-    while steps < 5 and (steps < 1 or time.perf_counter() - t0 < 10.0):
+    while steps < max_steps and (steps < 1 or time.perf_counter() - t0 < budget_s):
         orc.gan_step(G, D, g_opt, d_opt, *args)
         steps += 1
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": batch / dt, "unit": "molecules/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU restatement of src/model) GAN step, configs[1] shape at batch {batch}, "
-                      f"{steps} step(s) after 1 warm-up, {threads} threads of {os.cpu_count()} logical cores"}
+    return batch * steps / (time.perf_counter() - t0), steps
+
+
+def cpu_baseline(workload, batch: int, threads: int = 0):
+    """The CPU path timed beside the GPU number (SURVEY.md section 8d / BASELINE.md section 3): the oracle's GAN
+    step on the host cores with (i) the reference's own thread setting (train.py:16 `torch.set_num_threads(5)`)
+    and (ii) all physical cores, at the bench workload's shape (reduced batch: a bounded sample) and at
+    BASELINE configs[0] (N=9, L=1, B=32, the reference's CPU-runnable case)."""
+    logical = os.cpu_count() or 1
+    physical = max(1, logical // 2)
+    c1 = dict(WORKLOAD, vertexes=9, nodes=5, depth=1)
+    ref_threads = threads or min(5, logical)
+    variants = []
+    for name, wl, b, thr in (("bench workload shape", workload, batch, ref_threads),
+                             ("bench workload shape", workload, batch, min(physical, 64)),
+                             ("BASELINE configs[0] (N=9, L=1)", c1, 32, ref_threads),
+                             ("BASELINE configs[0] (N=9, L=1)", c1, 32, min(physical, 64))):
+        rate, steps = _cpu_gan_step_rate(wl, b, thr)
+        variants.append({"workload": name, "batch": b, "threads": thr, "value": rate, "steps": steps})
+    head = variants[0]
+    return {"value": head["value"], "unit": "molecules/s", "cores": head["threads"], "kind": "port",
+            "sample": f"oracle (torch CPU restatement of src/model) GAN step at the bench workload's shape, batch "
+                      f"{head['batch']}, {head['steps']} step(s) after 1 warm-up, {head['threads']} threads "
+                      f"(the reference's train.py:16 setting) of {logical} logical cores",
+            "variants": variants, "logical_cores": logical}
 
 
 def main():
@@ -105,14 +137,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if args.gpus != world:
+        # the driver's scaling run launches `torchrun --nproc-per-node N bench.py --gpus N`: a mismatch means the
+        # launcher did not start N ranks, and an N=1 measurement must not be recorded as an N-GPU number
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
 
     from druggen_amd import _lib, functional as dgf, synth
     from druggen_amd.model import Discriminator, Generator
     from druggen_amd.trainer import GANStep, GraphedGANStep, broadcast_parameters
 
-    w = dict(WORKLOAD)
+    overrides, cfg_batch, cfg_dtype, cfg_text = CONFIGS[args.config]
+    w = dict(WORKLOAD, **overrides)
+    act_dtype = args.dtype or cfg_dtype
+    dgf.set_activation_dtype(act_dtype)
     if args.vertexes:
         w["vertexes"] = args.vertexes
     if args.depth:
@@ -123,7 +161,7 @@ def main():
     G, D = Generator(*ctor, **kw).to(dev), Discriminator(*ctor, **kw).to(dev)
     broadcast_parameters(G)
     broadcast_parameters(D)
-    B = args.batch
+    B = args.batch or cfg_batch
     a, x, _, _ = synth.molecule_batch(B, w["vertexes"], w["edges"], w["nodes"], seed=1234 + rank)
     da, dx, _, _ = synth.molecule_batch(B, w["vertexes"], w["edges"], w["nodes"], seed=2234 + rank)
     gen_edge, gen_node = torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)
@@ -177,6 +215,14 @@ def main():
         raise SystemExit(f"non-finite losses d={d_loss} g={g_loss}")
 
     if rank == 0:
+        bf16 = act_dtype == "bf16"
+        # MFMA ceiling of the GEMM-shaped kernels by arithmetic: fp32 activations run the 3-way bf16 split
+        # (6 bf16 MFMAs per product: ceiling = bf16 peak / 6); bf16 activations one MFMA per product
+        x6 = os.environ.get("DG_ROW_GEMM") != "mfma32"
+        gemm_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (MFMA_BF16_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS)
+        gemm_how = ("1x v_mfma_f32_*_bf16 per product (bf16 operands, fp32 accumulate)" if bf16 else
+                    ("6x v_mfma_f32_32x32x16_bf16 per product (fp32 operands split 3-way into bf16, fp32 accumulate: "
+                     "fp32-class accuracy)" if x6 else "v_mfma_f32_32x32x2_f32"))
         kernels = {}
         for name in _lib.KERNEL_IDS:
             n, ms = _lib.prof_read(name)
@@ -188,18 +234,11 @@ def main():
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                                  "share_of_step": ms * 1e-3 / detail_elapsed}
                 fl = dgf.traffic_flops(name)
-                if fl:          # GEMM-shaped kernels: fp32-equivalent flop rate next to the byte rate
+                if fl:          # GEMM-shaped kernels: flop rate against the MFMA ceiling of their arithmetic
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                    if name == "row_gemm" and os.environ.get("DG_ROW_GEMM") != "mfma32":
-                        # bf16x6-split MFMA: 6 bf16 MFMAs per fp32 product -> the matrix pipe is no longer
-                        # the roof, the activation stream (HBM) is
-                        kernels[name].update({"bound": "hbm", "achieved_TFLOPs_fp32_equivalent": tf,
-                                              "mfma": "6x v_mfma_f32_32x32x16_bf16 per k16 step (3-way bf16 split, "
-                                                      "fp32 accumulate)",
-                                              "mfma_fp32_equivalent_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS / 6.0})
-                    else:
-                        kernels[name].update({"bound": "mfma", "achieved_TFLOPs": tf,
-                                              "frac_of_mfma_f32_peak": tf / MFMA_F32_PEAK_TFLOPS})
+                    kernels[name].update({"achieved_TFLOPs": tf, "mfma_peak_TFLOPs": gemm_peak,
+                                          "frac_of_mfma_peak": tf / gemm_peak, "mfma": gemm_how})
+                    kernels[name]["bound"] = "hbm" if kernels[name]["frac_of_hbm_peak"] >= tf / gemm_peak else "mfma"
                 else:
                     kernels[name]["bound"] = "hbm"
         (n_f, ms_f), bytes_f = attn_stats["attn_fwd"]
@@ -210,39 +249,61 @@ def main():
                    "avg_us": 1e3 * ms_f / n_f, "algorithmic_MB_per_launch": bytes_f / n_f / 1e6}
         elif "attn_fwd" in kernels:  # --graph: events cannot sit inside a replayed graph
             dom = dict(kernels["attn_fwd"])
-        traffic = None
-        side = os.path.join(ROOT, "profiles", "traffic.json")     # PMC pass (rocprofv3 --pmc), per launch, bytes
+        # HBM bytes per attention-forward launch from a PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their
+        # own runs, scripts/pmc_traffic.py): only reported when that pass was taken on THIS workload and dtype,
+        # together with the commit it was measured at
+        traffic, traffic_src = None, None
+        side = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(side):
             try:
-                traffic = json.load(open(side)).get("attn_fwd_bytes_per_launch")
+                rec = json.load(open(side))
+                if rec.get("config") == args.config and rec.get("dtype") == act_dtype and rec.get("batch") == B:
+                    traffic = rec.get("attn_fwd_bytes_per_launch")
+                    traffic_src = {k: rec.get(k) for k in ("commit", "measured", "method")}
             except Exception:
                 traffic = None
+        # the kernel family that decides the step time (largest share), next to the attention line
+        top = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
+        dominant = None
+        if top:
+            kt = kernels[top]
+            by_mfma = kt.get("bound") == "mfma"
+            dominant = {"kernel": top, "share_of_step": kt["share_of_step"], "bound": kt["bound"],
+                        "achieved": kt["achieved_TFLOPs"] if by_mfma else kt["achieved_GBps"],
+                        "peak": kt["mfma_peak_TFLOPs"] if by_mfma else HBM_PEAK_GBS,
+                        "unit": "TFLOP/s" if by_mfma else "GB/s",
+                        "frac": kt["frac_of_mfma_peak"] if by_mfma else kt["frac_of_hbm_peak"],
+                        "frac_of_hbm_peak": kt["frac_of_hbm_peak"], "frac_of_mfma_peak": kt.get("frac_of_mfma_peak"),
+                        "launches_per_step": kt["launches_per_step"], "avg_us": kt["avg_us"],
+                        "note": "measured in two extra fully instrumented steps after the timed region"}
         out = {
-            "metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs",
+            "metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs" if w["vertexes"] == 45 else
+                      f"molecules/sec GAN step (G+D fwd+bwd), N={w['vertexes']} graphs",
             "value": B * world * args.steps / elapsed,
             "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DrugGEN default 4-layer/8-head dim128 mlp_ratio3, N=45, E=5, "
-                                   "M=13, fp32, full WGAN-GP step (train.py:351-384) incl. gradient penalty + 2x AdamW",
+            "dtype": act_dtype, "data": "synthetic",
+            "config": {"workload": cfg_text + "; full WGAN-GP step (train.py:351-384) incl. gradient penalty + 2x AdamW",
+                       "baseline_config": args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "vertexes": w["vertexes"], "depth": w["depth"], "hip_graph_replay": bool(args.graph and world == 1),
-                       "row_gemm": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if os.environ.get("DG_ROW_GEMM") == "mfma32" else
-                                    "fp32 in/out, operands split 3-way into bf16, 6 MFMA cross products, fp32 accumulate: "
-                                    "error vs fp64 at or below an fp32 GEMM's (tests/test_hip_kernels.py::"
-                                    "test_row_gemm_split_bf16_is_fp32_class_accurate)")},
+                       "vertexes": w["vertexes"], "edges": w["edges"], "depth": w["depth"],
+                       "hip_graph_replay": bool(args.graph and world == 1),
+                       "gemm_arithmetic": gemm_how,
+                       "activations": "bf16 in HBM; fp32 parameters, optimizer state, weight gradients, softmax and "
+                                      "LayerNorm statistics" if bf16 else "fp32"},
             "roofline": {"kernel": "attn_core_fwd", "bound": "hbm", "achieved": dom.get("achieved_GBps"),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic,
+                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic, "traffic_source": traffic_src,
                          "launches_timed": dom.get("launches"), "avg_us": dom.get("avg_us"),
                          "algorithmic_bytes_per_launch": None if not dom else dom.get("algorithmic_MB_per_launch", 0) * 1e6},
+            "roofline_dominant": dominant,
             "kernels": kernels,
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_batch, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
