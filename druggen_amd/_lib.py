@@ -53,6 +53,9 @@ SIGNATURES = {
     "dg_embed_sym_pack": (c_int, [_P, _P, _P]),
     "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 7 + [_P]),
     "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 7 + [_P]),
+    "dg_onehot_embed_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dg_onehot_embed_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dg_onehot_embed_bwd": (c_int, [_P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "dg_densify": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dg_adamw_flat": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "dg_adamw_flat_devstep": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P]),

@@ -357,6 +357,63 @@ __global__ void embed_unpack_kernel(const float* __restrict__ red, float* __rest
     if (i < kHid) db1[i] = red[BwdPart::kB1 + i];
 }
 
+// ---------------------------------------------------------------- one-hot inputs ----
+// For a one-hot input graph (the generator's input and the discriminator's real batch: reference
+// src/data/utils.py:15-23 builds them with label2onehot) the embedding MLP has only E distinct results,
+// T[c] = f(e_c): out[b,i,j,:] = (T[l_ij] + T[l_ji]) / 2 is a table gather (HBM-bound: writes 256-512 B per row,
+// reads 8 B of labels), and its backward a segmented sum dT[c] = sum_rows g_ij ([l_ij = c] + [l_ji = c]) / 2.
+// The table itself (E x 128) is computed -- and differentiated -- by ordinary torch ops on the host side.
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_embed_fwd_kernel(const int* __restrict__ labels, const float* __restrict__ table,
+                                                             T* __restrict__ out, int64_t rows, int N, int E) {
+    __shared__ float4 tab[kMaxE * kC / 4];
+    for (int i = threadIdx.x; i < E * kC / 4; i += 256) tab[i] = ld4(table + i * 4);
+    __syncthreads();
+    const int col = threadIdx.x & 31;
+    const int64_t NN = static_cast<int64_t>(N) * N;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5); r < rows; r += static_cast<int64_t>(gridDim.x) * 8) {
+        const int64_t b = r / NN;
+        const int ij = static_cast<int>(r - b * NN), i = ij / N, j = ij - i * N;
+        int l1 = labels[r], l2 = labels[b * NN + static_cast<int64_t>(j) * N + i];
+        l1 = l1 < 0 ? 0 : (l1 >= E ? E - 1 : l1);      // the caller validated the labels; stay in bounds regardless
+        l2 = l2 < 0 ? 0 : (l2 >= E ? E - 1 : l2);
+        st4_stream(out + r * kC + 4 * col, 0.5f * (tab[l1 * (kC / 4) + col] + tab[l2 * (kC / 4) + col]));
+    }
+}
+
+template <typename T, int EP>
+__global__ __launch_bounds__(256) void onehot_embed_bwd_kernel(const int* __restrict__ labels, const T* __restrict__ g,
+                                                             float* __restrict__ part, int64_t rows, int N, int E) {
+    __shared__ float4 red[8][EP][32];
+    const int col = threadIdx.x & 31, rp = threadIdx.x >> 5;
+    const int64_t NN = static_cast<int64_t>(N) * N;
+    float4 acc[EP];
+#pragma unroll
+    for (int c = 0; c < EP; ++c) acc[c] = f4(0.f);
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * 8 + rp; r < rows; r += static_cast<int64_t>(gridDim.x) * 8) {
+        const int64_t b = r / NN;
+        const int ij = static_cast<int>(r - b * NN), i = ij / N, j = ij - i * N;
+        const int l1 = labels[r], l2 = labels[b * NN + static_cast<int64_t>(j) * N + i];
+        const float4 gv = ld4_stream(g + r * kC + 4 * col);
+#pragma unroll
+        for (int c = 0; c < EP; ++c) {
+            const float wgt = 0.5f * ((l1 == c ? 1.f : 0.f) + (l2 == c ? 1.f : 0.f));
+            acc[c] = fma4(f4(wgt), gv, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < EP; ++c) red[rp][c][col] = acc[c];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < E * 32; idx += 256) {
+        const int c = idx >> 5, cc = idx & 31;
+        float4 t = f4(0.f);
+        for (int p = 0; p < 8; ++p) t += red[p][c][cc];      // fixed order: bit-reproducible
+        st4(part + (static_cast<size_t>(blockIdx.x) * E + c) * kC + 4 * cc, t);
+    }
+}
+
+constexpr int kOneHotBlocks = 1024;
+
 int embed_grid(int total_tiles, int per_cu) {
     const int cap = 256 * per_cu;
     return total_tiles < cap ? (total_tiles < 1 ? 1 : total_tiles) : cap;
@@ -472,4 +529,53 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,
                        E);
     return check_launch("dg_embed_sym_bwd");
+}
+
+extern "C" size_t dg_onehot_embed_workspace_bytes(int E, int C) {
+    return E >= 1 && E <= kMaxE && C == kC ? static_cast<size_t>(kOneHotBlocks) * E * C * sizeof(float) : 0;
+}
+
+extern "C" int dg_onehot_embed_fwd(const int* labels, const float* table, void* out, int B, int N, int E, int C, int dtype,
+                                   dg_stream_t stream_) {
+    if (!labels || !table || !out) return fail(DG_E_ARG, "dg_onehot_embed_fwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_onehot_embed_fwd: unknown dtype %d", dtype);
+    if (B < 0 || N < 1 || E < 1 || E > kMaxE || C != kC)
+        return fail(DG_E_SHAPE, "dg_onehot_embed_fwd: unsupported N=%d E=%d C=%d (need E<=16, C=128)", N, E, C);
+    if (B == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t rows = static_cast<int64_t>(B) * N * N;
+    const int grid = static_cast<int>(rows / 8 + 1 < 4096 ? rows / 8 + 1 : 4096);
+    ProfScope prof(DG_K_EMBED_SYM, stream);
+    if (dtype == DG_DTYPE_BF16)
+        hipLaunchKernelGGL((onehot_embed_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, labels, table,
+                           static_cast<bf16_t*>(out), rows, N, E);
+    else
+        hipLaunchKernelGGL((onehot_embed_fwd_kernel<float>), dim3(grid), dim3(256), 0, stream, labels, table,
+                           static_cast<float*>(out), rows, N, E);
+    return check_launch("dg_onehot_embed_fwd");
+}
+
+extern "C" int dg_onehot_embed_bwd(const int* labels, const void* g, float* dtable, void* workspace, size_t workspace_bytes,
+                                   int B, int N, int E, int C, int dtype, dg_stream_t stream_) {
+    if (!labels || !g || !dtable || !workspace) return fail(DG_E_ARG, "dg_onehot_embed_bwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_onehot_embed_bwd: unknown dtype %d", dtype);
+    if (B < 1 || N < 1 || E < 1 || E > kMaxE || C != kC)
+        return fail(DG_E_SHAPE, "dg_onehot_embed_bwd: unsupported B=%d N=%d E=%d C=%d", B, N, E, C);
+    if (workspace_bytes < dg_onehot_embed_workspace_bytes(E, C)) return fail(DG_E_WORKSPACE, "dg_onehot_embed_bwd: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t rows = static_cast<int64_t>(B) * N * N;
+    const int grid = static_cast<int>(rows / 8 + 1 < kOneHotBlocks ? rows / 8 + 1 : kOneHotBlocks);
+    float* part = static_cast<float*>(workspace);
+    ProfScope prof(DG_K_EMBED_SYM, stream);
+#define BWD(T, EP_)                                                                                         \
+    hipLaunchKernelGGL((onehot_embed_bwd_kernel<T, EP_>), dim3(grid), dim3(256), 0, stream, labels,          \
+                       static_cast<const T*>(g), part, rows, N, E);
+    if (dtype == DG_DTYPE_BF16) {
+        if (E <= 8) { BWD(bf16_t, 8) } else { BWD(bf16_t, 16) }
+    } else {
+        if (E <= 8) { BWD(float, 8) } else { BWD(float, 16) }
+    }
+#undef BWD
+    hipLaunchKernelGGL(embed_reduce_kernel, dim3((E * C + 255) / 256), dim3(256), 0, stream, part, grid, E * C, dtable);
+    return check_launch("dg_onehot_embed_bwd");
 }

@@ -20,7 +20,7 @@ from . import _lib
 
 __all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops",
-           "set_activation_dtype", "activation_dtype", "activations"]
+           "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -1186,3 +1186,75 @@ def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
     if not ok or in_second_order_forward():
         return _composite_embed_sym(a, w1, b1, w2, b2, act).to(out_dtype)
     return _EmbedSym.apply(a, w1, b1, w2, b2, act, out_dtype)
+
+
+# --------------------------------------------------------------------------
+# one-hot input graphs: the embedding MLP collapses to an E-row table
+# (reference src/data/utils.py:15-23 + models.py:57-61,92-94)
+# --------------------------------------------------------------------------
+def as_one_hot(a, labels=None):
+    """Declare (after checking it) that the edge tensor ``a`` [B,N,N,E] is one-hot over its last dim -- true for
+    every adjacency the reference's ``load_molecules`` / ``label2onehot`` produces (generator input, the
+    discriminator's real batch), false for generated / interpolated tensors.  The int32 labels are attached to the
+    tensor object; Generator / Discriminator then evaluate the edge-embedding MLP on the E distinct rows only
+    (``dg_onehot_embed_fwd/bwd``).  The check costs one device->host read per NEW tensor object (the result is
+    cached on it), so a resident batch is checked once.  Returns ``a``."""
+    if getattr(a, "_dg_labels", None) is not None or not (torch.is_tensor(a) and a.is_cuda and a.dim() == 4):
+        return a
+    if a.requires_grad or a.dtype != torch.float32:
+        a._dg_labels = False
+        return a
+    with torch.no_grad():
+        if labels is None:
+            labels = a.argmax(-1).to(torch.int32)
+        ok = ((a.amax(-1) == 1) & (a.sum(-1) == 1) & (a.amin(-1) == 0)).all() if a.shape[-1] > 1 else (a == 1).all()
+    a._dg_labels = labels.contiguous() if bool(ok) else False     # the only host sync: once per tensor object
+    return a
+
+
+def one_hot_labels(a):
+    """The int32 labels attached by ``as_one_hot`` (None for tensors that are not declared one-hot)."""
+    lab = getattr(a, "_dg_labels", None)
+    return lab if torch.is_tensor(lab) else None
+
+
+class _OneHotEmbed(Function):
+    @staticmethod
+    def forward(ctx, labels, table, out_dtype):
+        B, N = labels.shape[0], labels.shape[1]
+        E, C = table.shape
+        lib = _lib.load()
+        table = _c(table)
+        out = torch.empty(B, N, N, C, dtype=out_dtype, device=labels.device)
+        with _dev(labels):
+            _lib.check(lib.dg_onehot_embed_fwd(labels.data_ptr(), _lib.fptr(table), _lib.ptr(out), B, N, E, C, _lib.dt(out),
+                                               _lib.stream_of(out)), "dg_onehot_embed_fwd")
+        _account("embed_sym", B * N * N * (8 + out.element_size() * C))
+        ctx.save_for_backward(labels)
+        ctx.shape = (E, C, out_dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (labels,) = ctx.saved_tensors
+        E, C, out_dtype = ctx.shape
+        B, N = labels.shape[0], labels.shape[1]
+        lib = _lib.load()
+        g = _c(g if g.dtype == out_dtype else g.to(out_dtype))
+        dtable = torch.empty(E, C, dtype=torch.float32, device=g.device)
+        need = int(lib.dg_onehot_embed_workspace_bytes(E, C))
+        with _dev(g):
+            ws = _scratch(g, need, "onehot")
+            _lib.check(lib.dg_onehot_embed_bwd(labels.data_ptr(), _lib.ptr(g), _lib.ptr(dtable), ws.data_ptr(), ws.numel(),
+                                               B, N, E, C, _lib.dt(g), _lib.stream_of(g)), "dg_onehot_embed_bwd")
+        _account("embed_sym", B * N * N * (8 + g.element_size() * C))
+        return None, dtable, None
+
+
+def embed_sym_onehot(labels, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
+    """``embed_sym`` for a one-hot input given by its labels [B,N,N]: the MLP runs on the E unit vectors (plain torch
+    ops on [E,64] / [E,128] tensors, differentiated by autograd), the [B,N,N,dim] result is a symmetrised gather."""
+    f = _ACT_FNS[act]
+    table = f(torch.nn.functional.linear(f(w1.t() + b1), w2, b2))      # [E, dim]: row c = f(one_hot(c))
+    return _OneHotEmbed.apply(labels, table, out_dtype)

@@ -47,7 +47,11 @@ def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, 
         # D(real) and D(fake) as one pass over the concatenated batch: every molecule is processed
         # independently (no cross-sample op in D), so the logits are the reference's; half the launches,
         # and each weight gradient is accumulated once instead of twice.
-        logits = discriminator(torch.cat([drug_adj, edge_sample]), torch.cat([drug_annot, node_sample]))
+        if isinstance(discriminator, torch.nn.DataParallel):      # scatter() would split the two halves differently
+            edges = torch.cat([drug_adj, edge_sample])
+        else:       # the halves stay separate tensors up to the edge embedding: a one-hot real batch takes the table path
+            edges = (drug_adj, edge_sample)
+        logits = discriminator(edges, torch.cat([drug_annot, node_sample]))
         n_real = drug_adj.shape[0]
         prediction_real = -torch.mean(logits[:n_real])
         prediction_fake = torch.mean(logits[n_real:])

@@ -40,21 +40,33 @@ class _Trunk(nn.Module):
         h = self._act(dgf.linear(h, seq[2].weight, seq[2].bias))
         return seq[4](h)
 
+    def _embed_edges(self, z_e, adt):
+        """Linear(E,64) - act - Linear(64,dim) - act - symmetrise (models.py:57-61,92-94)."""
+        el = self.edge_layers
+        if self._act_name is None or (self.training and self.dropout > 0.0):
+            edge = self._embed(el, z_e)
+            return ((edge + edge.permute(0, 2, 1, 3)) / 2).to(adt)
+        labels = dgf.one_hot_labels(z_e)
+        if (labels is not None and not z_e.requires_grad and not dgf.in_second_order_forward()
+                and el[2].weight.shape[0] == 128 and z_e.shape[-1] <= 16):
+            # one-hot graph (dataset batch): E distinct embeddings -> table gather (dg_onehot_embed_fwd)
+            return dgf.embed_sym_onehot(labels, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
+        # one kernel per direction (dg_embed_sym_fwd / _bwd)
+        return dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
+
     def _encode(self, z_e, z_n, need_edge):
-        if not z_e.is_cuda:
+        """``z_e`` may be a tuple of edge tensors that together form the batch (e.g. a one-hot real batch and a
+        dense generated one): each part takes its own embedding path, the encoder sees one batch."""
+        parts = tuple(z_e) if isinstance(z_e, (tuple, list)) else (z_e,)
+        if not parts[0].is_cuda:
             raise RuntimeError("druggen_amd modules run on MI355X only (no CPU fallback): move the model and "
                                "its inputs to a GPU device")
         adt = dgf.activation_dtype()      # storage of the encoder activations (float32, or bfloat16: configs[2])
         node = self._embed(self.node_layers, z_n)
         if node.dtype != adt:
             node = node.to(adt)
-        el = self.edge_layers
-        if self._act_name is not None and not (self.training and self.dropout > 0.0):
-            # Linear(E,64) - act - Linear(64,dim) - act - symmetrise: one kernel (dg_embed_sym_fwd)
-            edge = dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
-        else:
-            edge = self._embed(el, z_e)
-            edge = ((edge + edge.permute(0, 2, 1, 3)) / 2).to(adt)
+        edges = [self._embed_edges(p, adt) for p in parts]
+        edge = edges[0] if len(edges) == 1 else torch.cat(edges)
         return self.TransformerEncoder(node, edge, need_edge)
 
 

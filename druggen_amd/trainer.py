@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .model.loss import discriminator_loss, generator_loss
-from .functional import bump_weights_epoch
+from .functional import as_one_hot, bump_weights_epoch
 from .optim import FlatAdamW
 
 __all__ = ["GANStep", "GraphedGANStep", "GradBucket", "broadcast_parameters"]
@@ -146,6 +146,9 @@ class GANStep:
         """One iteration on this rank's shard.  Returns (d_loss, g_loss) as
         0-dim device tensors (local-shard values; no host sync)."""
         B, dev = gen_node.shape[0], gen_node.device
+        # dataset graphs are one-hot (reference utils.py:15-23): checked once per tensor object, then the edge
+        # embedding of these two batches is a table gather instead of an MLP over B N^2 rows
+        gen_edge, disc_edge = as_one_hot(gen_edge), as_one_hot(disc_edge)
         self.reset_grad()
         kw = {} if eps is None else {"eps": eps}
         shared = None

@@ -234,6 +234,17 @@ int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const flo
 /* dtype: storage of `out` / `g` (the [B,N,N,128] edge tensor); the one-hot input `a`, its gradient and
  * the parameters stay float32.                                                                       */
 
+/* One-hot fast path of the same op (reference src/data/utils.py:15-23 makes the generator's input and the
+ * discriminator's real batch one-hot): with labels l [B,N,N] (int32, 0 <= l < E) and the E x C table
+ * T[c] = f(e_c) (computed and differentiated by the caller: E rows of an MLP),
+ *   fwd: out[b,i,j,:] = (T[l_ij] + T[l_ji]) / 2          bwd: dT[c,:] = sum_rows g_ij ([l_ij = c] + [l_ji = c]) / 2
+ * HBM-bound gather / segmented sum instead of R = B N^2 MLP evaluations.  C = 128, E <= 16.          */
+size_t dg_onehot_embed_workspace_bytes(int E, int C);
+int dg_onehot_embed_fwd(const int* labels, const float* table, void* out, int B, int N, int E, int C, int dtype,
+                        dg_stream_t stream);
+int dg_onehot_embed_bwd(const int* labels, const void* g, float* dtable, void* workspace, size_t workspace_bytes,
+                        int B, int N, int E, int C, int dtype, dg_stream_t stream);
+
 /* ---- the steps either side of the path -------------------
  * dg_densify: reference src/data/utils.py:128-137 -- PyG to_dense_adj (scatter-ADD
  * of edge_attr at [b = u/N, u%N, v%N]; every graph is padded to N nodes) followed by

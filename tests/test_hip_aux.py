@@ -211,3 +211,34 @@ def test_smiles_to_device_batch_end_to_end():
         assert torch.equal(a_t.cpu(), torch.from_numpy(want_a))
         assert torch.equal(x_t.cpu(), torch.from_numpy(want_x))
         assert real.shape == (4, 45 * 9 + 45 * 45 * 5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,act", [(3, 45, 5, "relu"), (2, 9, 5, "tanh"), (1, 90, 10, "leaky")])
+def test_onehot_embedding_matches_the_dense_kernel(B, N, E, act, dtype):
+    """dg_onehot_embed_fwd/bwd (table gather / segmented sum for one-hot graphs, reference utils.py:15-23 +
+    models.py:57-61,92-94) == dg_embed_sym_fwd/bwd on the same one-hot input: output, exact i<->j symmetry and all
+    four parameter gradients.  A tensor that is not one-hot is not declared one-hot."""
+    from druggen_amd import functional as dgf, synth
+    a, _, bonds, _ = synth.molecule_batch(B, N, E, 7, seed=B * 100 + N)
+    a = torch.from_numpy(a).cuda()
+    g = torch.Generator().manual_seed(1)
+    ps = [(torch.randn(64, E, generator=g) * 0.4).cuda().requires_grad_(True), (torch.randn(64, generator=g) * 0.1).cuda().requires_grad_(True),
+          (torch.randn(128, 64, generator=g) * 0.2).cuda().requires_grad_(True), (torch.randn(128, generator=g) * 0.1).cuda().requires_grad_(True)]
+    assert dgf.one_hot_labels(a) is None
+    dgf.as_one_hot(a)
+    labels = dgf.one_hot_labels(a)
+    assert labels is not None and torch.equal(labels.cpu(), torch.from_numpy(bonds).to(torch.int32))
+    dense = dgf.embed_sym(a, *ps, act, dtype)
+    fast = dgf.embed_sym_onehot(labels, *ps, act, dtype)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert fast.dtype == dtype
+    assert float((fast.double() - dense.double()).norm() / dense.double().norm()) < tol
+    assert torch.equal(fast, fast.permute(0, 2, 1, 3))
+    up = torch.randn(B, N, N, 128, generator=g).to(dtype).cuda()
+    gd = torch.autograd.grad(dense, ps, up)
+    gf = torch.autograd.grad(fast, ps, up)
+    for x, y in zip(gf, gd):
+        assert float((x.double() - y.double()).norm() / y.double().norm()) < (2e-5 if dtype == torch.float32 else 1e-3)
+    soft = torch.softmax(torch.randn(B, N, N, E, generator=g), -1).cuda()
+    assert dgf.one_hot_labels(dgf.as_one_hot(soft)) is None
