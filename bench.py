@@ -301,6 +301,8 @@ def main():
             "roofline_dominant": dominant,
             "kernels": kernels,
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
+            "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_batch, args.cpu_threads)

@@ -25,6 +25,8 @@
 //   * narrow models (C < 32) use fewer quads per slice (LQS) and more phases.
 #include "bf16.h"
 
+#include <type_traits>
+
 namespace dg {
 namespace {
 
@@ -74,14 +76,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
         kk[t] = ld4(k + b * NC + L.off[t]);
         vv[t] = ld4(v + b * NC + L.off[t]);
     }
+    constexpr bool PF = false;   // a one-row-ahead prefetch measured slower here (4 waves per SIMD already overlap rows)
+    typedef typename raw4<T>::type Raw;
+    Raw re[JPL], rq;
+    auto request = [&](int i) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        rq = ld_raw(q + row * C + L.c0);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) re[t] = ld_raw_stream(e + row * NC + L.off[t]);
+    };
+    if (PF && rg < N) request(rg);
     for (int i = rg; i < N; i += RG) {
         const size_t row = static_cast<size_t>(b) * N + i;
-        const float4 aq = alpha * ld4(q + row * C + L.c0);
-        const T* er = e + row * NC;
+        if (!PF) request(i);
+        const float4 aq = alpha * cvt_raw(rq);
         T* sr = s + row * NC;
         float4 sv[JPL];
 #pragma unroll
-        for (int t = 0; t < JPL; ++t) sv[t] = ld4_stream(er + L.off[t]);
+        for (int t = 0; t < JPL; ++t) sv[t] = cvt_raw(re[t]);
+        if (PF && i + RG < N) request(i + RG);
         float4 m = f4(kNegBig);
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
 
 // --------------------------------------------------------------- backward ----
 template <typename T, int LQS, int JPL, int RW>
-__global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
+__global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
     const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
     T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, T* __restrict__ de, int N, int C,
@@ -135,21 +148,38 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_kernel(
     float4 dkk[JPL], dvv[JPL];
 #pragma unroll
     for (int t = 0; t < JPL; ++t) dkk[t] = dvv[t] = f4(0.f);
+    // bf16: the kernel is bound by per-row latency (2 waves per SIMD at this register count), not by bytes: the
+    // operands of row i + RW are requested -- still packed, 2 registers per slot -- before the arithmetic of row i.
+    // fp32 rows cost 4 registers per slot: no room for the second set, and that variant sits at the HBM roof already.
+    constexpr bool PF = !std::is_same<T, float>::value;
+    typedef typename raw4<T>::type Raw;
+    Raw re[JPL], rws[JPL], rq, rwo;
+    auto request = [&](int i) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        rq = ld_raw(q + row * C + L.c0);
+        rwo = ld_raw(wo + row * C + L.c0);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            re[t] = ld_raw_stream(e + row * NC + L.off[t]);
+            if (ws) rws[t] = ld_raw_stream(ws + row * NC + L.off[t]);
+        }
+    };
+    if (PF && rw < N) request(rw);
     for (int i = rw; i < N; i += RW) {
         const size_t row = static_cast<size_t>(b) * N + i;
         int kl = lane;                       // opaque per row: keeps the LDS operand reads inside the
         asm volatile("" : "+v"(kl));         // loop instead of hoisting 2*JPL float4 into registers
-        const float4 aq = alpha * ld4(q + row * C + L.c0);
-        const float4 woi = ld4(wo + row * C + L.c0);
-        const T* er = e + row * NC;
-        const T* wr = ws + row * NC;
+        if (!PF) request(i);
+        const float4 aq = alpha * cvt_raw(rq);
+        const float4 woi = cvt_raw(rwo);
         T* der = de + row * NC;
         float4 ee[JPL], wss[JPL], pe[JPL];
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
-            ee[t] = ld4_stream(er + L.off[t]);
-            wss[t] = ws ? ld4_stream(wr + L.off[t]) : f4(0.f);
+            ee[t] = cvt_raw(re[t]);
+            wss[t] = ws ? cvt_raw(rws[t]) : f4(0.f);
         }
+        if (PF && i + RW < N) request(i + RW);
         float4 m = f4(kNegBig);
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
@@ -252,25 +282,40 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
 #pragma unroll
     for (int t = 0; t < JPL; ++t) gkk[t] = gvv[t] = f4(0.f);
 
+    constexpr bool PF = !std::is_same<T, float>::value;   // bf16: request row i + RW (packed) before the math of row i
+    typedef typename raw4<T>::type Raw;
+    Raw re[JPL], rws[JPL], rte[JPL], rq, rwo, rtq;
+    auto request = [&](int i) {
+        const size_t row = static_cast<size_t>(b) * N + i;
+        rq = ld_raw(q + row * C + L.c0);
+        rwo = ld_raw(wo + row * C + L.c0);
+        rtq = ld_raw(tq + row * C + L.c0);
+#pragma unroll
+        for (int t = 0; t < JPL; ++t) {
+            const unsigned off = L.off[t];
+            re[t] = ld_raw_stream(e + row * NC + off);
+            if (ws) rws[t] = ld_raw_stream(ws + row * NC + off);
+            rte[t] = ld_raw_stream(te + row * NC + off);
+        }
+    };
+    if (PF && rw < N) request(rw);
     for (int i = rw; i < N; i += RW) {
         const size_t row = static_cast<size_t>(b) * N + i;
         int kl = lane;
         asm volatile("" : "+v"(kl));
-        const float4 qi = ld4(q + row * C + L.c0);
+        if (!PF) request(i);
+        const float4 qi = cvt_raw(rq);
         const float4 aq = alpha * qi;
-        const float4 woi = ld4(wo + row * C + L.c0);
-        const float4 tqi = ld4(tq + row * C + L.c0);
-        const T* er = e + row * NC;
-        const T* wr = ws + row * NC;
-        const T* tr = te + row * NC;
+        const float4 woi = cvt_raw(rwo);
+        const float4 tqi = cvt_raw(rtq);
         float4 ee[JPL], wss[JPL], tee[JPL], pe[JPL], sd[JPL];
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
-            const unsigned off = L.off[t];
-            ee[t] = ld4_stream(er + off);
-            wss[t] = ws ? ld4_stream(wr + off) : f4(0.f);
-            tee[t] = ld4_stream(tr + off);
+            ee[t] = cvt_raw(re[t]);
+            wss[t] = ws ? cvt_raw(rws[t]) : f4(0.f);
+            tee[t] = cvt_raw(rte[t]);
         }
+        if (PF && i + RW < N) request(i + RW);
         float4 m = f4(kNegBig);
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {

@@ -46,6 +46,18 @@ __device__ __forceinline__ float4 ld4_stream(const bf16_t* p) {
 __device__ __forceinline__ void st4_stream(bf16_t* p, float4 v) {
     __builtin_nontemporal_store(pack4_bf16(v), reinterpret_cast<u32x2_t*>(p));
 }
+// raw (unconverted) four-channel loads: a bf16 row slot costs 2 registers until it is unpacked, which makes a
+// one-row-ahead register prefetch affordable in the bf16 kernels
+template <typename T> struct raw4;
+template <> struct raw4<float> { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef u32x2_t type; };
+__device__ __forceinline__ float4 ld_raw_stream(const float* p) { return ld4_stream(p); }
+__device__ __forceinline__ u32x2_t ld_raw_stream(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p)); }
+__device__ __forceinline__ float4 ld_raw(const float* p) { return ld4(p); }
+__device__ __forceinline__ u32x2_t ld_raw(const bf16_t* p) { return *reinterpret_cast<const u32x2_t*>(p); }
+__device__ __forceinline__ float4 cvt_raw(float4 v) { return v; }
+__device__ __forceinline__ float4 cvt_raw(u32x2_t v) { return unpack4_bf16(v); }
+
 // one channel
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return static_cast<float>(*p); }

@@ -93,17 +93,39 @@ __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(
 // loads have returned (0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched on gfx9 encodings).
 __device__ __forceinline__ void wait_all_vmem_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-// butterfly over the lanes that differ in bits >= LOW of the lane id
+// butterfly over the lanes that differ in bits >= LOW of the lane id.  The steps over lane bits 3, 4 and 5 stay in
+// the VALU: xor 8 is a DPP row rotation by 8, xor 16 / xor 32 are v_permlane16_swap / v_permlane32_swap of the
+// value with itself (gfx950) -- after the swap one result register holds "my half", the other "the partner half" in
+// every lane, so the combine needs no select.  A __shfl_xor is a ds_bpermute round trip through the LDS crossbar
+// per step; three dependent ones per reduction dominated the per-row latency of the attention kernels.
+template <bool MAX>
+__device__ __forceinline__ float xor_step(float x, int m) {
+    float y;
+    if (m == 8) {
+        y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+    } else if (m == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]);
+        y = __uint_as_float(r[1]);
+    } else if (m == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]);
+        y = __uint_as_float(r[1]);
+    } else {
+        y = __shfl_xor(x, m, 64);
+    }
+    return MAX ? fmaxf(x, y) : x + y;
+}
 template <int LOW>
 __device__ __forceinline__ float xor_sum(float x) {
 #pragma unroll
-    for (int m = LOW; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
+    for (int m = LOW; m < 64; m <<= 1) x = xor_step<false>(x, m);
     return x;
 }
 template <int LOW>
 __device__ __forceinline__ float xor_max(float x) {
 #pragma unroll
-    for (int m = LOW; m < 64; m <<= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    for (int m = LOW; m < 64; m <<= 1) x = xor_step<true>(x, m);
     return x;
 }
 template <int LOW>

@@ -38,7 +38,7 @@ constexpr int kC = 128, kH = 384;
 constexpr int kSec = 24 * 4 * 64;                 // bf16x8 entries per packed section (96 KB)
 // sections of the FFN pack
 constexpr int kP16W1 = 0;                         // P16 of W1   [384][128]  (fc1 forward; h recompute)
-constexpr int kP32W2 = kSec;                      // P32 of W2   [128][384]  (fc2 forward)
+constexpr int kP16W2 = kSec;                      // P16 of W2   [128][384]  (fc2 forward)
 constexpr int kP16W2T = 2 * kSec;                 // P16 of W2^T [384][128]  (dh = dz W2)
 constexpr int kP16W1T = 3 * kSec;                 // P16 of W1^T [128][384]  (dx = dh W1)
 constexpr int kXBytes = kRowsPerTile * kC * 2;    // 16 KB
@@ -61,75 +61,88 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 //                    hidden channels 48 w + 16 i + 4 (lane >> 4) + reg
 //   SWAPPED = false: tile rows are the A operand; lane = hidden channel 48 w + 16 i + (lane & 15),
 //                    rows 16 rb + 4 (lane >> 4) + reg
-template <bool SWAPPED>
-__device__ __forceinline__ void gemm_up_block(const char* tile, int rb, const bf16x8 (&wf)[3][4], f32x4 (&acc)[3], int lane) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[4];
+__device__ __forceinline__ void up_frags(const char* tile, int rb, bf16x8 (&xf)[4], int lane) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         xf[ks] = *reinterpret_cast<const bf16x8*>(tile + tile_off(16 * rb + (lane & 15), 32 * ks + 8 * (lane >> 4), kC));
+}
+template <bool SWAPPED>
+__device__ __forceinline__ void up_mfma(const bf16x8 (&xf)[4], const bf16x8 (&wf)[3][4], f32x4 (&acc)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[i] = SWAPPED ? mfma16(wf[i][ks], xf[ks], acc[i]) : mfma16(xf[ks], wf[i][ks], acc[i]);
 }
-// 64 x 384 tile -> 384 -> 128 product (swapped): wave (c, g): channels 32 c + ..., row 32 g + (lane & 31).
-// Two accumulator chains (even / odd k-steps); fragment reads are fenced in groups of four k-steps so that
-// at most eight 16-byte fragments are in flight (24 hoisted reads would spill).
-__device__ __forceinline__ void gemm_down_swapped(const char* tile, const bf16x8 (&wf)[24], f32x16& acc, int g, int lane) {
-    f32x16 acc_b;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = acc_b[i] = 0.f;
-    const char* rowp = tile + (32 * g + (lane & 31)) * (kH * 2);
-    const int rsw = lane & 15, kh = lane >> 5;
-#pragma unroll
-    for (int k4 = 0; k4 < 6; ++k4) {
-        bf16x8 hf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int chunk = 2 * (4 * k4 + j) + kh;
-            hf[j] = *reinterpret_cast<const bf16x8*>(rowp + (((chunk & ~15) | ((chunk & 15) ^ rsw)) << 4));
+// The 128 -> 384 product of a 64-row tile as two rolled iterations over PAIRS of 16-row blocks: the fragments of
+// the next block are requested before the MFMAs of the current one (two fragment sets, three accumulators live),
+// `epi(rb, acc)` consumes a block's result.  The fences pin "request next, multiply current, finish current".
+template <bool SWAPPED, bool PREFETCH, typename Epi>
+__device__ __forceinline__ void gemm_up_tile(const char* tile, const bf16x8 (&wf)[3][4], int lane, Epi&& epi) {
+    if constexpr (PREFETCH) {
+        bf16x8 fa[4], fb[4];
+        up_frags(tile, 0, fa, lane);
+#pragma unroll 1
+        for (int rb = 0; rb < 4; rb += 2) {
+            f32x4 acc[3];
+            up_frags(tile, rb + 1, fb, lane);
+            up_mfma<SWAPPED>(fa, wf, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            epi(rb, acc);
+            if (rb + 2 < 4) up_frags(tile, rb + 2, fa, lane);
+            up_mfma<SWAPPED>(fb, wf, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            epi(rb + 1, acc);
         }
-        acc = mfma32(wf[4 * k4 + 0], hf[0], acc);
-        acc_b = mfma32(wf[4 * k4 + 1], hf[1], acc_b);
-        acc = mfma32(wf[4 * k4 + 2], hf[2], acc);
-        acc_b = mfma32(wf[4 * k4 + 3], hf[3], acc_b);
-        __builtin_amdgcn_sched_barrier(0);
+    } else {      // kernels at the register limit: one fragment set, the two waves of a SIMD overlap each other
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            bf16x8 fa[4];
+            f32x4 acc[3];
+            up_frags(tile, rb, fa, lane);
+            up_mfma<SWAPPED>(fa, wf, acc);
+            epi(rb, acc);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc_b[i];
 }
-__device__ __forceinline__ void acc_to_exchange(char* xch, const f32x16& acc, int c, int g, int lane) {
-    const int row = 32 * g + (lane & 31);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(xch + xch_off(row, 32 * c + 8 * q + 4 * (lane >> 5), kC)) =
-            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-}
-
 // 64 x 384 tile -> 384 -> 128 product on 16x16x32 tiles (swapped), one 16-row block per call: wave w owns
 // output channels [16 w, 16 w + 16) -- 48 registers of weight fragments, nothing duplicated across waves
 // (the 32x32x16 form above needs 96).  Result: lane = row 16 rb + (lane & 15), channels 16 w + 4 (lane >> 4) + reg.
+__device__ __forceinline__ void down16_frags(const char* rowp, int rsw, int kq, int k4, bf16x8 (&hf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int chunk = 4 * (4 * k4 + j) + kq;
+        hf[j] = *reinterpret_cast<const bf16x8*>(rowp + (((chunk & ~15) | ((chunk & 15) ^ rsw)) << 4));
+    }
+}
 __device__ __forceinline__ f32x4 gemm_down_block16(const char* tile, int rb, const bf16x8 (&wf)[12], int lane) {
     f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     const int row = 16 * rb + (lane & 15);
     const char* rowp = tile + row * (kH * 2);
     const int rsw = row & 15, kq = lane >> 4;
+    bf16x8 h0[4], h1[4];     // two groups of four k-steps in flight (32 registers, transient)
+    down16_frags(rowp, rsw, kq, 0, h0);
+    down16_frags(rowp, rsw, kq, 1, h1);
 #pragma unroll
-    for (int k4 = 0; k4 < 3; ++k4) {
-        bf16x8 hf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int chunk = 4 * (4 * k4 + j) + kq;
-            hf[j] = *reinterpret_cast<const bf16x8*>(rowp + (((chunk & ~15) | ((chunk & 15) ^ rsw)) << 4));
-        }
-        acc_a = mfma16(wf[4 * k4 + 0], hf[0], acc_a);
-        acc_b = mfma16(wf[4 * k4 + 1], hf[1], acc_b);
-        acc_a = mfma16(wf[4 * k4 + 2], hf[2], acc_a);
-        acc_b = mfma16(wf[4 * k4 + 3], hf[3], acc_b);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; j += 2) {
+        acc_a = mfma16(wf[j], h0[j], acc_a);
+        acc_b = mfma16(wf[j + 1], h0[j + 1], acc_b);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    down16_frags(rowp, rsw, kq, 2, h0);
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        acc_a = mfma16(wf[4 + j], h1[j], acc_a);
+        acc_b = mfma16(wf[4 + j + 1], h1[j + 1], acc_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        acc_a = mfma16(wf[8 + j], h0[j], acc_a);
+        acc_b = mfma16(wf[8 + j + 1], h0[j + 1], acc_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     return acc_a + acc_b;
 }
 
@@ -146,16 +159,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
     char* xch = htile + kHBytes;             // [64][128] fp32
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = w & 3, g = w >> 2, half = lane >> 5, col = lane & 31;
+    const int half = lane >> 5, col = lane & 31;
     const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
 
-    bf16x8 wf1[3][4], wf2[24];
+    bf16x8 wf1[3][4], wf2[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf1[i][ks] = pk[kP16W1 + ((3 * w + i) * 4 + ks) * 64 + lane];
 #pragma unroll
-    for (int ks = 0; ks < 24; ++ks) wf2[ks] = pk[kP32W2 + (c * 24 + ks) * 64 + lane];
+    for (int ks = 0; ks < 12; ++ks) wf2[ks] = pk[kP16W2 + (w * 12 + ks) * 64 + lane];
     float4 b1v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) b1v[i] = ld4(b1 + 48 * w + 16 * i + 4 * (lane >> 4));
@@ -164,20 +177,20 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
 
     int64_t tix = blockIdx.x;
     if (tix < tiles) dma_tile_bf16<kC, 8>(x, tix * kRowsPerTile, R, xbuf, w, lane);
+    wait_all_vmem();
     int buf = 0;
     for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
         const int64_t r0 = tix * kRowsPerTile;
-        wait_all_vmem();
+        // Every wave waited for its share of this tile's DMA BEFORE it issued the previous tile's stores (below), so
+        // a barrier is all that is needed here: the stores drain during this tile's MFMA phases instead of stalling
+        // every tile on their acknowledgement (vmcnt counts stores too).
         __syncthreads();
         if (tix + gridDim.x < tiles)
             dma_tile_bf16<kC, 8>(x, (tix + gridDim.x) * kRowsPerTile, R, xbuf + (buf ^ 1) * kXBytes, w, lane);
         const char* xt = xbuf + buf * kXBytes;
         // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element
         unsigned long long bits = 0ull;
-#pragma unroll 1
-        for (int nb = 0; nb < 4; ++nb) {
-            f32x4 acc1[3];
-            gemm_up_block<true>(xt, nb, wf1, acc1, lane);
+        gemm_up_tile<true, true>(xt, wf1, lane, [&](int nb, const f32x4 (&acc1)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 float4 v = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]) + b1v[i];
@@ -187,17 +200,21 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
                 *reinterpret_cast<u32x2_t*>(htile + tile_off(16 * nb + (lane & 15), 48 * w + 16 * i + 4 * (lane >> 4), kH)) =
                     pack4_bf16(v);
             }
-        }
+        });
         if (relu_bits) {
             const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
             relu_bits[bix] = static_cast<unsigned>(bits);
             relu_bits[bix + 1] = static_cast<unsigned>(bits >> 32);
         }
         __syncthreads();
-        // ---- fc2 -> exchange tile
-        f32x16 acc2;
-        gemm_down_swapped(htile, wf2, acc2, g, lane);
-        acc_to_exchange(xch, acc2, c, g, lane);
+        // ---- fc2 -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows)
+#pragma unroll 1
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4 a4 = gemm_down_block16(htile, nb, wf2, lane);
+            *reinterpret_cast<float4*>(xch + xch_off(16 * nb + (lane & 15), 16 * w + 4 * (lane >> 4), kC)) =
+                make_float4(a4[0], a4[1], a4[2], a4[3]);
+        }
+        wait_all_vmem();       // the next tile's DMA (issued a whole MFMA phase ago) and this wave's older stores
         __syncthreads();
         // ---- + b2 + x, LayerNorm, whole-row stores
 #pragma unroll
@@ -298,10 +315,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
         if (!dx) continue;     // block-uniform
         __syncthreads();
         // ---- dh = (dz W2) * mask -> DH tile
-#pragma unroll 1
-        for (int nb = 0; nb < 4; ++nb) {
-            f32x4 acc[3];
-            gemm_up_block<true>(dzt, nb, wfa, acc, lane);
+        gemm_up_tile<true, false>(dzt, wfa, lane, [&](int nb, const f32x4 (&acc)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const unsigned mb = static_cast<unsigned>(bits >> (nb * 12 + i * 4));
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
                 *reinterpret_cast<u32x2_t*>(dht + tile_off(16 * nb + (lane & 15), 48 * w + 16 * i + 4 * (lane >> 4), kH)) =
                     pack4_bf16(v);
             }
-        }
+        });
         __syncthreads();
         // ---- dx = dz + dh W1
 #pragma unroll 1
@@ -407,10 +421,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_bf16_kernel(const bf16_t* _
         const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
         unsigned long long bits = 0ull;
         if (MODE == 2) bits = static_cast<unsigned long long>(bits_io[bix]) | (static_cast<unsigned long long>(bits_io[bix + 1]) << 32);
-#pragma unroll 1
-        for (int mb = 0; mb < 4; ++mb) {
-            f32x4 acc[3];
-            gemm_up_block<false>(MODE == 1 ? xt : zt, mb, wf, acc, lane);
+        gemm_up_tile<false, false>(MODE == 1 ? xt : zt, wf, lane, [&](int mb, const f32x4 (&acc)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_bf16_kernel(const bf16_t* _
                 }
                 *reinterpret_cast<u32x2_t*>(tt + (48 * w + 16 * i + (lane & 15)) * kTPitch + (16 * mb + 4 * (lane >> 4)) * 2) = pv;
             }
-        }
+        });
         if (MODE == 1 && bits_io) {
             bits_io[bix] = static_cast<unsigned>(bits);
             bits_io[bix + 1] = static_cast<unsigned>(bits >> 32);
@@ -508,7 +519,7 @@ extern "C" int dg_ffn_bf16_pack(const float* w1, const float* w2, void* packed, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     bf16x8* p = static_cast<bf16x8*>(packed);
     int st = pack_bf16(w1, p + kP16W1, kH, kC, 0, 16, stream);            // W1 [384,128]: W' = W1
-    if (!st) st = pack_bf16(w2, p + kP32W2, kC, kH, 0, 32, stream);       // W2 [128,384]: W' = W2
+    if (!st) st = pack_bf16(w2, p + kP16W2, kC, kH, 0, 16, stream);       // W2 [128,384]: W' = W2
     if (!st) st = pack_bf16(w2, p + kP16W2T, kC, kH, 1, 16, stream);      // W' = W2^T [384,128]
     if (!st) st = pack_bf16(w1, p + kP16W1T, kH, kC, 1, 16, stream);      // W' = W1^T [128,384]
     return st;

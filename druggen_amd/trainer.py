@@ -96,7 +96,7 @@ class GANStep:
     def __init__(self, G: torch.nn.Module, D: torch.nn.Module, *, g_lr: float = 1e-5, d_lr: float = 1e-5,
                  betas: Sequence[float] = (0.9, 0.999), lambda_gp: float = 10.0, group=None,
                  skip_d_wgrad_in_g_step: bool = True, d_loss_fn=discriminator_loss, g_loss_fn=generator_loss,
-                 optimizer: str = "auto", share_generator_forward: bool = True):
+                 optimizer: str = "auto", share_generator_forward: bool = True, memory: str = "auto"):
         self.G, self.D = G, D
         self.lambda_gp = lambda_gp
         self.group = group
@@ -119,6 +119,46 @@ class GANStep:
         # identical, so one forward with its graph serves both.
         self.share_generator_forward = share_generator_forward
         self._d_loss_fn, self._g_loss_fn = d_loss_fn, g_loss_fn
+        # memory = "fast": one backward over the whole D loss, the generator forward shared by both steps (three
+        # Discriminator graphs and the Generator graph alive at once: ~1.2 GB per molecule at N=45, L=4 in fp32);
+        # "low": the three D terms are differentiated one after the other (-mean D(real), mean D(fake), lambda gp:
+        # gradients accumulate, each graph is freed before the next is built) and G runs again for the G step --
+        # same numbers up to the fp32 order of three additions per gradient element, a third of the peak memory.
+        # "auto" picks "low" when the fast path's estimate does not fit the device (BASELINE configs[3]: B = 2048
+        # per GPU in fp32 needs > 288 GB on the fast path).
+        if memory not in ("auto", "fast", "low"):
+            raise ValueError("memory must be 'auto', 'fast' or 'low'")
+        self.memory = memory
+
+    def _low_memory(self, gen_edge) -> bool:
+        if self.memory != "auto":
+            return self.memory == "low"
+        if not gen_edge.is_cuda or self._d_loss_fn is not discriminator_loss or self._g_loss_fn is not generator_loss:
+            return False
+        from .functional import activation_dtype
+        B, N = gen_edge.shape[0], gen_edge.shape[1]
+        dim = int(getattr(self.G, "dim", 128))
+        # block passes whose graphs are alive at the peak: G once, D four times (real + fake, gradient penalty
+        # and its double backward)
+        depth = int(getattr(self.G, "depth", 1)) + 4 * int(getattr(self.D, "depth", 1))
+        es = 2 if activation_dtype() == torch.bfloat16 else 4
+        # measured on MI355X at N=45, L=4 (bench.py peak_memory_GB): 0.18 GB per molecule in fp32, 0.077 GB with bf16
+        # activations = 8.7 / 7.4 edge tensors per block pass; 9 leaves a margin
+        estimate = 9.0 * B * N * N * dim * es * depth
+        return estimate > 0.85 * torch.cuda.get_device_properties(gen_edge.device).total_memory
+
+    def _d_step_low_memory(self, disc_edge, disc_node, gen_edge, gen_node, B, dev, eps):
+        """discriminator_loss (reference loss.py:52-72) + backward, one term at a time."""
+        from .model.loss import gradient_penalty
+        with torch.no_grad():
+            _, _, node_sample, edge_sample = self.G(gen_edge, gen_node)
+        loss_real = -torch.mean(self.D(disc_edge, disc_node))
+        loss_real.backward()
+        loss_fake = torch.mean(self.D(edge_sample, node_sample))
+        loss_fake.backward()
+        gp = self.lambda_gp * gradient_penalty(self.D, disc_node, disc_edge, node_sample, edge_sample, B, dev, eps=eps)
+        gp.backward()
+        return (loss_fake.detach() + loss_real.detach() + gp.detach())
 
     def _update(self, opt, bucket: GradBucket) -> None:
         """Average gradients across ranks (one all-reduce) and apply AdamW."""
@@ -152,14 +192,18 @@ class GANStep:
         self.reset_grad()
         kw = {} if eps is None else {"eps": eps}
         shared = None
-        if (self.share_generator_forward and self._d_loss_fn is discriminator_loss
+        low = self._low_memory(gen_edge)
+        if low:
+            d_loss = self._d_step_low_memory(disc_edge, disc_node, gen_edge, gen_node, B, dev, eps)
+        elif (self.share_generator_forward and self._d_loss_fn is discriminator_loss
                 and self._g_loss_fn is generator_loss
                 and not (self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0)):
             shared = self.G(gen_edge, gen_node)
             kw["generator_outputs"] = shared
-        _, _, d_loss = self._d_loss_fn(self.G, self.D, disc_edge, disc_node, gen_edge, gen_node, B, dev,
-                                       self.lambda_gp, **kw)
-        d_loss.backward()
+        if not low:
+            _, _, d_loss = self._d_loss_fn(self.G, self.D, disc_edge, disc_node, gen_edge, gen_node, B, dev,
+                                           self.lambda_gp, **kw)
+            d_loss.backward()
         self._update(self.d_optimizer, self.d_bucket)
         self.reset_grad()
         d_params = [p for p in self.D.parameters() if p.requires_grad] if self.skip_d_wgrad_in_g_step else []
