@@ -40,6 +40,7 @@ SIGNATURES = {
     "dg_edge_ffn_ln_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, c_int, _P]),
     "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_ffn_bf16_padded_rows": (c_int64, [c_int64]),
     "dg_ffn_bf16_packed_bytes": (c_size_t, []),
     "dg_ffn_bf16_pack": (c_int, [_P, _P, _P, _P]),
     "dg_ffn_bf16_mask_words": (c_size_t, [c_int64]),

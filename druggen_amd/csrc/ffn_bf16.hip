@@ -27,6 +27,8 @@
 // fragments).  Weight-gradient partials are reduced afterwards in a fixed order (bit-reproducible).
 #include "gemm_bf16.h"
 
+#include <cstring>
+
 namespace dg {
 
 int pack_bf16(const float* w, void* packed, int rows, int cols, int mode, int mb_size, hipStream_t stream);
@@ -116,6 +118,7 @@ __device__ __forceinline__ void down16_frags(const char* rowp, int rsw, int kq, 
         hf[j] = *reinterpret_cast<const bf16x8*>(rowp + (((chunk & ~15) | ((chunk & 15) ^ rsw)) << 4));
     }
 }
+template <bool FENCE = true>
 __device__ __forceinline__ f32x4 gemm_down_block16(const char* tile, int rb, const bf16x8 (&wf)[12], int lane) {
     f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     const int row = 16 * rb + (lane & 15);
@@ -129,20 +132,20 @@ __device__ __forceinline__ f32x4 gemm_down_block16(const char* tile, int rb, con
         acc_a = mfma16(wf[j], h0[j], acc_a);
         acc_b = mfma16(wf[j + 1], h0[j + 1], acc_b);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
     down16_frags(rowp, rsw, kq, 2, h0);
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         acc_a = mfma16(wf[4 + j], h1[j], acc_a);
         acc_b = mfma16(wf[4 + j + 1], h1[j + 1], acc_b);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         acc_a = mfma16(wf[8 + j], h0[j], acc_a);
         acc_b = mfma16(wf[8 + j + 1], h0[j + 1], acc_b);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
     return acc_a + acc_b;
 }
 
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              bf16_t* __restrict__ y, bf16_t* __restrict__ pre,
                                                              float* __restrict__ mean, float* __restrict__ rstd,
-                                                             unsigned* __restrict__ relu_bits, int64_t R, float eps) {
+                                                             unsigned* __restrict__ relu_bits, int64_t R, float eps, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xbuf = smem;                       // [2][64][128] bf16
     char* htile = smem + 2 * kXBytes;        // [64][384] bf16
@@ -185,11 +188,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
         // a barrier is all that is needed here: the stores drain during this tile's MFMA phases instead of stalling
         // every tile on their acknowledgement (vmcnt counts stores too).
         __syncthreads();
-        if (tix + gridDim.x < tiles)
+        if (tix + gridDim.x < tiles && !(dbg & 16))
             dma_tile_bf16<kC, 8>(x, (tix + gridDim.x) * kRowsPerTile, R, xbuf + (buf ^ 1) * kXBytes, w, lane);
         const char* xt = xbuf + buf * kXBytes;
         // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element
         unsigned long long bits = 0ull;
+        if (!(dbg & 1))
         gemm_up_tile<true, true>(xt, wf1, lane, [&](int nb, const f32x4 (&acc1)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -206,8 +210,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
             relu_bits[bix] = static_cast<unsigned>(bits);
             relu_bits[bix + 1] = static_cast<unsigned>(bits >> 32);
         }
-        __syncthreads();
+        if (!(dbg & 32)) __syncthreads();
         // ---- fc2 -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows)
+        if (!(dbg & 2))
 #pragma unroll 1
         for (int nb = 0; nb < 4; ++nb) {
             const f32x4 a4 = gemm_down_block16(htile, nb, wf2, lane);
@@ -215,8 +220,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
                 make_float4(a4[0], a4[1], a4[2], a4[3]);
         }
         wait_all_vmem();       // the next tile's DMA (issued a whole MFMA phase ago) and this wave's older stores
-        __syncthreads();
+        if (!(dbg & 32)) __syncthreads();
         // ---- + b2 + x, LayerNorm, whole-row stores
+        if (!(dbg & 4))
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rr = 8 * w + 2 * it + half;
@@ -224,17 +230,210 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __re
             const bool ok = row < R;
             float4 v = *reinterpret_cast<const float4*>(xch + xch_off(rr, 4 * col, kC)) + b2v;
             v += unpack4_bf16(*reinterpret_cast<const u32x2_t*>(xt + tile_off(rr, 4 * col, kC)));
-            if (pre && ok) st4(pre + row * kC + 4 * col, v);
+            if (pre && ok && !(dbg & 8)) st4(pre + row * kC + 4 * col, v);
             const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
             const float4 d = v - f4(mu);
             const float var = half_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
             const float rs = rsqrtf(var + eps);
-            if (ok) {
+            if (ok && !(dbg & 8)) {
                 st4(y + row * kC + 4 * col, fma4(rs * d, gam, bet));
                 if (col == 0) {
                     mean[row] = mu;
                     rstd[row] = rs;
                 }
+            }
+        }
+    }
+}
+
+// Forward, lean version.  Profiling the kernel above (PMC + phase ablation, profiles/r02_ffn_ablation.txt) showed it
+// VALU-issue bound, not MFMA or HBM bound: ~740 vector instructions per wave and tile against 96 MFMAs -- swizzled LDS
+// addresses recomputed for every fragment, and a row phase of 4 x ~100 dependent instructions (two rows per pass, two
+// 32-lane reductions with DPP + readlane each).  Here
+//   * every LDS address is a per-lane offset computed ONCE before the tile loop plus an immediate (the XOR swizzle
+//     only touches bits that are fixed per lane once the row block / k-group is an immediate);
+//   * the row phase handles the wave's 8 rows in ONE pass: 8 lanes x 16 channels per row, so the two LayerNorm
+//     reductions are 3 DPP steps inside a half-row (no readlane), and the results leave as 16-byte stores;
+//   * outputs are stored unconditionally (the caller pads them to whole tiles): no per-row branches.
+__device__ __forceinline__ float sum8(float x) {      // sum over the 8 lanes of a half-row, result in all 8
+    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror: lane i <-> 7 - i, i.e. the other quad
+    return x;
+}
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ x, const bf16x8* __restrict__ pk,
+                                                                const float* __restrict__ b1, const float* __restrict__ b2,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                bf16_t* __restrict__ y, bf16_t* __restrict__ pre,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                unsigned* __restrict__ relu_bits, int64_t R, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xbuf = smem;                       // [2][64][128] bf16
+    char* htile = smem + 2 * kXBytes;        // [64][384] bf16
+    char* zt = htile + kHBytes;              // [64][128] fp32 exchange tile
+    float4* gb = reinterpret_cast<float4*>(zt + kZBytes);   // gamma [32 x float4], beta [32 x float4]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
+
+    bf16x8 wf1[3][4], wf2[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf1[i][ks] = pk[kP16W1 + ((3 * w + i) * 4 + ks) * 64 + lane];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) wf2[ks] = pk[kP16W2 + (w * 12 + ks) * 64 + lane];
+    float4 b1v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b1v[i] = ld4(b1 + 48 * w + 16 * i + 4 * kq);
+    const float4 b2z = ld4(b2 + 16 * w + 4 * kq);
+    if (threadIdx.x < 32) gb[threadIdx.x] = ld4(gamma + 4 * threadIdx.x);
+    else if (threadIdx.x < 64) gb[threadIdx.x] = ld4(beta + 4 * (threadIdx.x - 32));
+    // ---- per-lane LDS byte offsets (row blocks of 16 rows and k-groups enter as immediates)
+    unsigned xf_off[4], hf_off[4], hw_off[3], zr_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xf_off[j] = r16 * (kC * 2) + (((4 * j + kq) ^ r16) << 4);          // X fragment, k-step j
+        hf_off[j] = r16 * (kH * 2) + (((4 * j + kq) ^ r16) << 4);          // H fragment, k-step 4 a + j (+ 256 a)
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int chunk = 6 * w + 2 * i + (kq >> 1);
+        hw_off[i] = r16 * (kH * 2) + (((chunk & ~15) | ((chunk & 15) ^ r16)) << 4) + (kq & 1) * 8;
+    }
+    const int zslot = 4 * w + kq;
+    const unsigned zw_off = r16 * (kC * 4) + (((zslot & ~7) | ((zslot & 7) ^ (r16 & 7))) << 4);
+    const unsigned xr_off = r16 * (kC * 2) + (((2 * w + (kq >> 1)) ^ r16) << 4) + (kq & 1) * 8;
+    const int r8 = lane >> 3, sub = lane & 7;      // row phase: row 8 w + r8, channels [16 sub, 16 sub + 16)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = 4 * sub + q;
+        zr_off[q] = (8 * w + r8) * (kC * 4) + (((slot & ~7) | ((slot & 7) ^ r8)) << 4);
+    }
+    wait_all_vmem_visible();
+
+    int64_t tix = blockIdx.x;
+    if (tix < tiles) dma_tile_bf16<kC, 8>(x, tix * kRowsPerTile, R, xbuf, w, lane);
+    wait_all_vmem();
+    int buf = 0;
+    for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
+        const int64_t r0 = tix * kRowsPerTile;
+        __syncthreads();      // x(t) landed everywhere (waited for before the previous stores); H / exchange tiles free
+        if (tix + gridDim.x < tiles)
+            dma_tile_bf16<kC, 8>(x, (tix + gridDim.x) * kRowsPerTile, R, xbuf + (buf ^ 1) * kXBytes, w, lane);
+        const char* xt = xbuf + buf * kXBytes;
+        // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element
+        unsigned long long bits = 0ull;
+        {
+            bf16x8 fa[4], fb[4];
+            auto frags = [&](int nb, bf16x8 (&f)[4]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8*>(xt + nb * (16 * kC * 2) + xf_off[ks]);
+            };
+            auto finish = [&](int nb, const f32x4 (&acc1)[3]) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float4 v = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]) + b1v[i];
+                    const unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                    bits |= static_cast<unsigned long long>(nib) << (nb * 12 + i * 4);
+                    v = max4(v, f4(0.f));
+                    *reinterpret_cast<u32x2_t*>(htile + nb * (16 * kH * 2) + hw_off[i]) = pack4_bf16(v);
+                }
+            };
+            frags(0, fa);
+#pragma unroll
+            for (int nb = 0; nb < 4; nb += 2) {
+                f32x4 acc1[3];
+                frags(nb + 1, fb);
+                up_mfma<true>(fa, wf1, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(nb, acc1);
+                if (nb + 2 < 4) frags(nb + 2, fa);
+                up_mfma<true>(fb, wf1, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(nb + 1, acc1);
+            }
+        }
+        if (SAVE) {
+            const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
+            relu_bits[bix] = static_cast<unsigned>(bits);
+            relu_bits[bix + 1] = static_cast<unsigned>(bits >> 32);
+        }
+        __syncthreads();
+        // ---- fc2 + b2 + x -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const char* hb = htile + nb * (16 * kH * 2);
+            f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 h0[4], h1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h0[j] = *reinterpret_cast<const bf16x8*>(hb + hf_off[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h1[j] = *reinterpret_cast<const bf16x8*>(hb + 256 + hf_off[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                acc_a = mfma16(wf2[j], h0[j], acc_a);
+                acc_b = mfma16(wf2[j + 1], h0[j + 1], acc_b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h0[j] = *reinterpret_cast<const bf16x8*>(hb + 512 + hf_off[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                acc_a = mfma16(wf2[4 + j], h1[j], acc_a);
+                acc_b = mfma16(wf2[4 + j + 1], h1[j + 1], acc_b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                acc_a = mfma16(wf2[8 + j], h0[j], acc_a);
+                acc_b = mfma16(wf2[8 + j + 1], h0[j + 1], acc_b);
+            }
+            const f32x4 a4 = acc_a + acc_b;
+            const float4 xr = unpack4_bf16(*reinterpret_cast<const u32x2_t*>(xt + nb * (16 * kC * 2) + xr_off));
+            *reinterpret_cast<float4*>(zt + nb * (16 * kC * 4) + zw_off) = make_float4(a4[0], a4[1], a4[2], a4[3]) + b2z + xr;
+        }
+        wait_all_vmem();       // the next tile's DMA (issued two MFMA phases ago) and this wave's older stores
+        __syncthreads();
+        // ---- LayerNorm of this wave's 8 rows in one pass, 16-byte stores
+        {
+            const int64_t row = r0 + 8 * w + r8;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(zt + zr_off[q]);
+            if (SAVE) {
+                u32x4_t p0, p1;
+                p0[0] = pack_bf16(v[0].x, v[0].y); p0[1] = pack_bf16(v[0].z, v[0].w);
+                p0[2] = pack_bf16(v[1].x, v[1].y); p0[3] = pack_bf16(v[1].z, v[1].w);
+                p1[0] = pack_bf16(v[2].x, v[2].y); p1[1] = pack_bf16(v[2].z, v[2].w);
+                p1[2] = pack_bf16(v[3].x, v[3].y); p1[3] = pack_bf16(v[3].z, v[3].w);
+                *reinterpret_cast<u32x4_t*>(pre + row * kC + 16 * sub) = p0;
+                *reinterpret_cast<u32x4_t*>(pre + row * kC + 16 * sub + 8) = p1;
+            }
+            float4 t = (v[0] + v[1]) + (v[2] + v[3]);
+            const float mu = sum8((t.x + t.y) + (t.z + t.w)) * (1.0f / 128.0f);
+            float4 sq = f4(0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = v[q] - f4(mu);
+                sq = fma4(v[q], v[q], sq);
+            }
+            const float var = sum8((sq.x + sq.y) + (sq.z + sq.w)) * (1.0f / 128.0f);
+            const float rs = rsqrtf(var + eps);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fma4(rs * v[q], gb[4 * sub + q], gb[32 + 4 * sub + q]);
+            u32x4_t o0, o1;
+            o0[0] = pack_bf16(v[0].x, v[0].y); o0[1] = pack_bf16(v[0].z, v[0].w);
+            o0[2] = pack_bf16(v[1].x, v[1].y); o0[3] = pack_bf16(v[1].z, v[1].w);
+            o1[0] = pack_bf16(v[2].x, v[2].y); o1[1] = pack_bf16(v[2].z, v[2].w);
+            o1[2] = pack_bf16(v[3].x, v[3].y); o1[3] = pack_bf16(v[3].z, v[3].w);
+            *reinterpret_cast<u32x4_t*>(y + row * kC + 16 * sub) = o0;
+            *reinterpret_cast<u32x4_t*>(y + row * kC + 16 * sub + 8) = o1;
+            if (sub == 0) {
+                mean[row] = mu;
+                rstd[row] = rs;
             }
         }
     }
@@ -525,6 +724,8 @@ extern "C" int dg_ffn_bf16_pack(const float* w1, const float* w2, void* packed, 
     return st;
 }
 
+extern "C" int64_t dg_ffn_bf16_padded_rows(int64_t R) { return R < 1 ? 0 : (R + kRowsPerTile - 1) / kRowsPerTile * kRowsPerTile; }
+
 extern "C" size_t dg_ffn_bf16_mask_words(int64_t R) {
     return R < 1 ? 0 : static_cast<size_t>((R + kRowsPerTile - 1) / kRowsPerTile) * 512 * 2;
 }
@@ -543,12 +744,31 @@ extern "C" int dg_ffn_ln_fwd_bf16(const void* x, const void* packed, const float
     if (R < 0) return fail(DG_E_SHAPE, "dg_ffn_ln_fwd_bf16: negative row count");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    constexpr int lds = 2 * kXBytes + kHBytes + kZBytes;
-    DG_OPT_IN_LDS((&ffn_fwd_bf16_kernel), lds);
+    static const bool plain = getenv("DG_FFN_FWD") && strcmp(getenv("DG_FFN_FWD"), "plain") == 0;
     ProfScope prof(DG_K_FFN, stream);
-    hipLaunchKernelGGL(ffn_fwd_bf16_kernel, dim3(ffn_grid(R)), dim3(512), lds, stream, static_cast<const bf16_t*>(x),
-                       static_cast<const bf16x8*>(packed), b1, b2, gamma, beta, static_cast<bf16_t*>(y),
-                       static_cast<bf16_t*>(pre), mean, rstd, relu_bits, R, eps);
+    if (plain) {
+        constexpr int lds = 2 * kXBytes + kHBytes + kZBytes;
+        DG_OPT_IN_LDS((&ffn_fwd_bf16_kernel), lds);
+        hipLaunchKernelGGL(ffn_fwd_bf16_kernel, dim3(ffn_grid(R)), dim3(512), lds, stream, static_cast<const bf16_t*>(x),
+                           static_cast<const bf16x8*>(packed), b1, b2, gamma, beta, static_cast<bf16_t*>(y),
+                           static_cast<bf16_t*>(pre), mean, rstd, relu_bits, R, eps,
+                           getenv("DG_FFN_DBG") ? atoi(getenv("DG_FFN_DBG")) : 0);
+        return check_launch("dg_ffn_ln_fwd_bf16");
+    }
+    // lean kernel: stores whole 64-row tiles -- y, pre_ln, mean, rstd must hold dg_ffn_bf16_padded_rows(R) rows
+    constexpr int lds = 2 * kXBytes + kHBytes + kZBytes + 1024;
+    const bool save = pre != nullptr && relu_bits != nullptr;
+    if (save) {
+        DG_OPT_IN_LDS((&ffn_fwd_bf16_v2_kernel<true>), lds);
+        hipLaunchKernelGGL(ffn_fwd_bf16_v2_kernel<true>, dim3(ffn_grid(R)), dim3(512), lds, stream,
+                           static_cast<const bf16_t*>(x), static_cast<const bf16x8*>(packed), b1, b2, gamma, beta,
+                           static_cast<bf16_t*>(y), static_cast<bf16_t*>(pre), mean, rstd, relu_bits, R, eps);
+    } else {
+        DG_OPT_IN_LDS((&ffn_fwd_bf16_v2_kernel<false>), lds);
+        hipLaunchKernelGGL(ffn_fwd_bf16_v2_kernel<false>, dim3(ffn_grid(R)), dim3(512), lds, stream,
+                           static_cast<const bf16_t*>(x), static_cast<const bf16x8*>(packed), b1, b2, gamma, beta,
+                           static_cast<bf16_t*>(y), static_cast<bf16_t*>(pre), mean, rstd, relu_bits, R, eps);
+    }
     return check_launch("dg_ffn_ln_fwd_bf16");
 }
 

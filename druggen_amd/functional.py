@@ -742,10 +742,11 @@ class _FFNLNFusedBF16(Function):
         lib = _lib.load()
         dev = x2.device
         record = any(ctx.needs_input_grad)
-        y = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-        mean = torch.empty(R, dtype=torch.float32, device=dev)
-        rstd = torch.empty(R, dtype=torch.float32, device=dev)
-        pre = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if record else None
+        Rp = int(lib.dg_ffn_bf16_padded_rows(R))      # the kernel stores whole 64-row tiles
+        y = torch.empty(Rp, C, dtype=torch.bfloat16, device=dev)[:R]
+        mean = torch.empty(Rp, dtype=torch.float32, device=dev)[:R]
+        rstd = torch.empty(Rp, dtype=torch.float32, device=dev)[:R]
+        pre = torch.empty(Rp, C, dtype=torch.bfloat16, device=dev)[:R] if record else None
         bits = torch.empty(int(lib.dg_ffn_bf16_mask_words(R)), dtype=torch.int32, device=dev) if record else None
         with _dev(x2):
             _lib.check(lib.dg_ffn_ln_fwd_bf16(_lib.ptr(x2), _ffn_packed_bf16(w1, w2).data_ptr(), _lib.fptr(_c(b1)),

@@ -192,11 +192,13 @@ int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* relu_bits, 
  * recomputes it.  `packed` holds the four bf16 fragment-order copies of (W1 [384,128], W2 [128,384])
  * made by dg_ffn_bf16_pack (dg_ffn_bf16_packed_bytes() bytes).  The forward saves pre_ln [R,128] bf16,
  * mean / rstd [R] and one ReLU-mask bit per hidden element (dg_ffn_bf16_mask_words(R) uint32 words);
- * pre_ln and relu_bits may be NULL when no backward will follow.
+ * pre_ln and relu_bits may be NULL when no backward will follow.  The forward stores whole 64-row tiles: its four
+ * outputs must be allocated with dg_ffn_bf16_padded_rows(R) rows (the first R are the result).
  * _bwd: dy [R,128] -> dz [R,128] (scratch the caller owns: LayerNorm input gradient, bf16), dx (nullable),
  * dgamma, dbeta, and -- when dw1 != NULL -- dw1 [384,128], db1, dw2 [128,384], db2 (float32);
  * bits_scratch: dg_ffn_bf16_mask_words(R) words of scratch, needed with the weight gradients.
  * First order only: the gradient penalty's twice-differentiated pass uses dg_edge_ffn_ln_fwd/_bwd.   */
+int64_t dg_ffn_bf16_padded_rows(int64_t R);     /* rows y / pre_ln / mean / rstd of _fwd must hold (R rounded up to whole tiles) */
 size_t dg_ffn_bf16_packed_bytes(void);
 int dg_ffn_bf16_pack(const float* w1, const float* w2, void* packed, dg_stream_t stream);
 size_t dg_ffn_bf16_mask_words(int64_t R);
