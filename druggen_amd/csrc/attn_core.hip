@@ -61,12 +61,18 @@ template <typename T, int LQS, int JPL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, const T* __restrict__ e,
                                                       T* __restrict__ s, T* __restrict__ o, int N, int C,
-                                                      float alpha, int RG) {
+                                                      float alpha, int RG, int B) {
     constexpr int QS = 1 << LQS;
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.y * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (slice * QS * 4 >= C) return;  // wave-uniform; no barriers in this kernel
-    const int b = blockIdx.x / RG, rg = blockIdx.x % RG;
+    // XCD-aware placement (speed only): workgroup id -> XCD is round robin (id % 8), and each XCD has its own L2.
+    // All RG row groups of a molecule get ids with the same residue mod 8, consecutive in that XCD's dispatch order,
+    // so the molecule's k, v rows are fetched from HBM once instead of once per XCD (PMC: reads 1.30x -> ~1.0x
+    // of the algorithmic bytes).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / RG) * 8 + xcd, rg = slot % RG;
+    if (b >= B) return;
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
 
@@ -473,12 +479,12 @@ extern "C" int dg_attn_core_fwd(const void* q_, const void* k_, const void* v_, 
     int RG = (N + rows_per_wave - 1) / rows_per_wave;
     if (const char* env = getenv("DG_ATTN_FWD_RG")) RG = atoi(env) > 0 ? atoi(env) : RG;
     if (RG > N) RG = N;
-    dim3 grid(static_cast<unsigned>(B) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
+    dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
     ProfScope prof(DG_K_ATTN_FWD, stream);
 #define LAUNCH_T(T, LQS, JPL)                                                                                     \
     hipLaunchKernelGGL((attn_fwd_kernel<T, LQS, JPL>), grid, block, 0, stream, static_cast<const T*>(q_),         \
                        static_cast<const T*>(k_), static_cast<const T*>(v_), static_cast<const T*>(e_),          \
-                       static_cast<T*>(s_), static_cast<T*>(o_), N, C, alpha, RG);
+                       static_cast<T*>(s_), static_cast<T*>(o_), N, C, alpha, RG, B);
 #define LAUNCH(LQS, JPL)                                       \
     if (g.lqs == LQS && g.jpl == JPL) {                        \
         if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, LQS, JPL) } \

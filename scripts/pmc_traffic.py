@@ -30,9 +30,14 @@ def per_kernel(path):
 
 
 def main():
+    """pmc_traffic.py <fetch csv> <write csv> [config dtype batch commit]"""
     rd, rc = per_kernel(sys.argv[1])
     wr, wc = per_kernel(sys.argv[2])
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; "
+    meta = sys.argv[3:7] + [None] * 4
+    out = {"config": meta[0], "dtype": meta[1], "batch": int(meta[2]) if meta[2] else None, "commit": meta[3],
+           "measured": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) on bench.py --steps 3 --warmup 1",
+           "method": "read = 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128 B request), write = WRITE_SIZE*1024",
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; "
                    "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; averages per launch over the "
                    "launch mix of the GAN step"}
     for key, tag in (("attn_fwd_kernel", "attn_fwd"), ("attn_bwd_kernel", "attn_bwd"), ("attn_bwd2_kernel", "attn_bwd2")):
