@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (single GPU)")
     ap.add_argument("--vertexes", type=int, default=0, help="override N (parity-case shapes; not the headline)")
     ap.add_argument("--depth", type=int, default=0, help="override L")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary measurement (BASELINE configs[2]: bf16 activations, batch 2048) that the "
+                         "default single-GPU run appends as `bf16_configs2` after the timed region")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's own setting (train.py:16: 5 threads)")
     return ap.parse_args()
@@ -115,6 +118,36 @@ def cpu_baseline(workload, batch: int, threads: int = 0):
                       f"{head['batch']}, {head['steps']} step(s) after 1 warm-up, {head['threads']} threads "
                       f"(the reference's train.py:16 setting) of {logical} logical cores",
             "variants": variants, "logical_cores": logical}
+
+
+def secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w, batch=2048, steps=4, warmup=2):
+    """BASELINE configs[2] beside the headline: the same model with bf16 activations at batch 2048, measured in the same
+    process AFTER the headline's timed region (same timing discipline: synchronize, K steps, synchronize).  Not part of
+    `value`; `python bench.py --config c3` is the full-length version of this line."""
+    torch.cuda.empty_cache()
+    a, x, _, _ = synth.molecule_batch(batch, w["vertexes"], w["edges"], w["nodes"], seed=4321)
+    da, dx, _, _ = synth.molecule_batch(batch, w["vertexes"], w["edges"], w["nodes"], seed=5321)
+    ge, gn = torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev)
+    de, dn = torch.from_numpy(da).to(dev), torch.from_numpy(dx).to(dev)
+    prev = dgf.activation_dtype()
+    dgf.set_activation_dtype("bf16")
+    try:
+        st = GANStep(G, D, lambda_gp=10.0)
+        for _ in range(warmup):
+            st.step(de, dn, ge, gn)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses = st.step(de, dn, ge, gn)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ok = all(bool(torch.isfinite(v)) for v in losses)
+    finally:
+        dgf.set_activation_dtype(prev)
+    return {"metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs", "value": batch * steps / dt, "unit": "molecules/s",
+            "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "dtype": "bf16", "batch_per_gpu": batch,
+            "config": "BASELINE configs[2]: same model, bf16 activations in HBM (fp32 parameters / optimizer / statistics), "
+                      "batch 2048, 1 GPU", "finite_losses": ok}
 
 
 def main():
@@ -304,6 +337,8 @@ def main():
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
         }
+        if world == 1 and args.config == "c2" and act_dtype == "f32" and not args.no_extra and not args.graph:
+            out["bf16_configs2"] = secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_batch, args.cpu_threads)
         print(json.dumps(out), flush=True)

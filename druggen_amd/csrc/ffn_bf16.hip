@@ -150,106 +150,10 @@ __device__ __forceinline__ f32x4 gemm_down_block16(const char* tile, int rb, con
 }
 
 // ------------------------------------------------------------------------------------ forward --
-__global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_kernel(const bf16_t* __restrict__ x, const bf16x8* __restrict__ pk,
-                                                             const float* __restrict__ b1, const float* __restrict__ b2,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             bf16_t* __restrict__ y, bf16_t* __restrict__ pre,
-                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                             unsigned* __restrict__ relu_bits, int64_t R, float eps, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xbuf = smem;                       // [2][64][128] bf16
-    char* htile = smem + 2 * kXBytes;        // [64][384] bf16
-    char* xch = htile + kHBytes;             // [64][128] fp32
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, col = lane & 31;
-    const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
-
-    bf16x8 wf1[3][4], wf2[12];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wf1[i][ks] = pk[kP16W1 + ((3 * w + i) * 4 + ks) * 64 + lane];
-#pragma unroll
-    for (int ks = 0; ks < 12; ++ks) wf2[ks] = pk[kP16W2 + (w * 12 + ks) * 64 + lane];
-    float4 b1v[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) b1v[i] = ld4(b1 + 48 * w + 16 * i + 4 * (lane >> 4));
-    const float4 b2v = ld4(b2 + 4 * col), gam = ld4(gamma + 4 * col), bet = ld4(beta + 4 * col);
-    wait_all_vmem_visible();
-
-    int64_t tix = blockIdx.x;
-    if (tix < tiles) dma_tile_bf16<kC, 8>(x, tix * kRowsPerTile, R, xbuf, w, lane);
-    wait_all_vmem();
-    int buf = 0;
-    for (; tix < tiles; tix += gridDim.x, buf ^= 1) {
-        const int64_t r0 = tix * kRowsPerTile;
-        // Every wave waited for its share of this tile's DMA BEFORE it issued the previous tile's stores (below), so
-        // a barrier is all that is needed here: the stores drain during this tile's MFMA phases instead of stalling
-        // every tile on their acknowledgement (vmcnt counts stores too).
-        __syncthreads();
-        if (tix + gridDim.x < tiles && !(dbg & 16))
-            dma_tile_bf16<kC, 8>(x, (tix + gridDim.x) * kRowsPerTile, R, xbuf + (buf ^ 1) * kXBytes, w, lane);
-        const char* xt = xbuf + buf * kXBytes;
-        // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element
-        unsigned long long bits = 0ull;
-        if (!(dbg & 1))
-        gemm_up_tile<true, true>(xt, wf1, lane, [&](int nb, const f32x4 (&acc1)[3]) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float4 v = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]) + b1v[i];
-                const unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-                bits |= static_cast<unsigned long long>(nib) << (nb * 12 + i * 4);
-                v = max4(v, f4(0.f));
-                *reinterpret_cast<u32x2_t*>(htile + tile_off(16 * nb + (lane & 15), 48 * w + 16 * i + 4 * (lane >> 4), kH)) =
-                    pack4_bf16(v);
-            }
-        });
-        if (relu_bits) {
-            const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
-            relu_bits[bix] = static_cast<unsigned>(bits);
-            relu_bits[bix + 1] = static_cast<unsigned>(bits >> 32);
-        }
-        if (!(dbg & 32)) __syncthreads();
-        // ---- fc2 -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows)
-        if (!(dbg & 2))
-#pragma unroll 1
-        for (int nb = 0; nb < 4; ++nb) {
-            const f32x4 a4 = gemm_down_block16(htile, nb, wf2, lane);
-            *reinterpret_cast<float4*>(xch + xch_off(16 * nb + (lane & 15), 16 * w + 4 * (lane >> 4), kC)) =
-                make_float4(a4[0], a4[1], a4[2], a4[3]);
-        }
-        wait_all_vmem();       // the next tile's DMA (issued a whole MFMA phase ago) and this wave's older stores
-        if (!(dbg & 32)) __syncthreads();
-        // ---- + b2 + x, LayerNorm, whole-row stores
-        if (!(dbg & 4))
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rr = 8 * w + 2 * it + half;
-            const int64_t row = r0 + rr;
-            const bool ok = row < R;
-            float4 v = *reinterpret_cast<const float4*>(xch + xch_off(rr, 4 * col, kC)) + b2v;
-            v += unpack4_bf16(*reinterpret_cast<const u32x2_t*>(xt + tile_off(rr, 4 * col, kC)));
-            if (pre && ok && !(dbg & 8)) st4(pre + row * kC + 4 * col, v);
-            const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
-            const float4 d = v - f4(mu);
-            const float var = half_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
-            const float rs = rsqrtf(var + eps);
-            if (ok && !(dbg & 8)) {
-                st4(y + row * kC + 4 * col, fma4(rs * d, gam, bet));
-                if (col == 0) {
-                    mean[row] = mu;
-                    rstd[row] = rs;
-                }
-            }
-        }
-    }
-}
-
-// Forward, lean version.  Profiling the kernel above (PMC + phase ablation, profiles/r02_ffn_ablation.txt) showed it
-// VALU-issue bound, not MFMA or HBM bound: ~740 vector instructions per wave and tile against 96 MFMAs -- swizzled LDS
-// addresses recomputed for every fragment, and a row phase of 4 x ~100 dependent instructions (two rows per pass, two
-// 32-lane reductions with DPP + readlane each).  Here
+// The first version of this kernel (PMC counters, phase ablation and s_memtime stamps: profiles/r02_ffn_fwd_phases.txt)
+// was VALU-issue bound, not MFMA or HBM bound: ~740 vector instructions per wave and tile against 96 MFMAs -- swizzled
+// LDS addresses recomputed for every fragment, ~25 instructions per 4 hidden values in the fc1 epilogue, a row phase of
+// 4 x ~100 dependent instructions -- and its phases ran strictly one after the other in all 8 waves.  Here
 //   * every LDS address is a per-lane offset computed ONCE before the tile loop plus an immediate (the XOR swizzle
 //     only touches bits that are fixed per lane once the row block / k-group is an immediate);
 //   * the row phase handles the wave's 8 rows in ONE pass: 8 lanes x 16 channels per row, so the two LayerNorm
@@ -324,74 +228,75 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_bf16_v2_kernel(const bf16_t* _
         if (tix + gridDim.x < tiles)
             dma_tile_bf16<kC, 8>(x, (tix + gridDim.x) * kRowsPerTile, R, xbuf + (buf ^ 1) * kXBytes, w, lane);
         const char* xt = xbuf + buf * kXBytes;
-        // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element
-        unsigned long long bits = 0ull;
+        // ---- fc1 + b1 + ReLU -> H tile (bf16), one mask bit per element.  Software pipeline over the four 16-row
+        // blocks: the MFMAs of block nb + 1 are issued before the epilogue of block nb (two accumulator sets), so
+        // the epilogue's vector instructions fill the MFMA issue gaps; the bias enters as the accumulators' initial
+        // value; the ReLU bits are taken from the packed bf16 words (2 values per instruction).
+        unsigned bits_lo = 0u, bits_hi = 0u;
         {
             bf16x8 fa[4], fb[4];
+            f32x4 acc_a[3], acc_b[3];
             auto frags = [&](int nb, bf16x8 (&f)[4]) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8*>(xt + nb * (16 * kC * 2) + xf_off[ks]);
             };
-            auto finish = [&](int nb, const f32x4 (&acc1)[3]) {
+            auto mfmas = [&](const bf16x8 (&f)[4], f32x4 (&acc)[3]) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] = f32x4{b1v[i].x, b1v[i].y, b1v[i].z, b1v[i].w};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc[i] = mfma16(wf1[i][ks], f[ks], acc[i]);
+            };
+            auto finish = [&](int nb, const f32x4 (&acc)[3]) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    float4 v = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]) + b1v[i];
-                    const unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-                    bits |= static_cast<unsigned long long>(nib) << (nb * 12 + i * 4);
-                    v = max4(v, f4(0.f));
-                    *reinterpret_cast<u32x2_t*>(htile + nb * (16 * kH * 2) + hw_off[i]) = pack4_bf16(v);
+                    const u32x2_t pv = pack4_bf16(max4(make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), f4(0.f)));
+                    // a positive bf16 half plus 0x7FFF carries into its bit 15: flags at bits 15 / 31 (values 0, 2 of the
+                    // group) and, for the second word, shifted to 14 / 30 (values 1... see ffn_mask4 for the decoding)
+                    const unsigned f0 = (pv[0] + 0x7FFF7FFFu) & 0x80008000u, f1 = (pv[1] + 0x7FFF7FFFu) & 0x80008000u;
+                    const unsigned fl = f0 | (f1 >> 1);
+                    const int g = nb * 3 + i;                    // 12 groups per lane and tile, 7 per word
+                    if (g < 7) bits_lo |= fl >> (2 * g);
+                    else bits_hi |= fl >> (2 * (g - 7));
+                    *reinterpret_cast<u32x2_t*>(htile + nb * (16 * kH * 2) + hw_off[i]) = pv;
                 }
             };
             frags(0, fa);
-#pragma unroll
-            for (int nb = 0; nb < 4; nb += 2) {
-                f32x4 acc1[3];
-                frags(nb + 1, fb);
-                up_mfma<true>(fa, wf1, acc1);
-                __builtin_amdgcn_sched_barrier(0);
-                finish(nb, acc1);
-                if (nb + 2 < 4) frags(nb + 2, fa);
-                up_mfma<true>(fb, wf1, acc1);
-                __builtin_amdgcn_sched_barrier(0);
-                finish(nb + 1, acc1);
-            }
+            frags(1, fb);
+            mfmas(fa, acc_a);
+            mfmas(fb, acc_b);
+            frags(2, fa);
+            finish(0, acc_a);
+            mfmas(fa, acc_a);
+            frags(3, fb);
+            finish(1, acc_b);
+            mfmas(fb, acc_b);
+            finish(2, acc_a);
+            finish(3, acc_b);
         }
+        const unsigned long long bits = static_cast<unsigned long long>(bits_lo) | (static_cast<unsigned long long>(bits_hi) << 32);
         if (SAVE) {
             const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
             relu_bits[bix] = static_cast<unsigned>(bits);
             relu_bits[bix + 1] = static_cast<unsigned>(bits >> 32);
         }
         __syncthreads();
-        // ---- fc2 + b2 + x -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows)
+        // ---- fc2 + b2 + x -> exchange tile (wave w: output channels [16 w, 16 w + 16) of all 64 rows); four
+        // accumulator chains per 16-row block (dependent 16x16x32 MFMAs need ~3 others in between)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const char* hb = htile + nb * (16 * kH * 2);
-            f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
-            bf16x8 h0[4], h1[4];
+            f32x4 ac[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h0[j] = *reinterpret_cast<const bf16x8*>(hb + hf_off[j]);
+            for (int a = 0; a < 3; ++a) {
+                bf16x8 hf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h1[j] = *reinterpret_cast<const bf16x8*>(hb + 256 + hf_off[j]);
+                for (int j = 0; j < 4; ++j) hf[j] = *reinterpret_cast<const bf16x8*>(hb + 256 * a + hf_off[j]);
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                acc_a = mfma16(wf2[j], h0[j], acc_a);
-                acc_b = mfma16(wf2[j + 1], h0[j + 1], acc_b);
+                for (int j = 0; j < 4; ++j) ac[j] = mfma16(wf2[4 * a + j], hf[j], ac[j]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h0[j] = *reinterpret_cast<const bf16x8*>(hb + 512 + hf_off[j]);
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                acc_a = mfma16(wf2[4 + j], h1[j], acc_a);
-                acc_b = mfma16(wf2[4 + j + 1], h1[j + 1], acc_b);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                acc_a = mfma16(wf2[8 + j], h0[j], acc_a);
-                acc_b = mfma16(wf2[8 + j + 1], h0[j + 1], acc_b);
-            }
-            const f32x4 a4 = acc_a + acc_b;
+            const f32x4 a4 = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             const float4 xr = unpack4_bf16(*reinterpret_cast<const u32x2_t*>(xt + nb * (16 * kC * 2) + xr_off));
             *reinterpret_cast<float4*>(zt + nb * (16 * kC * 4) + zw_off) = make_float4(a4[0], a4[1], a4[2], a4[3]) + b2z + xr;
         }
@@ -517,9 +422,10 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
         gemm_up_tile<true, false>(dzt, wfa, lane, [&](int nb, const f32x4 (&acc)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const unsigned mb = static_cast<unsigned>(bits >> (nb * 12 + i * 4));
-                const float4 v = make_float4(mb & 1u ? acc[i][0] : 0.f, mb & 2u ? acc[i][1] : 0.f,
-                                             mb & 4u ? acc[i][2] : 0.f, mb & 8u ? acc[i][3] : 0.f);
+                const int g = nb * 3 + i;                     // layout written by the forward kernel (12 groups, 7 per word)
+                const unsigned t = g < 7 ? static_cast<unsigned>(bits) << (2 * g) : static_cast<unsigned>(bits >> 32) << (2 * (g - 7));
+                const float4 v = make_float4(t & 0x8000u ? acc[i][0] : 0.f, t & 0x80000000u ? acc[i][1] : 0.f,
+                                             t & 0x4000u ? acc[i][2] : 0.f, t & 0x40000000u ? acc[i][3] : 0.f);
                 *reinterpret_cast<u32x2_t*>(dht + tile_off(16 * nb + (lane & 15), 48 * w + 16 * i + 4 * (lane >> 4), kH)) =
                     pack4_bf16(v);
             }
@@ -744,17 +650,7 @@ extern "C" int dg_ffn_ln_fwd_bf16(const void* x, const void* packed, const float
     if (R < 0) return fail(DG_E_SHAPE, "dg_ffn_ln_fwd_bf16: negative row count");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const bool plain = getenv("DG_FFN_FWD") && strcmp(getenv("DG_FFN_FWD"), "plain") == 0;
     ProfScope prof(DG_K_FFN, stream);
-    if (plain) {
-        constexpr int lds = 2 * kXBytes + kHBytes + kZBytes;
-        DG_OPT_IN_LDS((&ffn_fwd_bf16_kernel), lds);
-        hipLaunchKernelGGL(ffn_fwd_bf16_kernel, dim3(ffn_grid(R)), dim3(512), lds, stream, static_cast<const bf16_t*>(x),
-                           static_cast<const bf16x8*>(packed), b1, b2, gamma, beta, static_cast<bf16_t*>(y),
-                           static_cast<bf16_t*>(pre), mean, rstd, relu_bits, R, eps,
-                           getenv("DG_FFN_DBG") ? atoi(getenv("DG_FFN_DBG")) : 0);
-        return check_launch("dg_ffn_ln_fwd_bf16");
-    }
     // lean kernel: stores whole 64-row tiles -- y, pre_ln, mean, rstd must hold dg_ffn_bf16_padded_rows(R) rows
     constexpr int lds = 2 * kXBytes + kHBytes + kZBytes + 1024;
     const bool save = pre != nullptr && relu_bits != nullptr;
