@@ -398,6 +398,15 @@ constexpr int kX6Pitch = 272;                 // bytes per LDS row of one bf16 p
 constexpr int kX6Plane = kTR * kX6Pitch;      // one plane of a 64-row chunk
 constexpr int kX6Buf = 3 * kX6Plane;          // three planes (also holds the 64 x 128 fp32 exchange tile)
 constexpr int kX6Lds = 2 * kX6Buf;            // double-buffered
+// fp16 two-plane variant (K = 128 kernels): two planes, then the 64 inverse row scales of the chunk
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kH3Plane = kTR * kX6Pitch;      // same row pitch as the bf16 planes
+constexpr int kH3Rs = 2 * kH3Plane;           // byte offset of float inv_row_scale[64] (past the 32 KiB exchange tile)
+constexpr int kH3Buf = kH3Rs + kTR * 4;
+constexpr int kH3Lds = 2 * kH3Buf;
+static_assert(kH3Rs >= kTR * 128 * 4, "the fp32 exchange tile must not reach the row scales");
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = static_cast<__bf16>(x);
@@ -427,6 +436,80 @@ __global__ void pack_weight_x6_kernel(const float* __restrict__ w, bf16x8* __res
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) p[(static_cast<size_t>(t * k_steps + ks) * 3 + pl) * 64 + lane] = out[pl];
+}
+
+// ---- fp16 x 3: power-of-two scaled two-plane split -------------------------------------------------------
+// A row a (and a weight column w) is multiplied by a power of two that brings its largest magnitude into
+// [2^14, 2^15) -- exact -- and split as hi = fp16(x), lo = fp16(x - hi): the residual is exact in fp32 and
+// hi + lo carries 22 significand bits of every element that is within 2^-18 of the row maximum (smaller
+// elements lose bits only below 2^-39 of the maximum).  a.w ~= hi.hi + hi.lo + lo.hi with fp32
+// accumulation (the dropped lo.lo term is 2^-22 relative): three MFMAs per product instead of the six of
+// the bf16 three-plane split, two LDS planes instead of three, and the same fp32-class error (measured
+// against fp64 in tests/test_hip_kernels.py).  The epilogue multiplies by the inverse scales.
+__device__ __forceinline__ unsigned scale_exponent(float absmax) {   // biased exponent, clamped away from 0
+    const unsigned e = __float_as_uint(absmax) >> 23;
+    return e < 15u ? 15u : e;
+}
+__device__ __forceinline__ float scale_of(unsigned e) { return __uint_as_float((268u - e) << 23); }      // 2^(14 - (e - 127))
+__device__ __forceinline__ float inv_scale_of(unsigned e) { return __uint_as_float((e - 14u) << 23); }
+__device__ __forceinline__ void split_h2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    const f32x2 xs = {x0 * s, x1 * s};
+    const f16x2 h = __builtin_convertvector(xs, f16x2);
+    const f32x2 r = xs - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+// unsigned max steps (the ordering of |float| bit patterns): 0 is the identity, so the DPP move folds into v_max_u32
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_umax_step(unsigned x) {
+    const unsigned moved = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xF, 0xF, true));
+    return x > moved ? x : moved;
+}
+// biased exponent of max |.| over the float4s of the 32 lanes of a half-wave (one 128-wide row), in every lane
+__device__ __forceinline__ unsigned half_absmax_exponent(const float4& v) {
+    const unsigned m = 0x7FFFFFFFu;
+    const unsigned a = __float_as_uint(v.x) & m, b = __float_as_uint(v.y) & m, c = __float_as_uint(v.z) & m,
+                   d = __float_as_uint(v.w) & m;
+    unsigned x = max(max(a, b), max(c, d));
+    x = dpp_umax_step<0xB1>(x);
+    x = dpp_umax_step<0x4E>(x);
+    x = dpp_umax_step<0x141>(x);
+    x = dpp_umax_step<0x140>(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x = r[0] > r[1] ? r[0] : r[1];
+    const unsigned e = x >> 23;
+    return e < 15u ? 15u : e;
+}
+
+// packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs]
+__global__ void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows, int cols, int mode,
+                                      int n_tiles, int k_steps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one (slab, k-step, lane)
+    if (idx >= n_tiles * k_steps * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % k_steps, t = (idx >> 6) / k_steps;
+    const int n = 32 * t + (lane & 31);
+    const int n_out = mode == 0 ? rows : cols, kdim = mode == 0 ? cols : rows;
+    auto at = [&](int k) -> float {
+        if (n >= n_out || k >= kdim) return 0.f;
+        return mode == 0 ? w[static_cast<size_t>(n) * cols + k] : w[static_cast<size_t>(k) * cols + n];
+    };
+    float mx = 0.f;
+    for (int k = 0; k < kdim; ++k) mx = fmaxf(mx, fabsf(at(k)));
+    const unsigned e = scale_exponent(mx);
+    const float sc = scale_of(e);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = at(ks * 16 + 8 * (lane >> 5) + j) * sc;
+        hi[j] = static_cast<_Float16>(xs);
+        lo[j] = static_cast<_Float16>(xs - static_cast<float>(hi[j]));
+    }
+    p[(static_cast<size_t>(t * k_steps + ks) * 2 + 0) * 64 + lane] = hi;
+    p[(static_cast<size_t>(t * k_steps + ks) * 2 + 1) * 64 + lane] = lo;
+    if (ks == 0 && lane < 32)
+        reinterpret_cast<float*>(p + static_cast<size_t>(n_tiles) * k_steps * 2 * 64)[n] = inv_scale_of(e);
 }
 
 // exact three-way split of a float4 into bf16 planes by truncation: h = top 16 bits of x,
@@ -459,7 +542,7 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 // the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
 // per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
 template <int KC, int NG, bool EXCH, int NC = 4>
-__global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __restrict__ a, const bf16x8* __restrict__ packed,
+__global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
     // NC = 6 (N = 384 only): six consumer waves = six resident 32-column slabs (one 192-column half of the
     // output per blockIdx.y), two producer waves; no B-fragment stream from L2, the A tile is read twice.
@@ -467,9 +550,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
     constexpr int K = KC * 128, KS = KC * 8, N = NC == 6 ? 384 : 128 * NG, UPT = KC * NG;
     constexpr int SLABS = NC == 6 ? 12 : 4 * NG;   // 32-column slabs of the whole output (bit-mask layout)
     static_assert(NC == 4 || (NC == 6 && KC == 1 && NG == 1 && !EXCH), "6 consumers: resident-B 128 -> 384 only");
-    static_assert(KC == 1 || NG == 1, "either the contraction or the output is chunked, not both");
+    static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* lds = smem_raw;                              // planes[2][3][64 rows][272 B]
+    char* lds = smem_raw;                              // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
@@ -503,15 +586,19 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
             }
         };
         auto write = [&](const float4 (&set)[PFN], int64_t chunk) {   // chunks past the end land in the idle buffer
-            char* pl = lds + (chunk & 1) * kX6Buf;
+            char* pl = lds + (chunk & 1) * kH3Buf;
 #pragma unroll
             for (int i = 0; i < PFN; ++i) {
-                const int L = pt + 64 * NM * i, r = L >> 5, c4 = L & 31;
-                u32x2 h, m, l;
-                split4(set[i], h, m, l);
-                *reinterpret_cast<u32x2*>(pl + 0 * kX6Plane + r * kX6Pitch + c4 * 8) = h;
-                *reinterpret_cast<u32x2*>(pl + 1 * kX6Plane + r * kX6Pitch + c4 * 8) = m;
-                *reinterpret_cast<u32x2*>(pl + 2 * kX6Plane + r * kX6Pitch + c4 * 8) = l;
+                const int L = pt + 64 * NM * i, r = L >> 5, c4 = L & 31;   // the 32 lanes of a half-wave hold one row
+                const unsigned e = half_absmax_exponent(set[i]);
+                const float sc = scale_of(e);
+                unsigned h0, h1, l0, l1;
+                split_h2(set[i].x, set[i].y, sc, h0, l0);
+                split_h2(set[i].z, set[i].w, sc, h1, l1);
+                const u32x2 h = {h0, h1}, l = {l0, l1};
+                *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
+                *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
+                if (c4 == 0) *reinterpret_cast<float*>(pl + kH3Rs + r * 4) = inv_scale_of(e);
             }
         };
         auto end_of_iteration = [&](int64_t c) {
@@ -544,20 +631,25 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
 
     // ---------------------------------------------------------------------- consumers
     const unsigned relu_sel = ep.relu ? 0xFFFFFFFFu : 0u;
-    // B fragments of the current unit in two halves (k-steps 0-3 and 4-7, 48 VGPRs each).  When the
+    // B fragments of the current unit in two halves (k-steps 0-3 and 4-7, 32 VGPRs each).  When the
     // unit changes (K = 384 or N = 384) the halves form a ring: half 1 of this unit is requested from L2
     // at the start of the unit, half 0 of the next unit after the first four k-steps.
-    bf16x8 bset[2][3][4];
-    auto load_b = [&](bf16x8 (&bfr)[3][4], int g, int kc, int h) {
-        const bf16x8* wp = packed + static_cast<size_t>(NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) * KS * 3 * 64 + lane;
+    f16x8 bset[2][2][4];
+    auto load_b = [&](f16x8 (&bfr)[2][4], int g, int kc, int h) {
+        const f16x8* wp = packed + static_cast<size_t>(NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) * KS * 2 * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bfr[p][ks] = wp[((kc * 8 + 4 * h + ks) * 3 + p) * 64];
+            for (int p = 0; p < 2; ++p) bfr[p][ks] = wp[((kc * 8 + 4 * h + ks) * 2 + p) * 64];
     };
-    float bias_g[NG];
+    const float* inv_cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(SLABS) * KS * 2 * 64);
+    float bias_g[NG], cs_g[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) bias_g[g] = ep.bias ? ep.bias[32 * (NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) + col] : 0.f;
+    for (int g = 0; g < NG; ++g) {
+        const int n = 32 * (NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) + col;
+        bias_g[g] = ep.bias ? ep.bias[n] : 0.f;
+        cs_g[g] = inv_cs[n];
+    }
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
     f32x16 acc[2];
     // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
@@ -583,17 +675,25 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
                 res[it] = ld4(ep.residual + rrow * 128 + col * 4);
             }
         }
-        const char* pl = lds + (chunk & 1) * kX6Buf;
+        const char* pl = lds + (chunk & 1) * kH3Buf;
         // fragments of step ks + 1 are requested before the MFMAs of step ks; consecutive MFMAs alternate
         // between the two row blocks (independent accumulators)
-        bf16x8 af[2][2][3];
-        auto frags = [&](int ks, bf16x8 (&dst)[2][3]) {
+        f16x8 af[2][2][2];
+        auto frags = [&](int ks, f16x8 (&dst)[2][2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    dst[m][p] = *reinterpret_cast<const bf16x8*>(pl + p * kX6Plane + (32 * m + col) * kX6Pitch +
-                                                                 (ks * 16 + 8 * half) * 2);
+                for (int p = 0; p < 2; ++p)
+                    dst[m][p] = *reinterpret_cast<const f16x8*>(pl + p * kH3Plane + (32 * m + col) * kX6Pitch +
+                                                                (ks * 16 + 8 * half) * 2);
+        };
+        // inverse scales of this lane's accumulator rows: 32 m + 8 q + 4 half + (0..3), times the column's
+        auto row_scales = [&](float4 (&rs)[2][4], float cs) {
+            const float* rsp = reinterpret_cast<const float*>(pl + kH3Rs);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs[m][q] = cs * ld4(rsp + 32 * m + 8 * q + 4 * half);
         };
         frags(0, af[0]);
 #pragma unroll
@@ -603,14 +703,14 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
                 const int un = (pos_kc * NG + pos_g + 1) % UPT;   // next position: same tile, or the next tile's first
                 load_b(bset[0], NG > 1 ? (un + rot) % NG : 0, KC > 1 ? (un + rot) % KC : 0, 0);
             }
-            const bf16x8(&f)[2][3] = af[ks & 1];
-            const bf16x8(&bfr)[3][4] = bset[ks >> 2];
-            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+            const f16x8(&f)[2][2] = af[ks & 1];
+            const f16x8(&bfr)[2][4] = bset[ks >> 2];
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // lo.hi, hi.lo, hi.hi: smallest terms first
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[m][TA[t]], bfr[TB[t]][ks & 3], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[TB[t]][ks & 3], acc[m], 0, 0, 0);
         }
         if (!EXCH && kc == KC - 1) {
             // direct epilogue of column group g from the accumulator layout
@@ -623,11 +723,13 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
             if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
             float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
             float out[2][16];
+            float4 rs[2][4];
+            row_scales(rs, cs_g[g]);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    float v = acc[m][reg] + bias;
+                    float v = fmaf(acc[m][reg], comp(rs[m][reg >> 2], reg & 3), bias);
                     if (BITS) {
                         newbits |= (v > 0.f ? 1u : 0u) << (16 * m + reg);
                         v = __uint_as_float((__float_as_uint(fmaxf(v, 0.f)) & relu_sel) | (__float_as_uint(v) & ~relu_sel));
@@ -657,15 +759,17 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_kernel(const float* __rest
         }
         if (EXCH && kc == KC - 1) {
             // exchange through the consumed planes so that each half-wave finalises whole 512-byte rows
-            float* ex = reinterpret_cast<float*>(lds + (chunk & 1) * kX6Buf);
+            float* ex = reinterpret_cast<float*>(lds + (chunk & 1) * kH3Buf);
             const float bias = bias_g[0];
+            float4 rs[2][4];
+            row_scales(rs, cs_g[0]);
             __syncthreads();   // every consumer has finished its fragment reads
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    float v = acc[m][reg] + bias;
+                    float v = fmaf(acc[m][reg], comp(rs[m][reg >> 2], reg & 3), bias);
                     if (ep.relu) v = fmaxf(v, 0.f);
                     ex[rr * 128 + 32 * w + col] = v;
                 }
@@ -1031,7 +1135,8 @@ static bool use_x6() {
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract) {
     if (n_out < 1 || k_contract < 1) return 0;
     const size_t nt = (n_out + 31) / 32, kc = (k_contract + 127) / 128;
-    if (use_x6()) return nt * kc * 8 * 3 * 64 * 4;   // [slab][k-step][plane][lane] x 8 bf16
+    if (use_x6() && kc == 1) return nt * 8 * 2 * 64 * 4 + nt * 32;   // fp16x3: [slab][k-step][plane][lane] x 8 fp16, inv_col_scale
+    if (use_x6()) return nt * kc * 8 * 3 * 64 * 4;   // bf16x6: [slab][k-step][plane][lane] x 8 bf16
     return nt * kc * 16 * 64 * 4;
 }
 
@@ -1040,6 +1145,12 @@ int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mod
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
+    if (use_x6() && kc == 1) {
+        const int total3 = nt * 8 * 64;
+        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3((total3 + 255) / 256), dim3(256), 0,
+                           static_cast<hipStream_t>(stream_), w, reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt, 8);
+        return check_launch("dg_row_gemm_pack");
+    }
     if (use_x6()) {
         const int total6 = nt * kc * 8 * 64;
         hipLaunchKernelGGL(pack_weight_x6_kernel, dim3((total6 + 255) / 256), dim3(256), 0,
@@ -1089,19 +1200,19 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         (void)ng;
 #define LAUNCH6(KC_, NG_, EX_)                                                                                     \
     {                                                                                                              \
-        DG_OPT_IN_LDS((&row_gemm_x6_kernel<KC_, NG_, EX_>), kX6Lds);                               \
-        hipLaunchKernelGGL((row_gemm_x6_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kX6Lds, stream, a,           \
-                           reinterpret_cast<const bf16x8*>(packed), y, R, ep);                                     \
+        DG_OPT_IN_LDS((&row_gemm_h3_kernel<KC_, NG_, EX_>), kH3Lds);                                               \
+        hipLaunchKernelGGL((row_gemm_h3_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kH3Lds, stream, a,          \
+                           reinterpret_cast<const f16x8*>(packed), y, R, ep);                                      \
     }
         static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
         if (K == 128 && N == 384 && split_n) {   // two 192-column halves, B resident in six consumer waves
-            DG_OPT_IN_LDS((&row_gemm_x6_kernel<1, 1, false, 6>), kX6Lds);
-            hipLaunchKernelGGL((row_gemm_x6_kernel<1, 1, false, 6>), dim3(seqs, 2), dim3(512), kX6Lds, stream, a,
-                               reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+            DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), kH3Lds);
+            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs, 2), dim3(512), kH3Lds, stream, a,
+                               reinterpret_cast<const f16x8*>(packed), y, R, ep);
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
         else if (K == 128) LAUNCH6(1, 1, false)
-        else if (!(getenv("DG_GEMM_K384") && strcmp(getenv("DG_GEMM_K384"), "stream") == 0)) {
+        else {
             constexpr int lds384 = 2 * kX6Buf + kTR * 128 * 4;
             DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<true>), lds384);
             DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<false>), lds384);
@@ -1111,8 +1222,7 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
             else
                 hipLaunchKernelGGL(row_gemm_x6_k384_kernel<false>, dim3(seqs), dim3(512), lds384, stream, a,
                                    reinterpret_cast<const bf16x8*>(packed), y, R, ep);
-        } else if (exch) LAUNCH6(3, 1, true)
-        else LAUNCH6(3, 1, false)
+        }
 #undef LAUNCH6
         return check_launch("dg_row_gemm");
     }
