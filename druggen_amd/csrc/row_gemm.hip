@@ -483,32 +483,46 @@ __device__ __forceinline__ unsigned half_absmax_exponent(const float4& v) {
     return e < 15u ? 15u : e;
 }
 
-// packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs]
-__global__ void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows, int cols, int mode,
-                                      int n_tiles, int k_steps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one (slab, k-step, lane)
-    if (idx >= n_tiles * k_steps * 64) return;
-    const int lane = idx & 63, ks = (idx >> 6) % k_steps, t = (idx >> 6) / k_steps;
-    const int n = 32 * t + (lane & 31);
+// packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs] (one scale
+// per output column over the whole contraction).  One 512-thread workgroup per (32-column slab, 128-wide k
+// chunk): thread = (k-step, lane) keeps its 8 values in registers while the column maxima are reduced through LDS.
+__global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows,
+                                                             int cols, int mode, int n_tiles) {
+    __shared__ unsigned part[16][32];
+    const int t = blockIdx.x, kcb = blockIdx.y, kchunks = gridDim.y, k_steps = 8 * kchunks;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int c = lane & 31, n = 32 * t + c;
     const int n_out = mode == 0 ? rows : cols, kdim = mode == 0 ? cols : rows;
     auto at = [&](int k) -> float {
         if (n >= n_out || k >= kdim) return 0.f;
         return mode == 0 ? w[static_cast<size_t>(n) * cols + k] : w[static_cast<size_t>(k) * cols + n];
     };
-    float mx = 0.f;
-    for (int k = 0; k < kdim; ++k) mx = fmaxf(mx, fabsf(at(k)));
-    const unsigned e = scale_exponent(mx);
+    float v[8];
+    unsigned mx = 0;
+    for (int kc = 0; kc < kchunks; ++kc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = at(kc * 128 + ks * 16 + 8 * (lane >> 5) + j);
+            if (kc == kcb) v[j] = x;
+            mx = max(mx, __float_as_uint(x) & 0x7FFFFFFFu);
+        }
+    part[2 * ks + (lane >> 5)][c] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = max(mx, part[i][c]);
+    const unsigned e = scale_exponent(__uint_as_float(mx));
     const float sc = scale_of(e);
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float xs = at(ks * 16 + 8 * (lane >> 5) + j) * sc;
+        const float xs = v[j] * sc;
         hi[j] = static_cast<_Float16>(xs);
         lo[j] = static_cast<_Float16>(xs - static_cast<float>(hi[j]));
     }
-    p[(static_cast<size_t>(t * k_steps + ks) * 2 + 0) * 64 + lane] = hi;
-    p[(static_cast<size_t>(t * k_steps + ks) * 2 + 1) * 64 + lane] = lo;
-    if (ks == 0 && lane < 32)
+    const size_t slot = static_cast<size_t>(t) * k_steps + 8 * kcb + ks;
+    p[(slot * 2 + 0) * 64 + lane] = hi;
+    p[(slot * 2 + 1) * 64 + lane] = lo;
+    if (kcb == 0 && ks == 0 && lane < 32)
         reinterpret_cast<float*>(p + static_cast<size_t>(n_tiles) * k_steps * 2 * 64)[n] = inv_scale_of(e);
 }
 
@@ -857,21 +871,21 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 //     planes, and the finished tile's epilogue (exchange tile in LDS -> residual / LayerNorm -> 512-byte
 //     row stores).  Their loop is one straight line per tile pair so that hipcc can count loads in flight.
 // Barriers: B(c) ends every chunk; A(c) precedes the exchange-tile write of a chunk that completes a tile.
-__device__ __forceinline__ void load_b128_async(bf16x8& dst, const bf16x8* p) {
+__device__ __forceinline__ void load_b128_async(f16x8& dst, const f16x8* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void wait_b_refill(bf16x8& b0, bf16x8& b1, bf16x8& b2) {
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b0), "+v"(b1), "+v"(b2) : "n"(N));
+__device__ __forceinline__ void wait_b_refill(f16x8& b0, f16x8& b1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
 }
 
 template <bool EXCH>
-__global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* __restrict__ a, const bf16x8* __restrict__ packed,
+__global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                                   float* __restrict__ y, int64_t R, Epilogue ep) {
     constexpr int KC = 3, K = 384, KS = 24;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* lds = smem_raw;                                          // planes[2][3][64 rows][272 B]
-    float* ex = reinterpret_cast<float*>(smem_raw + 2 * kX6Buf);   // exchange tile [64][128] fp32
+    char* lds = smem_raw;                                          // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
+    float* ex = reinterpret_cast<float*>(smem_raw + 2 * kH3Buf);   // exchange tile [64][128] fp32
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
@@ -911,15 +925,19 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
             }
         };
         auto write = [&](const float4 (&set)[8], int c) {   // chunks past the end land in the idle buffer
-            char* pl = lds + (c & 1) * kX6Buf;
+            char* pl = lds + (c & 1) * kH3Buf;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {   // the scale of a row is per 128-wide chunk: each chunk has its own accumulation
                 const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
-                u32x2 h, m, l;
-                split4(set[i], h, m, l);
-                *reinterpret_cast<u32x2*>(pl + 0 * kX6Plane + r * kX6Pitch + c4 * 8) = h;
-                *reinterpret_cast<u32x2*>(pl + 1 * kX6Plane + r * kX6Pitch + c4 * 8) = m;
-                *reinterpret_cast<u32x2*>(pl + 2 * kX6Plane + r * kX6Pitch + c4 * 8) = l;
+                const unsigned e = half_absmax_exponent(set[i]);
+                const float sc = scale_of(e);
+                unsigned h0, h1, l0, l1;
+                split_h2(set[i].x, set[i].y, sc, h0, l0);
+                split_h2(set[i].z, set[i].w, sc, h1, l1);
+                const u32x2 h = {h0, h1}, l = {l0, l1};
+                *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
+                *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
+                if (c4 == 0) *reinterpret_cast<float*>(pl + kH3Rs + r * 4) = inv_scale_of(e);
             }
         };
         float4 res[8];   // residual rows of the tile being finished: pw * 16 + it * 2 + half
@@ -1024,16 +1042,17 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
     }
 
     // -------------------------------------------------------------------------- consumers
-    bf16x8 bfr[3][8];
-    auto b_ptr = [&](int pos) { return packed + (static_cast<size_t>(w) * KS + ((pos + rot) % KC) * 8) * 3 * 64 + lane; };
+    f16x8 bfr[2][8];
+    auto b_ptr = [&](int pos) { return packed + (static_cast<size_t>(w) * KS + ((pos + rot) % KC) * 8) * 2 * 64 + lane; };
     {
-        const bf16x8* b0 = b_ptr(0);
+        const f16x8* b0 = b_ptr(0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bfr[p][ks] = b0[(ks * 3 + p) * 64];
+            for (int p = 0; p < 2; ++p) bfr[p][ks] = b0[(ks * 2 + p) * 64];
     }
     const float bias = ep.bias ? ep.bias[32 * w + col] : 0.f;
+    const float cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(4) * KS * 2 * 64)[32 * w + col];
     f32x16 accs[2][2];
     int chunk = 0;
     __syncthreads();   // chunk 0 is in planes[0]
@@ -1045,44 +1064,62 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
         }
-        const bf16x8* bnext = b_ptr((pos + 1) % KC);
-        const char* pl = lds + (chunk & 1) * kX6Buf;
-        bf16x8 af[2][2][3];
-        auto frags = [&](int ks, bf16x8 (&dst)[2][3]) {
+        const f16x8* bnext = b_ptr((pos + 1) % KC);
+        const char* pl = lds + (chunk & 1) * kH3Buf;
+        f16x8 af[2][2][2];
+        auto frags = [&](int ks, f16x8 (&dst)[2][2]) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    dst[m][p] = *reinterpret_cast<const bf16x8*>(pl + p * kX6Plane + (32 * m + col) * kX6Pitch +
-                                                                 (ks * 16 + 8 * half) * 2);
+                for (int p = 0; p < 2; ++p)
+                    dst[m][p] = *reinterpret_cast<const f16x8*>(pl + p * kH3Plane + (32 * m + col) * kX6Pitch +
+                                                                (ks * 16 + 8 * half) * 2);
         };
+        f32x16 part[2];   // this chunk's products; folded into `acc` with the chunk's inverse row scales
         frags(0, af[0]);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             if (ks + 1 < 8) frags(ks + 1, af[(ks + 1) & 1]);
             if (!SECOND) {
                 switch (ks) {
-                    case 0: wait_b_refill<21>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 1: wait_b_refill<18>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 2: wait_b_refill<15>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 3: wait_b_refill<12>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 4: wait_b_refill<9>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 5: wait_b_refill<6>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    case 6: wait_b_refill<3>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
-                    default: wait_b_refill<0>(bfr[0][ks], bfr[1][ks], bfr[2][ks]); break;
+                    case 0: wait_b_refill<14>(bfr[0][ks], bfr[1][ks]); break;
+                    case 1: wait_b_refill<12>(bfr[0][ks], bfr[1][ks]); break;
+                    case 2: wait_b_refill<10>(bfr[0][ks], bfr[1][ks]); break;
+                    case 3: wait_b_refill<8>(bfr[0][ks], bfr[1][ks]); break;
+                    case 4: wait_b_refill<6>(bfr[0][ks], bfr[1][ks]); break;
+                    case 5: wait_b_refill<4>(bfr[0][ks], bfr[1][ks]); break;
+                    case 6: wait_b_refill<2>(bfr[0][ks], bfr[1][ks]); break;
+                    default: wait_b_refill<0>(bfr[0][ks], bfr[1][ks]); break;
                 }
             }
-            const bf16x8(&f)[2][3] = af[ks & 1];
-            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+            const f16x8(&f)[2][2] = af[ks & 1];
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // lo.hi, hi.lo, hi.hi: smallest terms first
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[m][TA[t]], bfr[TB[t]][ks], acc[m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) {
+                    if (ks == 0 && t == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        part[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[TB[t]][ks], zero, 0, 0, 0);
+                    } else {
+                        part[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[TB[t]][ks], part[m], 0, 0, 0);
+                    }
+                }
             if (SECOND) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) load_b128_async(bfr[p][ks], bnext + (ks * 3 + p) * 64);
+                for (int p = 0; p < 2; ++p) load_b128_async(bfr[p][ks], bnext + (ks * 2 + p) * 64);
             }
+        }
+        {
+            const float* rsp = reinterpret_cast<const float*>(pl + kH3Rs);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 r4 = ld4(rsp + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][4 * q + i] = fmaf(part[m][4 * q + i], comp(r4, i), acc[m][4 * q + i]);
+                }
         }
         if (pos == KC - 1) {
             __syncthreads();   // A: the movers have finished with the previous exchange tile
@@ -1091,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    float v = acc[m][reg] + bias;
+                    float v = fmaf(acc[m][reg], cs, bias);
                     if (ep.relu) v = fmaxf(v, 0.f);
                     ex[rr * 128 + 32 * w + col] = v;
                 }
@@ -1111,11 +1148,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_x6_k384_kernel(const float* _
         for (int pos = 0; pos < KC; ++pos) {
             body(pos, accs[0], std::false_type{});
             if (pos + 1 < KC) {   // no partner tile: refill between the units
-                const bf16x8* bnext = b_ptr(pos + 1);
+                const f16x8* bnext = b_ptr(pos + 1);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) load_b128_async(bfr[q][ks], bnext + (ks * 3 + q) * 64);
+                    for (int q = 0; q < 2; ++q) load_b128_async(bfr[q][ks], bnext + (ks * 2 + q) * 64);
             }
         }
     }
@@ -1135,8 +1172,7 @@ static bool use_x6() {
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract) {
     if (n_out < 1 || k_contract < 1) return 0;
     const size_t nt = (n_out + 31) / 32, kc = (k_contract + 127) / 128;
-    if (use_x6() && kc == 1) return nt * 8 * 2 * 64 * 4 + nt * 32;   // fp16x3: [slab][k-step][plane][lane] x 8 fp16, inv_col_scale
-    if (use_x6()) return nt * kc * 8 * 3 * 64 * 4;   // bf16x6: [slab][k-step][plane][lane] x 8 bf16
+    if (use_x6()) return nt * kc * 8 * 2 * 64 * 4 + nt * 32;   // fp16x3: [slab][k-step][plane][lane] x 8 fp16, inv_col_scale
     return nt * kc * 16 * 64 * 4;
 }
 
@@ -1145,17 +1181,9 @@ int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mod
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
-    if (use_x6() && kc == 1) {
-        const int total3 = nt * 8 * 64;
-        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3((total3 + 255) / 256), dim3(256), 0,
-                           static_cast<hipStream_t>(stream_), w, reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt, 8);
-        return check_launch("dg_row_gemm_pack");
-    }
     if (use_x6()) {
-        const int total6 = nt * kc * 8 * 64;
-        hipLaunchKernelGGL(pack_weight_x6_kernel, dim3((total6 + 255) / 256), dim3(256), 0,
-                           static_cast<hipStream_t>(stream_), w, reinterpret_cast<bf16x8*>(packed), rows, cols, mode, nt,
-                           kc * 8);
+        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3(nt, kc), dim3(512), 0, static_cast<hipStream_t>(stream_), w,
+                           reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt);
         return check_launch("dg_row_gemm_pack");
     }
     const int total = nt * kc * 16 * 64;
@@ -1213,15 +1241,15 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
         else if (K == 128) LAUNCH6(1, 1, false)
         else {
-            constexpr int lds384 = 2 * kX6Buf + kTR * 128 * 4;
-            DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<true>), lds384);
-            DG_OPT_IN_LDS((&row_gemm_x6_k384_kernel<false>), lds384);
+            constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;
+            DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<true>), lds384);
+            DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<false>), lds384);
             if (exch)
-                hipLaunchKernelGGL(row_gemm_x6_k384_kernel<true>, dim3(seqs), dim3(512), lds384, stream, a,
-                                   reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+                hipLaunchKernelGGL(row_gemm_h3_k384_kernel<true>, dim3(seqs), dim3(512), lds384, stream, a,
+                                   reinterpret_cast<const f16x8*>(packed), y, R, ep);
             else
-                hipLaunchKernelGGL(row_gemm_x6_k384_kernel<false>, dim3(seqs), dim3(512), lds384, stream, a,
-                                   reinterpret_cast<const bf16x8*>(packed), y, R, ep);
+                hipLaunchKernelGGL(row_gemm_h3_k384_kernel<false>, dim3(seqs), dim3(512), lds384, stream, a,
+                                   reinterpret_cast<const f16x8*>(packed), y, R, ep);
         }
 #undef LAUNCH6
         return check_launch("dg_row_gemm");
