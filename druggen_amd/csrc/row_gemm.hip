@@ -558,11 +558,13 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 template <int KC, int NG, bool EXCH, int NC = 4>
 __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
-    // NC = 6 (N = 384 only): six consumer waves = six resident 32-column slabs (one 192-column half of the
-    // output per blockIdx.y), two producer waves; no B-fragment stream from L2, the A tile is read twice.
+    // NC = 6 (N = 384 only): six consumer waves, each with two resident 32-column slabs (w and w + 6: 128 VGPRs
+    // of fp16 fragments), two producer waves: no B-fragment stream from L2, the A tile is read once and every
+    // A fragment read from LDS feeds two slabs.
     constexpr int NM = 8 - NC, PFN = 2048 / (64 * NM);   // producer waves, float4 per producer thread and chunk
     constexpr int K = KC * 128, KS = KC * 8, N = NC == 6 ? 384 : 128 * NG, UPT = KC * NG;
     constexpr int SLABS = NC == 6 ? 12 : 4 * NG;   // 32-column slabs of the whole output (bit-mask layout)
+    constexpr int NS = NC == 6 ? 2 : 1;            // slabs per consumer wave
     static_assert(NC == 4 || (NC == 6 && KC == 1 && NG == 1 && !EXCH), "6 consumers: resident-B 128 -> 384 only");
     static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -648,24 +650,30 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     // B fragments of the current unit in two halves (k-steps 0-3 and 4-7, 32 VGPRs each).  When the
     // unit changes (K = 384 or N = 384) the halves form a ring: half 1 of this unit is requested from L2
     // at the start of the unit, half 0 of the next unit after the first four k-steps.
-    f16x8 bset[2][2][4];
-    auto load_b = [&](f16x8 (&bfr)[2][4], int g, int kc, int h) {
-        const f16x8* wp = packed + static_cast<size_t>(NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) * KS * 2 * 64 + lane;
+    f16x8 bset[2][NS][2][4];
+    auto slab_of = [&](int g, int s) { return NC == 6 ? w + 6 * s : 4 * g + w; };
+    auto load_b = [&](f16x8 (&bfr)[NS][2][4], int g, int kc, int h) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int s = 0; s < NS; ++s) {
+            const f16x8* wp = packed + static_cast<size_t>(slab_of(g, s)) * KS * 2 * 64 + lane;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bfr[p][ks] = wp[((kc * 8 + 4 * h + ks) * 2 + p) * 64];
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bfr[s][p][ks] = wp[((kc * 8 + 4 * h + ks) * 2 + p) * 64];
+        }
     };
     const float* inv_cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(SLABS) * KS * 2 * 64);
-    float bias_g[NG], cs_g[NG];
+    float bias_g[NG * NS], cs_g[NG * NS];   // NS > 1 only with NG == 1
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n = 32 * (NC == 6 ? 6 * blockIdx.y + w : 4 * g + w) + col;
-        bias_g[g] = ep.bias ? ep.bias[n] : 0.f;
-        cs_g[g] = inv_cs[n];
-    }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = 32 * slab_of(g, s) + col;
+            bias_g[g * NS + s] = ep.bias ? ep.bias[n] : 0.f;
+            cs_g[g * NS + s] = inv_cs[n];
+        }
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
-    f32x16 acc[2];
+    f32x16 acc[NS][2];
     // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
     // contraction is complete; `bnext` receives the B fragments of the following unit meanwhile
     auto unit = [&](int64_t ti, int pos_kc, int pos_g) {   // positions within the tile; values are rotated
@@ -677,9 +685,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         if (UPT > 1) load_b(bset[1], g, kcv, 1);
         if (kc == 0) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[s][m][i] = 0.f;
         }
         if (EXCH && kc == KC - 1 && ep.residual) {
 #pragma unroll
@@ -702,12 +712,10 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                                                                 (ks * 16 + 8 * half) * 2);
         };
         // inverse scales of this lane's accumulator rows: 32 m + 8 q + 4 half + (0..3), times the column's
-        auto row_scales = [&](float4 (&rs)[2][4], float cs) {
+        auto row_scales = [&](float4 (&rs)[4], int m, float cs) {
             const float* rsp = reinterpret_cast<const float*>(pl + kH3Rs);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs[m][q] = cs * ld4(rsp + 32 * m + 8 * q + 4 * half);
+            for (int q = 0; q < 4; ++q) rs[q] = cs * ld4(rsp + 32 * m + 8 * q + 4 * half);
         };
         frags(0, af[0]);
 #pragma unroll
@@ -718,72 +726,76 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                 load_b(bset[0], NG > 1 ? (un + rot) % NG : 0, KC > 1 ? (un + rot) % KC : 0, 0);
             }
             const f16x8(&f)[2][2] = af[ks & 1];
-            const f16x8(&bfr)[2][4] = bset[ks >> 2];
+            const f16x8(&bfr)[NS][2][4] = bset[ks >> 2];
             constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // lo.hi, hi.lo, hi.hi: smallest terms first
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[TB[t]][ks & 3], acc[m], 0, 0, 0);
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[s][TB[t]][ks & 3], acc[s][m], 0, 0, 0);
         }
         if (!EXCH && kc == KC - 1) {
-            // direct epilogue of column group g from the accumulator layout
+            // direct epilogue from the accumulator layout, one (slab, 32-row block) at a time
             constexpr bool BITS = NG == 3 || NC == 6;   // ReLU bit masks in / out: only the fc1-shaped launches use them
-            const int slab = NC == 6 ? 6 * static_cast<int>(blockIdx.y) + w : 4 * g + w;
-            const int n = 32 * slab + col;
-            const float bias = bias_g[g];
-            const size_t bix = (static_cast<size_t>(tix) * SLABS + slab) * 64 + lane;
-            unsigned bits = 0xFFFFFFFFu, newbits = 0;
-            if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
-            float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
-            float out[2][16];
-            float4 rs[2][4];
-            row_scales(rs, cs_g[g]);
+            const bool full = r0 + kTR <= R;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int s = 0; s < NS; ++s) {
+                const int slab = slab_of(g, s);
+                const int n = 32 * slab + col;
+                const float bias = bias_g[g * NS + s];
+                const size_t bix = (static_cast<size_t>(tix) * SLABS + slab) * 64 + lane;
+                unsigned bits = 0xFFFFFFFFu, newbits = 0;
+                if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
+                float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float v = fmaf(acc[m][reg], comp(rs[m][reg >> 2], reg & 3), bias);
-                    if (BITS) {
-                        newbits |= (v > 0.f ? 1u : 0u) << (16 * m + reg);
-                        v = __uint_as_float((__float_as_uint(fmaxf(v, 0.f)) & relu_sel) | (__float_as_uint(v) & ~relu_sel));
-                        v = (bits >> (16 * m + reg)) & 1u ? v : 0.f;
-                    } else if (ep.relu) {
-                        v = fmaxf(v, 0.f);
-                    }
-                    out[m][reg] = v;
-                }
-            // one uniform branch for the tail tile: per-store predicates would put every store in its own
-            // block and hipcc then drains the queue (vmcnt(0)) in front of each of them
-            if (r0 + kTR <= R) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) yb[(32 * m + (reg & 3) + 8 * (reg >> 2)) * N] = out[m][reg];
-            } else {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m) {
+                    float out[16];
+                    float4 rs[4];
+                    row_scales(rs, m, cs_g[g * NS + s]);
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2);
-                        if (r0 + rr + 4 * half < R) yb[rr * N] = out[m][reg];
+                        float v = fmaf(acc[s][m][reg], comp(rs[reg >> 2], reg & 3), bias);
+                        if (BITS) {
+                            newbits |= (v > 0.f ? 1u : 0u) << (16 * m + reg);
+                            v = __uint_as_float((__float_as_uint(fmaxf(v, 0.f)) & relu_sel) | (__float_as_uint(v) & ~relu_sel));
+                            v = (bits >> (16 * m + reg)) & 1u ? v : 0.f;
+                        } else if (ep.relu) {
+                            v = fmaxf(v, 0.f);
+                        }
+                        out[reg] = v;
                     }
+                    // one uniform branch for the tail tile: per-store predicates would put every store in its own
+                    // block and hipcc then drains the queue (vmcnt(0)) in front of each of them
+                    if (full) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) yb[(32 * m + (reg & 3) + 8 * (reg >> 2)) * N] = out[reg];
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2);
+                            if (r0 + rr + 4 * half < R) yb[rr * N] = out[reg];
+                        }
+                    }
+                }
+                if (BITS && ep.relu_bits) ep.relu_bits[bix] = newbits;
             }
-            if (BITS && ep.relu_bits) ep.relu_bits[bix] = newbits;
         }
         if (EXCH && kc == KC - 1) {
             // exchange through the consumed planes so that each half-wave finalises whole 512-byte rows
             float* ex = reinterpret_cast<float*>(lds + (chunk & 1) * kH3Buf);
             const float bias = bias_g[0];
             float4 rs[2][4];
-            row_scales(rs, cs_g[0]);
+            row_scales(rs[0], 0, cs_g[0]);
+            row_scales(rs[1], 1, cs_g[0]);
             __syncthreads();   // every consumer has finished its fragment reads
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    float v = fmaf(acc[m][reg], comp(rs[m][reg >> 2], reg & 3), bias);
+                    float v = fmaf(acc[0][m][reg], comp(rs[m][reg >> 2], reg & 3), bias);
                     if (ep.relu) v = fmaxf(v, 0.f);
                     ex[rr * 128 + 32 * w + col] = v;
                 }
@@ -1233,9 +1245,9 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
                            reinterpret_cast<const f16x8*>(packed), y, R, ep);                                      \
     }
         static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
-        if (K == 128 && N == 384 && split_n) {   // two 192-column halves, B resident in six consumer waves
+        if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)
             DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), kH3Lds);
-            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs, 2), dim3(512), kH3Lds, stream, a,
+            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs), dim3(512), kH3Lds, stream, a,
                                reinterpret_cast<const f16x8*>(packed), y, R, ep);
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
