@@ -16,7 +16,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libdruggen_hip.so")
+LIB_PATH = os.environ.get("DG_LIB") or os.path.join(_PKG, "lib", "libdruggen_hip.so")   # DG_LIB: developer A/B builds
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/druggen_hip.h one to one

@@ -26,6 +26,9 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef DG_DBG
+#define DG_DBG 0
+#endif
 namespace dg {
 namespace {
 
@@ -402,6 +405,7 @@ constexpr int kX6Lds = 2 * kX6Buf;            // double-buffered
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kH3Plane = kTR * kX6Pitch;      // same row pitch as the bf16 planes
 constexpr int kH3Rs = 2 * kH3Plane;           // byte offset of float inv_row_scale[64] (past the 32 KiB exchange tile)
 constexpr int kH3Buf = kH3Rs + kTR * 4;
@@ -452,14 +456,6 @@ __device__ __forceinline__ unsigned scale_exponent(float absmax) {   // biased e
 }
 __device__ __forceinline__ float scale_of(unsigned e) { return __uint_as_float((268u - e) << 23); }      // 2^(14 - (e - 127))
 __device__ __forceinline__ float inv_scale_of(unsigned e) { return __uint_as_float((e - 14u) << 23); }
-__device__ __forceinline__ void split_h2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
-    const f32x2 xs = {x0 * s, x1 * s};
-    const f16x2 h = __builtin_convertvector(xs, f16x2);
-    const f32x2 r = xs - __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
 __device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 // unsigned max steps (the ordering of |float| bit patterns): 0 is the identity, so the DPP move folds into v_max_u32
 template <int CTRL>
@@ -467,20 +463,76 @@ __device__ __forceinline__ unsigned dpp_umax_step(unsigned x) {
     const unsigned moved = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xF, 0xF, true));
     return x > moved ? x : moved;
 }
-// biased exponent of max |.| over the float4s of the 32 lanes of a half-wave (one 128-wide row), in every lane
-__device__ __forceinline__ unsigned half_absmax_exponent(const float4& v) {
-    const unsigned m = 0x7FFFFFFFu;
-    const unsigned a = __float_as_uint(v.x) & m, b = __float_as_uint(v.y) & m, c = __float_as_uint(v.z) & m,
-                   d = __float_as_uint(v.w) & m;
-    unsigned x = max(max(a, b), max(c, d));
-    x = dpp_umax_step<0xB1>(x);
-    x = dpp_umax_step<0x4E>(x);
-    x = dpp_umax_step<0x141>(x);
-    x = dpp_umax_step<0x140>(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-    x = r[0] > r[1] ? r[0] : r[1];
-    const unsigned e = x >> 23;
-    return e < 15u ? 15u : e;
+// Producer side of the fp16x3 kernels: thread `pt` holds PFN float4s, the i-th belonging to tile row (pt + STRIDE i) >> 5
+// at float4 column (pt & 31) (the 32 lanes of a half-wave hold one 128-wide row).  Row maximum -> power-of-two scale
+// -> hi / lo fp16 planes + the inverse scale, written to the LDS image `pl`.  The work is staged across groups of
+// eight float4s so that the eight independent dependency chains (DPP reduction, conversions) interleave instead of
+// running one after the other: the producers' VALU latency is the critical path of these kernels.
+template <int PFN, int STRIDE>
+__device__ __forceinline__ void split_write_h3(const float4 (&set)[PFN], char* pl, int pt) {
+    constexpr int G = PFN > 8 ? 2 : 4;   // the 16-float4 producers (two waves) are short of registers
+    static_assert(PFN % G == 0, "whole groups");
+#pragma unroll
+    for (int g0 = 0; g0 < PFN; g0 += G) {
+        unsigned m[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {   // |.| maximum of the four components: two VOP3 instructions with abs modifiers
+            const float4& v = set[g0 + j];
+            float t, u;
+            asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(v.x), "v"(v.y), "v"(v.z));
+            asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(u) : "v"(v.w), "v"(t));
+            m[j] = __float_as_uint(u);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = dpp_umax_step<0xB1>(m[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = dpp_umax_step<0x4E>(m[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = dpp_umax_step<0x141>(m[j]);
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = dpp_umax_step<0x140>(m[j]);
+        float sc[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const auto r = __builtin_amdgcn_permlane16_swap(m[j], m[j], false, false);
+            const unsigned x = r[0] > r[1] ? r[0] : r[1];
+            const unsigned e = max(x >> 23, 15u);
+            m[j] = e;
+            sc[j] = scale_of(e);
+        }
+        f32x2 xa[G], xb[G];
+        f16x2 ha[G], hb[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const float4& v = set[g0 + j];
+            xa[j] = f32x2{v.x, v.y} * sc[j];
+            xb[j] = f32x2{v.z, v.w} * sc[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            ha[j] = __builtin_convertvector(xa[j], f16x2);
+            hb[j] = __builtin_convertvector(xb[j], f16x2);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            xa[j] -= __builtin_convertvector(ha[j], f32x2);
+            xb[j] -= __builtin_convertvector(hb[j], f32x2);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int L = pt + STRIDE * (g0 + j), r = L >> 5, c4 = L & 31;
+            const f16x2 la = __builtin_convertvector(xa[j], f16x2), lb = __builtin_convertvector(xb[j], f16x2);
+            const u32x2 h = {__builtin_bit_cast(unsigned, ha[j]), __builtin_bit_cast(unsigned, hb[j])};
+            const u32x2 l = {__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+            *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
+            *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
+        }
+        if ((pt & 31) == 0) {   // one divergent block per group (branches between the stages would serialise the chains)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                *reinterpret_cast<float*>(pl + kH3Rs + ((pt + STRIDE * (g0 + j)) >> 5) * 4) = inv_scale_of(m[j]);
+        }
+    }
 }
 
 // packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs] (one scale
@@ -529,7 +581,6 @@ __global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __rest
 // exact three-way split of a float4 into bf16 planes by truncation: h = top 16 bits of x,
 // m = top 16 bits of (x - h), l = top 16 bits of (x - h - m); every remainder is exact and
 // h + m + l covers all 24 significand bits.  v_perm_b32 packs the high halves of a pair.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x2& l) {
     const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -589,33 +640,25 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         // Straight-line on purpose (chunk indices are clamped instead of guarded): with branches around
         // the loads hipcc can no longer count how many younger loads may stay in flight and drains
         // the whole queue (vmcnt(0)) before every split, which serialises the stream with HBM latency.
+        // uniform 64-bit tile base + a 32-bit per-lane byte offset; rows past the end of a partial tile are clamped
+        // on the offset (row-major: the row term dominates the comparison)
+        const unsigned voff0 = static_cast<unsigned>(pt >> 5) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
         auto fetch = [&](float4 (&set)[PFN], int64_t chunk) {
             if (chunk > nchunks - 1) chunk = nchunks - 1;
             const int64_t r0 = tile_of(chunk) * kTR;
-            const int kc = KC == 1 ? 0 : (static_cast<int>(chunk % KC) + rot) % KC;
+            const char* base = reinterpret_cast<const char*>(a) + r0 * (K * 4);
+            const int64_t last = R - 1 - r0;   // >= 0
+            const unsigned lim = last >= kTR - 1 ? 0xFFFFFFFFu
+                                                 : static_cast<unsigned>(last) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
 #pragma unroll
             for (int i = 0; i < PFN; ++i) {
-                const int L = pt + 64 * NM * i;
-                int64_t row = r0 + (L >> 5);
-                if (row > R - 1) row = R - 1;
-                set[i] = ld4(a + row * K + kc * 128 + (L & 31) * 4);
+                unsigned off = voff0 + i * (2 * NM * K * 4);   // 64 NM threads = 2 NM rows per step
+                off = off < lim ? off : lim;
+                set[i] = ld4(reinterpret_cast<const float*>(base + off));
             }
         };
         auto write = [&](const float4 (&set)[PFN], int64_t chunk) {   // chunks past the end land in the idle buffer
-            char* pl = lds + (chunk & 1) * kH3Buf;
-#pragma unroll
-            for (int i = 0; i < PFN; ++i) {
-                const int L = pt + 64 * NM * i, r = L >> 5, c4 = L & 31;   // the 32 lanes of a half-wave hold one row
-                const unsigned e = half_absmax_exponent(set[i]);
-                const float sc = scale_of(e);
-                unsigned h0, h1, l0, l1;
-                split_h2(set[i].x, set[i].y, sc, h0, l0);
-                split_h2(set[i].z, set[i].w, sc, h1, l1);
-                const u32x2 h = {h0, h1}, l = {l0, l1};
-                *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
-                *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
-                if (c4 == 0) *reinterpret_cast<float*>(pl + kH3Rs + r * 4) = inv_scale_of(e);
-            }
+            split_write_h3<PFN, 64 * NM>(set, lds + (chunk & 1) * kH3Buf, pt);
         };
         auto end_of_iteration = [&](int64_t c) {
             if (EXCH && c % KC == KC - 1 && c < nchunks) {   // the consumers' exchange epilogue: two more barriers
@@ -920,47 +963,56 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
 
     if (w >= 4) {
         // ---------------------------------------------------------------------- movers
+        // (they are the critical path: their VALU work wins the issue arbitration against the consumer on the SIMD)
+        __builtin_amdgcn_s_setprio(3);
         const int pw = w - 4, pt = threadIdx.x - 256;
         float4 pf[3][8];
+        // loads of a chunk: uniform 64-bit base (tile, k chunk) + a 32-bit per-lane byte offset; rows past the end
+        // of a partial tile are clamped on the offset (row-major, so the row term dominates the comparison)
+        const unsigned voff0 = static_cast<unsigned>(pt >> 5) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
         auto fetch = [&](float4 (&set)[8], int c) {
             if (c > nchunks - 1) c = nchunks - 1;
             int ti, pos;
             chunk_map(c, ti, pos);
             const int64_t r0 = tile_row0(ti);
             const int kc = (pos + rot) % KC;
+            const char* base = reinterpret_cast<const char*>(a) + (r0 * K + kc * 128) * 4;
+            const int64_t last = R - 1 - r0;   // >= 0
+            const unsigned lim = last >= kTR - 1 ? 0xFFFFFFFFu : static_cast<unsigned>(last) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int L = pt + 256 * i;
-                int64_t row = r0 + (L >> 5);
-                if (row > R - 1) row = R - 1;
-                set[i] = ld4(a + row * K + kc * 128 + (L & 31) * 4);
+                unsigned off = voff0 + i * (8 * K * 4);
+                off = off < lim ? off : lim;
+                if (DG_DBG & 8) set[i] = f4(static_cast<float>(off & 7));
+                else set[i] = ld4(reinterpret_cast<const float*>(base + off));
             }
         };
         auto write = [&](const float4 (&set)[8], int c) {   // chunks past the end land in the idle buffer
-            char* pl = lds + (c & 1) * kH3Buf;
+            // the scale of a row is per 128-wide chunk: each chunk has its own accumulation
+            if (DG_DBG & 2) {
+                char* pl = lds + (c & 1) * kH3Buf;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {   // the scale of a row is per 128-wide chunk: each chunk has its own accumulation
-                const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
-                const unsigned e = half_absmax_exponent(set[i]);
-                const float sc = scale_of(e);
-                unsigned h0, h1, l0, l1;
-                split_h2(set[i].x, set[i].y, sc, h0, l0);
-                split_h2(set[i].z, set[i].w, sc, h1, l1);
-                const u32x2 h = {h0, h1}, l = {l0, l1};
-                *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
-                *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
-                if (c4 == 0) *reinterpret_cast<float*>(pl + kH3Rs + r * 4) = inv_scale_of(e);
+                for (int i = 0; i < 8; ++i) {
+                    const int L = pt + 256 * i, r = L >> 5, c4 = L & 31;
+                    *reinterpret_cast<float4*>(pl + (i & 1) * kH3Plane + r * kX6Pitch + (c4 >> 1) * 16) = set[i];
+                }
+            } else {
+                split_write_h3<8, 256>(set, lds + (c & 1) * kH3Buf, pt);
             }
         };
         float4 res[8];   // residual rows of the tile being finished: pw * 16 + it * 2 + half
         auto fetch_residual = [&](int ti) {
             if (!EXCH || !ep.residual) return;
             const int64_t r0 = tile_row0(ti);
+            const char* base = reinterpret_cast<const char*>(ep.residual) + r0 * 512;
+            const int64_t last = R - 1 - r0;
+            const unsigned lim = last >= kTR - 1 ? 0xFFFFFFFFu : static_cast<unsigned>(last) * 512 + col * 16;
+            const unsigned roff0 = static_cast<unsigned>(pw * 16 + half) * 512 + col * 16;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                int64_t rrow = r0 + pw * 16 + it * 2 + half;
-                if (rrow > R - 1) rrow = R - 1;
-                res[it] = ld4(ep.residual + rrow * 128 + col * 4);
+                unsigned off = roff0 + it * 1024;
+                off = off < lim ? off : lim;
+                res[it] = ld4(reinterpret_cast<const float*>(base + off));
             }
         };
         auto store_tile = [&](int ti) {   // exchange tile -> residual / LayerNorm -> global rows
@@ -999,7 +1051,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int it = 4 * hg + j;
-                        st4(yrow + it * 256, yv[j]);
+                        if (!(DG_DBG & 4) || yv[j].x == 1.2345e-30f) st4(yrow + it * 256, yv[j]);
                         if (EXCH && ep.pre && ep.gamma) st4(ep.pre + (r0 + pw * 16 + it * 2 + half) * 128 + col * 4, pv[j]);
                     }
                 } else {
@@ -1024,32 +1076,52 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
                 }
             }
         };
-        fetch(pf[0], 0);
-        fetch(pf[1], 1);
-        fetch(pf[2], 2);
-        write(pf[0], 0);
-        fetch(pf[0], 3);
-        __syncthreads();   // chunk 0 is in planes[0]
+#if DG_DBG & 16
+        unsigned long long tl = __builtin_amdgcn_s_memtime(), tW = 0, tF = 0, tB = 0, tS = 0, t00 = tl;
+#define STAMP(x) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); x += t_ - tl; tl = t_; }
+#else
+#define STAMP(x)
+#endif
+#define SYNC() { __syncthreads(); STAMP(tB) }
+#define STORE_TILE(t) { store_tile(t); STAMP(tS) }
+#define WRITE(a_, b_) { write(a_, b_); STAMP(tW) }
+#define FETCH(a_, b_) { fetch(a_, b_); STAMP(tF) }
+        FETCH(pf[0], 0);
+        FETCH(pf[1], 1);
+        FETCH(pf[2], 2);
+        WRITE(pf[0], 0);
+        FETCH(pf[0], 3);
+        SYNC();   // chunk 0 is in planes[0]
         int c = 0;
         for (int p = 0; p < npairs; ++p, c += 6) {
             const int t0 = 2 * p, t1 = 2 * p + 1;
-            write(pf[1], c + 1); fetch(pf[1], c + 4); __syncthreads();                              // (t0, 0)
-            write(pf[2], c + 2); fetch(pf[2], c + 5); __syncthreads();                              // (t1, 0)
-            write(pf[0], c + 3); fetch(pf[0], c + 6); __syncthreads();                              // (t0, 1)
-            write(pf[1], c + 4); fetch(pf[1], c + 7); fetch_residual(t0); __syncthreads();          // (t1, 1)
-            write(pf[2], c + 5); fetch(pf[2], c + 8); __syncthreads(); __syncthreads();             // (t0, 2): A, B
-            store_tile(t0);
+            WRITE(pf[1], c + 1); FETCH(pf[1], c + 4); SYNC();                              // (t0, 0)
+            WRITE(pf[2], c + 2); FETCH(pf[2], c + 5); SYNC();                              // (t1, 0)
+            WRITE(pf[0], c + 3); FETCH(pf[0], c + 6); SYNC();                              // (t0, 1)
+            WRITE(pf[1], c + 4); FETCH(pf[1], c + 7); fetch_residual(t0); SYNC();          // (t1, 1)
+            WRITE(pf[2], c + 5); FETCH(pf[2], c + 8); SYNC(); SYNC();             // (t0, 2): A, B
+            STORE_TILE(t0);
             fetch_residual(t1);
-            write(pf[0], c + 6); fetch(pf[0], c + 9); __syncthreads(); __syncthreads();             // (t1, 2): A, B
-            store_tile(t1);
+            WRITE(pf[0], c + 6); FETCH(pf[0], c + 9); SYNC(); SYNC();             // (t1, 2): A, B
+            STORE_TILE(t1);
         }
         if (ntl & 1) {
             const int t = ntl - 1;
-            write(pf[1], c + 1); fetch(pf[1], c + 4); __syncthreads();                              // (t, 0)
-            write(pf[2], c + 2); fetch(pf[2], c + 5); fetch_residual(t); __syncthreads();           // (t, 1)
-            write(pf[0], c + 3); __syncthreads(); __syncthreads();                                  // (t, 2): A, B
-            store_tile(t);
+            WRITE(pf[1], c + 1); FETCH(pf[1], c + 4); SYNC();                              // (t, 0)
+            WRITE(pf[2], c + 2); FETCH(pf[2], c + 5); fetch_residual(t); SYNC();           // (t, 1)
+            WRITE(pf[0], c + 3); SYNC(); SYNC();                                  // (t, 2): A, B
+            STORE_TILE(t);
         }
+#if DG_DBG & 16
+        if (lane == 0 && blockIdx.x == 17 && ep.rstd) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(ep.rstd) + 8 * w;
+            o[0] = tW; o[1] = tF; o[2] = tB; o[3] = tS; o[4] = __builtin_amdgcn_s_memtime() - t00; o[5] = ntl;
+        }
+#endif
+#undef SYNC
+#undef STORE_TILE
+#undef WRITE
+#undef FETCH
         return;
     }
 
@@ -1068,6 +1140,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
     f32x16 accs[2][2];
     int chunk = 0;
     __syncthreads();   // chunk 0 is in planes[0]
+#if DG_DBG & 16
+    unsigned long long tl = __builtin_amdgcn_s_memtime(), tM = 0, tFo = 0, tE = 0, tB = 0, t00 = tl;
+#endif
     auto body = [&](int pos, f32x16 (&acc)[2], auto second_tag) {
         constexpr bool SECOND = decltype(second_tag)::value;
         if (pos == 0) {
@@ -1110,7 +1185,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    if (ks == 0 && t == 0) {
+                    if (DG_DBG & 1) {
+                        if (ks == 0 && t == 0) for (int i = 0; i < 16; ++i) part[m][i] = f[m][0][0] * (float)bfr[0][ks][i & 7];
+                    } else if (ks == 0 && t == 0) {
                         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         part[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[TB[t]][ks], zero, 0, 0, 0);
                     } else {
@@ -1122,6 +1199,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
                 for (int p = 0; p < 2; ++p) load_b128_async(bfr[p][ks], bnext + (ks * 2 + p) * 64);
             }
         }
+        STAMP(tM)
         {
             const float* rsp = reinterpret_cast<const float*>(pl + kH3Rs);
 #pragma unroll
@@ -1133,8 +1211,10 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
                     for (int i = 0; i < 4; ++i) acc[m][4 * q + i] = fmaf(part[m][4 * q + i], comp(r4, i), acc[m][4 * q + i]);
                 }
         }
+        STAMP(tFo)
         if (pos == KC - 1) {
             __syncthreads();   // A: the movers have finished with the previous exchange tile
+            STAMP(tB)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1145,7 +1225,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
                     ex[rr * 128 + 32 * w + col] = v;
                 }
         }
+        STAMP(tE)
         __syncthreads();   // B
+        STAMP(tB)
         ++chunk;
     };
     for (int p = 0; p < npairs; ++p) {
@@ -1168,6 +1250,13 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
             }
         }
     }
+#if DG_DBG & 16
+    if (lane == 0 && blockIdx.x == 17 && ep.rstd) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(ep.rstd) + 8 * w;
+        o[0] = tM; o[1] = tFo; o[2] = tE; o[3] = tB; o[4] = __builtin_amdgcn_s_memtime() - t00; o[5] = ntl;
+    }
+#endif
+#undef STAMP
 }
 
 }  // namespace
