@@ -249,13 +249,15 @@ def main():
 
     if rank == 0:
         bf16 = act_dtype == "bf16"
-        # MFMA ceiling of the GEMM-shaped kernels by arithmetic: fp32 activations run the 3-way bf16 split
-        # (6 bf16 MFMAs per product: ceiling = bf16 peak / 6); bf16 activations one MFMA per product
-        x6 = os.environ.get("DG_ROW_GEMM") != "mfma32"
-        gemm_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (MFMA_BF16_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS)
+        # MFMA ceiling of the GEMM-shaped kernels by arithmetic: fp32 activations run a power-of-two scaled fp16
+        # two-plane split (3 fp16 MFMAs per product: ceiling = 16-bit peak / 3; the weight-gradient kernel still
+        # uses the 3-way bf16 split, 6 MFMAs per product); bf16 activations one MFMA per product
+        split = os.environ.get("DG_ROW_GEMM") != "mfma32"
+        gemm_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS)
         gemm_how = ("1x v_mfma_f32_*_bf16 per product (bf16 operands, fp32 accumulate)" if bf16 else
-                    ("6x v_mfma_f32_32x32x16_bf16 per product (fp32 operands split 3-way into bf16, fp32 accumulate: "
-                     "fp32-class accuracy)" if x6 else "v_mfma_f32_32x32x2_f32"))
+                    ("3x v_mfma_f32_32x32x16_f16 per product (fp32 operands scaled by a power of two and split hi + lo "
+                     "into fp16, fp32 accumulate: fp32-class accuracy, tests/test_hip_kernels.py)" if split
+                     else "v_mfma_f32_32x32x2_f32"))
         kernels = {}
         for name in _lib.KERNEL_IDS:
             n, ms = _lib.prof_read(name)
@@ -269,9 +271,12 @@ def main():
                 fl = dgf.traffic_flops(name)
                 if fl:          # GEMM-shaped kernels: flop rate against the MFMA ceiling of their arithmetic
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                    kernels[name].update({"achieved_TFLOPs": tf, "mfma_peak_TFLOPs": gemm_peak,
-                                          "frac_of_mfma_peak": tf / gemm_peak, "mfma": gemm_how})
-                    kernels[name]["bound"] = "hbm" if kernels[name]["frac_of_hbm_peak"] >= tf / gemm_peak else "mfma"
+                    peak, how = gemm_peak, gemm_how
+                    if name == "linear_wgrad" and not bf16 and split:     # still the 3-way bf16 split
+                        peak, how = MFMA_BF16_PEAK_TFLOPS / 6.0, "6x v_mfma_f32_32x32x16_bf16 per product (fp32 operands split 3-way into bf16)"
+                    kernels[name].update({"achieved_TFLOPs": tf, "mfma_peak_TFLOPs": peak,
+                                          "frac_of_mfma_peak": tf / peak, "mfma": how})
+                    kernels[name]["bound"] = "hbm" if kernels[name]["frac_of_hbm_peak"] >= tf / peak else "mfma"
                 else:
                     kernels[name]["bound"] = "hbm"
         (n_f, ms_f), bytes_f = attn_stats["attn_fwd"]

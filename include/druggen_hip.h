@@ -142,6 +142,9 @@ int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* d
  * nn.Linear weight w[rows,cols]: mode 0 -> B[k][n] = w[n][k] (forward, N=rows,
  * K=cols); mode 1 -> B[k][n] = w[k][n] (input gradient dx = dy.w, N=cols, K=rows).
  * (K,N) in {(128,128), (128,384), (384,128)}; others DG_E_SHAPE.
+ * fp32 arithmetic: rows of a (per 128-wide chunk) and columns of B are scaled by an exact power of two
+ * and split hi + lo into fp16; three MFMA products with fp32 accumulation, inverse scales in the
+ * epilogue -- element-wise error at the level of an fp32 GEMM (tests/test_hip_kernels.py).
  * ReLU backward without a pass over the activations: a forward launch with
  * relu != 0 can write one bit per output element into relu_bits_out
  * (dg_row_gemm_mask_words(R,K,N) uint32 words, laid out per tile/wave/lane); the
