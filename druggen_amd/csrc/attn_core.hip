@@ -131,7 +131,7 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
     const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
     T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, T* __restrict__ de, int N, int C,
-    float alpha) {
+    float alpha, int SL, int B) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // k_j, v_j in the lane layout, shared by the RW waves: kv[2][JPL][64]; then the reduction area
@@ -139,7 +139,12 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     float4* red = kv + 2 * JPL * 64;  // [(RW-1)][2*JPL][64]
     const int lane = threadIdx.x & 63;
     const int rw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x, slice = blockIdx.y;
+    // XCD-aware placement (speed only; workgroup id -> XCD is id % 8): the SL channel slices of a molecule get
+    // consecutive ids on ONE XCD, so they run at the same time behind the same L2.  With bf16 rows a slice covers
+    // 64 of the 128 bytes of a cache line: the other half is then an L2 hit instead of a second HBM fetch.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / SL) * 8 + xcd, slice = slot % SL;
+    if (b >= B) return;   // block-uniform
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
 
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
     const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
     const T* __restrict__ tq, const T* __restrict__ tk, const T* __restrict__ tv,
     const T* __restrict__ te, T* __restrict__ gq, T* __restrict__ gk, T* __restrict__ gv,
-    T* __restrict__ ge, T* __restrict__ gws, T* __restrict__ gwo, int N, int C, float alpha) {
+    T* __restrict__ ge, T* __restrict__ gws, T* __restrict__ gwo, int N, int C, float alpha, int SL, int B) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // per-neighbour operands live in LDS (read-only, shared by the RW waves):
@@ -269,7 +274,12 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
     float4* red = kv + 4 * JPL * 64;  // [(RW-1)][2*JPL][64]
     const int lane = threadIdx.x & 63;
     const int rw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x, slice = blockIdx.y;
+    // XCD-aware placement (speed only; workgroup id -> XCD is id % 8): the SL channel slices of a molecule get
+    // consecutive ids on ONE XCD, so they run at the same time behind the same L2.  With bf16 rows a slice covers
+    // 64 of the 128 bytes of a cache line: the other half is then an L2 hit instead of a second HBM fetch.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / SL) * 8 + xcd, slice = slot % SL;
+    if (b >= B) return;   // block-uniform
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
 
@@ -509,7 +519,7 @@ extern "C" int dg_attn_core_bwd(const void* q_, const void* k_, const void* v_, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static const int rw_env = getenv("DG_ATTN_BWD_RW") ? atoi(getenv("DG_ATTN_BWD_RW")) : 0;
     const bool rw8 = rw_env == 8 && g.jpl <= 6;
-    dim3 grid(B, g.slices), block(64 * (rw8 ? 8 : kRW));
+    dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * g.slices), block(64 * (rw8 ? 8 : kRW));
     ProfScope prof(DG_K_ATTN_BWD, stream);
 #define LAUNCH_T(T, LQS, JPL, RW_)                                                                              \
     {                                                                                                           \
@@ -519,7 +529,7 @@ extern "C" int dg_attn_core_bwd(const void* q_, const void* k_, const void* v_, 
                            static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_),     \
                            static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_),   \
                            static_cast<T*>(dq_), static_cast<T*>(dk_), static_cast<T*>(dv_), static_cast<T*>(de_), \
-                           N, C, alpha);                                                                        \
+                           N, C, alpha, g.slices, B);                                                           \
     }
 #define LAUNCH_RW(LQS, JPL, RW_)                                        \
     {                                                                   \
@@ -549,7 +559,7 @@ extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_,
         return fail(DG_E_SHAPE, "dg_attn_core_bwd2: unsupported shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    dim3 grid(B, g.slices), block(64 * kRW);
+    dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * g.slices), block(64 * kRW);
     ProfScope prof(DG_K_ATTN_BWD2, stream);
 #define LAUNCH_T(T, LQS, JPL)                                                                                     \
     {                                                                                                             \
@@ -561,7 +571,7 @@ extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_,
                            static_cast<const T*>(tq_), static_cast<const T*>(tk_), static_cast<const T*>(tv_),    \
                            static_cast<const T*>(te_), static_cast<T*>(gq_), static_cast<T*>(gk_),                \
                            static_cast<T*>(gv_), static_cast<T*>(ge_), static_cast<T*>(gws_), static_cast<T*>(gwo_), \
-                           N, C, alpha);                                                                          \
+                           N, C, alpha, g.slices, B);                                                             \
     }
 #define LAUNCH(LQS, JPL)                                   \
     if (g.lqs == LQS && g.jpl == JPL) {                    \
