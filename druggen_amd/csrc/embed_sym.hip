@@ -26,7 +26,10 @@ constexpr int kMaxE = 16;
 
 enum Act { kRelu = 0, kLeaky = 1, kSigmoid = 2, kTanh = 3 };
 
-__device__ __forceinline__ float act_fwd(float x, int act) {
+// ACT is a template parameter of the kernels: a run-time switch inside the per-element loops costs a branch ladder
+// per value and keeps hipcc from scheduling across the elements
+template <int act>
+__device__ __forceinline__ float act_fwd(float x) {
     switch (act) {
         case kRelu: return fmaxf(x, 0.f);
         case kLeaky: return x > 0.f ? x : 0.01f * x;
@@ -35,7 +38,8 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     }
 }
 // derivative expressed through the OUTPUT y = act(x)
-__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+template <int act>
+__device__ __forceinline__ float act_grad_from_output(float y) {
     switch (act) {
         case kRelu: return y > 0.f ? 1.f : 0.f;
         case kLeaky: return y > 0.f ? 1.f : 0.01f;
@@ -79,11 +83,12 @@ struct Smem {
 
 // Stage the pair table, the input rows and the layer-1 activations of one tile.
 // EP = padded number of input features (8 or 16): sizes the per-lane weight / accumulator arrays.
-template <int EP>
+template <int EP, int ACT>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const float* __restrict__ w1,
-                                           const float* __restrict__ b1, int act, int N, int E, int NP, PairTile t,
+                                           const float* __restrict__ b1, int N, int E, int NP, PairTile t,
                                            int (*ij)[2], float (*at)[kMaxE], float* h1) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque per call: keeps the per-row LDS offsets out of the caller's loop preheader
     if (tid < kPairs) {
         const int p = t.p0 + tid;
         int i = 0, j = 0;
@@ -115,7 +120,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const fl
         float s = bb;
 #pragma unroll
         for (int e = 0; e < EP; ++e) s = fmaf(w[e], at[row][e], s);
-        h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)] = act_fwd(s, act);
+        h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)] = act_fwd<ACT>(s);
     }
     __syncthreads();
 }
@@ -140,12 +145,12 @@ __device__ __forceinline__ void layer2_mfma(const float* h1, const float4 (&bf)[
     }
 }
 
-template <typename T, int EP>
+template <typename T, int EP, int ACT>
 __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w1,
                                                           const float* __restrict__ b1,
                                                           const float* __restrict__ w2p,
                                                           const float* __restrict__ b2, T* __restrict__ out,
-                                                          int B, int N, int E, int act, int tiles_per_mol) {
+                                                          int B, int N, int E, int tiles_per_mol) {
     __shared__ int ij[kPairs][2];
     __shared__ float at[64][kMaxE];
     __shared__ __attribute__((aligned(16))) float h1[64 * kHid];
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
     const int total = B * tiles_per_mol;
     for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
-        stage_tile<EP>(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        stage_tile<EP, ACT>(a, w1, b1, N, E, NP, t, ij, at, h1);
         f32x16 acc0, acc1;
         layer2_mfma(h1, bf, acc0, acc1);
 #pragma unroll
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
             const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const int i = ij[pr][0], j = ij[pr][1];
             if (i < 0) continue;
-            const float s = 0.5f * (act_fwd(acc0[reg] + bias2, act) + act_fwd(acc1[reg] + bias2, act));
+            const float s = 0.5f * (act_fwd<ACT>(acc0[reg] + bias2) + act_fwd<ACT>(acc1[reg] + bias2));
             const int64_t base = static_cast<int64_t>(t.b) * N;
             st1(out + ((base + i) * N + j) * kC + n, s);
             st1(out + ((base + j) * N + i) * kC + n, s);
@@ -190,11 +195,11 @@ struct BwdPart {
     static constexpr int kW2 = 0, kB2 = kC * kHid, kW1 = kB2 + kC, kB1 = kW1 + kHid * kMaxE, kTotal = kB1 + kHid;
 };
 
-template <typename T, int EP>
-__global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
+template <typename T, int EP, int ACT>
+__global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
-    const T* __restrict__ g, float* __restrict__ da, float* __restrict__ part, int B, int N, int E, int act,
+    const T* __restrict__ g, float* __restrict__ da, float* __restrict__ part, int B, int N, int E,
     int tiles_per_mol) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* h1 = reinterpret_cast<float*>(smem_raw);                 // [64][64] swizzled
@@ -218,7 +223,12 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
     const int total = B * tiles_per_mol;
     for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
-        stage_tile<EP>(a, w1, b1, act, N, E, NP, t, ij, at, h1);
+        stage_tile<EP, ACT>(a, w1, b1, N, E, NP, t, ij, at, h1);
+        // Per-iteration opaque copy of the lane id: every swizzled LDS offset below is derived from it, so hipcc cannot
+        // hoist the ~200 loop-invariant offsets out of the tile loop (it did, and spilled 150 of them to scratch).
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int half = lo >> 5, col = lo & 31, n = 32 * w + col;
         f32x16 acc0, acc1;
         {
             float4 bf[8];
@@ -236,13 +246,16 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
                 const int64_t base = static_cast<int64_t>(t.b) * N;
                 float gs = 0.5f * (ld1(g + ((base + i) * N + j) * kC + n) + ld1(g + ((base + j) * N + i) * kC + n));
                 if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
-                p0 = gs * act_grad_from_output(act_fwd(acc0[reg] + bias2, act), act);
-                p1 = gs * act_grad_from_output(act_fwd(acc1[reg] + bias2, act), act);
+                p0 = gs * act_grad_from_output<ACT>(act_fwd<ACT>(acc0[reg] + bias2));
+                p1 = gs * act_grad_from_output<ACT>(act_fwd<ACT>(acc1[reg] + bias2));
             }
             ab2 += p0 + p1;
             const int c = n >> 2;
             d2[pr * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p0;
             d2[(32 + pr) * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p1;
+            // four rows at a time: without the fence hipcc hoists all 64 gradient loads (and their addresses) above
+            // the loop, 428 registers per lane = one wave per SIMD
+            if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         // dW2 += dpre2^T h1 : contraction over the 64 tile rows, operands by ds_read_b32
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) void embed_sym_bwd_kernel(
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const float hv = h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)];
-            const float p = dh[reg] * act_grad_from_output(hv, act);
+            const float p = dh[reg] * act_grad_from_output<ACT>(hv);
             ab1 += p;
 #pragma unroll
             for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, at[row][e], aw1[e]);
@@ -414,6 +427,7 @@ __global__ __launch_bounds__(256) void onehot_embed_bwd_kernel(const int* __rest
 
 constexpr int kOneHotBlocks = 1024;
 
+constexpr int kBwdPerCu = 2;   // backward workgroups per CU (71 KB of LDS each): their serial phases overlap
 int embed_grid(int total_tiles, int per_cu) {
     const int cap = 256 * per_cu;
     return total_tiles < cap ? (total_tiles < 1 ? 1 : total_tiles) : cap;
@@ -432,7 +446,7 @@ extern "C" size_t dg_embed_sym_packed_floats(void) { return static_cast<size_t>(
 
 extern "C" size_t dg_embed_sym_workspace_bytes(int B, int N) {
     const int tiles = B * ((N * (N + 1) / 2 + kPairs - 1) / kPairs);
-    return (static_cast<size_t>(embed_grid(tiles, 1)) + 1) * BwdPart::kTotal * sizeof(float);
+    return (static_cast<size_t>(embed_grid(tiles, kBwdPerCu)) + 1) * BwdPart::kTotal * sizeof(float);
 }
 
 extern "C" int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream_) {
@@ -482,14 +496,22 @@ extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     ProfScope prof(DG_K_EMBED_SYM, stream);
-#define FWD(T, EP_)                                                                                               \
-    hipLaunchKernelGGL((embed_sym_fwd_kernel<T, EP_>), dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, b1, \
-                       w2_packed, b2, static_cast<T*>(out), B, N, E, act, tpm);
+#define FWD_A(T, EP_, ACT_)                                                                                      \
+    hipLaunchKernelGGL((embed_sym_fwd_kernel<T, EP_, ACT_>), dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, \
+                       b1, w2_packed, b2, static_cast<T*>(out), B, N, E, tpm);
+#define FWD(T, EP_)                                                                                             \
+    switch (act) {                                                                                              \
+        case kRelu: FWD_A(T, EP_, kRelu) break;                                                                 \
+        case kLeaky: FWD_A(T, EP_, kLeaky) break;                                                               \
+        case kSigmoid: FWD_A(T, EP_, kSigmoid) break;                                                           \
+        default: FWD_A(T, EP_, kTanh) break;                                                                    \
+    }
     if (dtype == DG_DTYPE_BF16) {
         if (E <= 8) { FWD(bf16_t, 8) } else { FWD(bf16_t, 16) }
     } else {
         if (E <= 8) { FWD(float, 8) } else { FWD(float, 16) }
     }
+#undef FWD_A
 #undef FWD
     return check_launch("dg_embed_sym_fwd");
 }
@@ -507,22 +529,30 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
         return fail(DG_E_WORKSPACE, "dg_embed_sym_bwd: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
-    const int grid = embed_grid(B * tpm, 1);
+    const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
-#define BWD(T, EP_)                                                                                               \
+#define BWD_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                             \
-        DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_>), lds_bytes);                                                \
-        hipLaunchKernelGGL((embed_sym_bwd_kernel<T, EP_>), dim3(grid), dim3(256), lds_bytes, stream, a, w1, b1,    \
-                           w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), da, part, B, N, E, act, tpm); \
+        DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_, ACT_>), lds_bytes);                                           \
+        hipLaunchKernelGGL((embed_sym_bwd_kernel<T, EP_, ACT_>), dim3(grid), dim3(256), lds_bytes, stream, a, w1,  \
+                           b1, w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), da, part, B, N, E, tpm); \
+    }
+#define BWD(T, EP_)                                                                                               \
+    switch (act) {                                                                                                \
+        case kRelu: BWD_A(T, EP_, kRelu) break;                                                                   \
+        case kLeaky: BWD_A(T, EP_, kLeaky) break;                                                                 \
+        case kSigmoid: BWD_A(T, EP_, kSigmoid) break;                                                             \
+        default: BWD_A(T, EP_, kTanh) break;                                                                      \
     }
     if (dtype == DG_DTYPE_BF16) {
         if (E <= 8) BWD(bf16_t, 8) else BWD(bf16_t, 16)
     } else {
         if (E <= 8) BWD(float, 8) else BWD(float, 16)
     }
+#undef BWD_A
 #undef BWD
     hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
                        BwdPart::kTotal, red);
