@@ -620,6 +620,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* lds = smem_raw;                              // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
+    float* xb = reinterpret_cast<float*>(smem_raw + kH3Lds);   // direct epilogue: one 32 x 32 fp32 tile per consumer wave
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
@@ -667,6 +668,12 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             }
             __syncthreads();
         };
+#if DG_DBG & 16
+        unsigned long long tl = __builtin_amdgcn_s_memtime(), tW = 0, tF = 0, tB = 0, t00 = tl;
+#define GSTAMP(x) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); x += t_ - tl; tl = t_; }
+#else
+#define GSTAMP(x)
+#endif
         fetch(pf[0], 0);
         fetch(pf[1], 1);
         fetch(pf[2], 2);
@@ -675,16 +682,22 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         __syncthreads();
         for (int64_t c = 0; c < padded; c += 3) {
             // iteration c writes chunk c + 1 (the consumers are on chunk c) and refills its register set
-            write(pf[1], c + 1);
-            fetch(pf[1], c + 4);
-            end_of_iteration(c);
-            write(pf[2], c + 2);
-            fetch(pf[2], c + 5);
-            end_of_iteration(c + 1);
-            write(pf[0], c + 3);
-            fetch(pf[0], c + 6);
-            end_of_iteration(c + 2);
+            write(pf[1], c + 1); GSTAMP(tW)
+            fetch(pf[1], c + 4); GSTAMP(tF)
+            end_of_iteration(c); GSTAMP(tB)
+            write(pf[2], c + 2); GSTAMP(tW)
+            fetch(pf[2], c + 5); GSTAMP(tF)
+            end_of_iteration(c + 1); GSTAMP(tB)
+            write(pf[0], c + 3); GSTAMP(tW)
+            fetch(pf[0], c + 6); GSTAMP(tF)
+            end_of_iteration(c + 2); GSTAMP(tB)
         }
+#if DG_DBG & 16
+        if (lane == 0 && blockIdx.x == 17 && ep.rstd) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(ep.rstd) + 8 * w;
+            o[0] = tW; o[1] = tF; o[2] = tB; o[3] = 0; o[4] = __builtin_amdgcn_s_memtime() - t00; o[5] = my_tiles;
+        }
+#endif
         return;
     }
 
@@ -717,6 +730,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         }
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
     f32x16 acc[NS][2];
+#if DG_DBG & 16
+    unsigned long long tl = 0, tM = 0, tE = 0, tB = 0, t00 = 0, tC = 0, tS = 0;
+#endif
     // one unit = one (chunk, column group): MFMAs on planes[chunk & 1] with `bfr`, epilogue when the
     // contraction is complete; `bnext` receives the B fragments of the following unit meanwhile
     auto unit = [&](int64_t ti, int pos_kc, int pos_g) {   // positions within the tile; values are rotated
@@ -726,6 +742,19 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         const int64_t tix = blockIdx.x + ti * gridDim.x;
         const int64_t r0 = tix * kTR;
         if (UPT > 1) load_b(bset[1], g, kcv, 1);
+        // ReLU mask words of this unit's slabs, requested before the MFMA phase and unconditionally (a null mask reads a
+        // valid dummy word): a load inside the epilogue would be awaited with vmcnt(0) -- i.e. behind the stores
+        // the previous slab has just issued -- once per slab, whether or not a mask is present
+        constexpr bool BITS_IN = !EXCH && (NG == 3 || NC == 6);
+        unsigned mask_in[NS];
+        if (BITS_IN) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const size_t bix = (static_cast<size_t>(tix) * SLABS + slab_of(g, s)) * 64 + lane;
+                const unsigned* mp = ep.mask_bits ? ep.mask_bits + bix : reinterpret_cast<const unsigned*>(packed) + lane;
+                mask_in[s] = *mp;
+            }
+        }
         if (kc == 0) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -779,6 +808,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                     for (int m = 0; m < 2; ++m)
                         acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[s][TB[t]][ks & 3], acc[s][m], 0, 0, 0);
         }
+        GSTAMP(tM)
+        if (DG_DBG & 128) __builtin_amdgcn_s_setprio(2);
         if (!EXCH && kc == KC - 1) {
             // direct epilogue from the accumulator layout, one (slab, 32-row block) at a time
             constexpr bool BITS = NG == 3 || NC == 6;   // ReLU bit masks in / out: only the fc1-shaped launches use them
@@ -790,8 +821,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                 const float bias = bias_g[g * NS + s];
                 const size_t bix = (static_cast<size_t>(tix) * SLABS + slab) * 64 + lane;
                 unsigned bits = 0xFFFFFFFFu, newbits = 0;
-                if (BITS && ep.mask_bits) bits = ep.mask_bits[bix];
-                float* yb = y + (r0 + 4 * half) * N + n;          // one 64-bit base, constant offsets below
+                if (BITS) bits = ep.mask_bits ? mask_in[s] : 0xFFFFFFFFu;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     float out[16];
@@ -809,18 +839,31 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                         }
                         out[reg] = v;
                     }
-                    // one uniform branch for the tail tile: per-store predicates would put every store in its own
-                    // block and hipcc then drains the queue (vmcnt(0)) in front of each of them
-                    if (full) {
+                    GSTAMP(tC)
+                    // Leave as whole 128-byte row segments: the 32 x 32 block goes through a wave-private 4 KiB LDS tile
+                    // (no barrier: one wave, LDS operations stay in order) and out as four 16-byte-per-lane stores, each
+                    // covering 8 rows -- instead of sixteen 4-byte-per-lane stores, which cost the consumers as much
+                    // time as their MFMAs (profiles/r02_gemm_n384_phases.txt).
+                    {
+                        float* xw = xb + w * (32 * 32);
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) yb[(32 * m + (reg & 3) + 8 * (reg >> 2)) * N] = out[reg];
-                    } else {
+                        for (int reg = 0; reg < 16; ++reg) xw[((reg & 3) + 8 * (reg >> 2) + 4 * half) * 32 + col] = out[reg];
+                        __builtin_amdgcn_wave_barrier();   // compiler-level ordering only: other lanes' writes are read below
+                        float4 rowv[4];
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2);
-                            if (r0 + rr + 4 * half < R) yb[rr * N] = out[reg];
+                        for (int i = 0; i < 4; ++i) rowv[i] = ld4(xw + (8 * i + (lane >> 3)) * 32 + 4 * (lane & 7));
+                        __builtin_amdgcn_wave_barrier();
+                        float* yr = y + (r0 + 32 * m + (lane >> 3)) * N + 32 * slab + 4 * (lane & 7);
+                        if (full) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) st4(yr + static_cast<size_t>(8 * i) * N, rowv[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (r0 + 32 * m + 8 * i + (lane >> 3) < R) st4(yr + static_cast<size_t>(8 * i) * N, rowv[i]);
                         }
                     }
+                    GSTAMP(tS)
                 }
                 if (BITS && ep.relu_bits) ep.relu_bits[bix] = newbits;
             }
@@ -896,11 +939,17 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             if (r0 + kTR <= R) finish_rows(std::false_type{});
             else finish_rows(std::true_type{});
         }
+        GSTAMP(tE)
+        if (DG_DBG & 128) __builtin_amdgcn_s_setprio(0);
         if (pos_g == NG - 1) __syncthreads();   // end of this chunk's iteration
+        GSTAMP(tB)
     };
     load_b(bset[0], NG > 1 ? rot : 0, KC > 1 ? rot : 0, 0);
     if (UPT == 1) load_b(bset[1], 0, 0, 1);
     __syncthreads();   // chunk 0 is in planes[0]
+#if DG_DBG & 16
+    tl = t00 = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
         if constexpr (UPT == 1) {
             unit(ti, 0, 0);
@@ -910,6 +959,14 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         }
     }
     for (int64_t c = nchunks; c < padded; ++c) __syncthreads();   // match the producers' padded iterations
+#if DG_DBG & 16
+    if (lane == 0 && blockIdx.x == 17 && ep.rstd) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(ep.rstd) + 8 * w;
+        o[0] = tM; o[1] = tE; o[2] = tB; o[3] = 0; o[4] = __builtin_amdgcn_s_memtime() - t00; o[5] = my_tiles;
+        o[6] = tC; o[7] = tS;
+    }
+#endif
+#undef GSTAMP
 }
 
 
@@ -1329,17 +1386,20 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         (void)ng;
 #define LAUNCH6(KC_, NG_, EX_)                                                                                     \
     {                                                                                                              \
-        DG_OPT_IN_LDS((&row_gemm_h3_kernel<KC_, NG_, EX_>), kH3Lds);                                               \
-        hipLaunchKernelGGL((row_gemm_h3_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), kH3Lds, stream, a,          \
+        constexpr int lds_ = kH3Lds + (EX_ ? 0 : 4 * 32 * 32 * 4);                                                \
+        DG_OPT_IN_LDS((&row_gemm_h3_kernel<KC_, NG_, EX_>), lds_);                                                 \
+        hipLaunchKernelGGL((row_gemm_h3_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), lds_, stream, a,            \
                            reinterpret_cast<const f16x8*>(packed), y, R, ep);                                      \
     }
         static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
         if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)
-            DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), kH3Lds);
-            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs), dim3(512), kH3Lds, stream, a,
+            constexpr int lds6 = kH3Lds + 6 * 32 * 32 * 4;
+            DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), lds6);
+            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs), dim3(512), lds6, stream, a,
                                reinterpret_cast<const f16x8*>(packed), y, R, ep);
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
         else if (K == 128 && exch) LAUNCH6(1, 1, true)
+        else if (K == 128 && !(mask_bits || relu_bits_out) && getenv("DG_GEMM_PLAIN_EXCH")) LAUNCH6(1, 1, true)
         else if (K == 128) LAUNCH6(1, 1, false)
         else {
             constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;

@@ -3,7 +3,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from druggen_amd import functional as dgf, _lib
-R, K, N = 256 * 45 * 45, 384, 128
+K, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (384, 128)
+R = 256 * 45 * 45
 a = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
 pw = dgf.packed_weight(w, 0)
 y = torch.empty(R, N, device="cuda")
@@ -20,10 +21,13 @@ s_.record()
 for _ in range(20): run()
 e_.record(); torch.cuda.synchronize()
 us = s_.elapsed_time(e_) / 20 * 1e3
-print(f"wave time {us:.1f} us per launch -> {dbg.cpu().view(8, 8)[4, 4].item() / us / 1e3:.2f} GHz if ticks are shader cycles")
+print(f"wave time {us:.1f} us per launch -> {dbg.cpu().view(8, 8)[7, 4].item() / us / 1e3:.2f} GHz if ticks are shader cycles")
 d = dbg.cpu().view(8, 8)
-names = {True: ["write(wait+split)", "fetch issue", "barrier", "store_tile"], False: ["mfma+frags", "fold", "exchange", "barrier"]}
+k384 = K == 384
+names = {True: ["write(wait+split)", "fetch issue", "barrier", "store_tile"],
+         False: ["mfma+frags", "fold", "exchange", "barrier"] if k384 else ["mfma+frags", "epilogue", "barrier", "-"]}
+ncons = 4 if (k384 or N == 128) else 6
 for w_ in range(8):
     r = d[w_].tolist()
-    nm = names[w_ >= 4]
-    print(f"wave {w_} ({'mover' if w_ >= 4 else 'consumer'}): total {r[4]} ticks, tiles {r[5]}: " + ", ".join(f"{n} {v} ({100*v/max(r[4],1):.0f}%)" for n, v in zip(nm, r[:4])))
+    nm = names[w_ >= ncons]
+    print(f"wave {w_} ({'mover' if w_ >= ncons else 'consumer'}): total {r[4]} ticks, tiles {r[5]}: " + ", ".join(f"{n} {v} ({100*v/max(r[4],1):.0f}%)" for n, v in zip(nm, r[:4])) + (f" | epilogue compute {r[6]} stores {r[7]}" if w_ < ncons and not k384 else ""))
