@@ -444,10 +444,15 @@ struct Geometry {
     int lqs, jpl, slices;
 };
 
-bool pick_geometry(int N, int C, Geometry* g) {
+// narrow = true (second-order kernel): for N > 48 a wave takes 16 channels x 16 neighbour phases instead of 32 x 8, so
+// a lane keeps 6 neighbour slots instead of 12 -- the 12-slot second-order kernel needs > 500 registers per lane and
+// spills 400 of them (N = 90: 1071 -> 433 us); the slices of a molecule share an XCD, so the half lines meet in L2.
+// The first-order backward is faster with 12 slots (216 vs 289 us).
+bool pick_geometry(int N, int C, Geometry* g, bool narrow = false) {
     if (C < 8 || (C & 3) || N < 1) return false;
     const int cq = C / 4;
     g->lqs = cq >= 5 ? 3 : (cq >= 3 ? 2 : 1);
+    if (narrow && g->lqs == 3 && N > 48 && N <= 96 && (cq & 3) == 0) g->lqs = 2;
     const int qs = 1 << g->lqs, P = 64 >> g->lqs;
     g->slices = (cq + qs - 1) / qs;
     const int need = (N + P - 1) / P;
@@ -555,7 +560,7 @@ extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_,
         return fail(DG_E_ARG, "dg_attn_core_bwd2: null pointer");
     if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_attn_core_bwd2: unknown dtype %d", dtype);
     Geometry g;
-    if (B < 0 || !pick_geometry(N, C, &g))
+    if (B < 0 || !pick_geometry(N, C, &g, true))
         return fail(DG_E_SHAPE, "dg_attn_core_bwd2: unsupported shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
