@@ -452,7 +452,7 @@ bool pick_geometry(int N, int C, Geometry* g, bool narrow = false) {
     if (C < 8 || (C & 3) || N < 1) return false;
     const int cq = C / 4;
     g->lqs = cq >= 5 ? 3 : (cq >= 3 ? 2 : 1);
-    if (narrow && g->lqs == 3 && N > 48 && N <= 96 && (cq & 3) == 0) g->lqs = 2;
+    if (narrow && g->lqs == 3 && N > 48 && N <= 96 && (cq & 3) == 0) g->lqs = 2;   // N = 45: 365 vs 428 us, stays wide
     const int qs = 1 << g->lqs, P = 64 >> g->lqs;
     g->slices = (cq + qs - 1) / qs;
     const int need = (N + P - 1) / P;
