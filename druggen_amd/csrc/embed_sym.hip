@@ -349,6 +349,171 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------- second order ----
+// Backward of the backward above for the gradient penalty (reference src/model/loss.py:32-39 differentiates
+// d out / d a): t = dL/d(da) [B,N,N,E] is the adjoint of the first backward's input gradient.  Piecewise-linear
+// activations only (ReLU, LeakyReLU: act'' = 0, so nothing reaches a, b1, b2):
+//   da   = W1^T p1,   p1 = (W2^T p2) * act'(h1),   p2 = gs * act'(f)            (first backward, recomputed)
+//   q    = (W1 t) * act'(h1)                                                     [rows, 64]
+//   x    = (W2 q) * act'(f)            gg_ij = gg_ji = (x_ij + x_ji) / 2         adjoint of the upstream gradient g
+//   gW2 += p2^T q                      gW1 += p1^T t
+// Same tile program as the first backward with (q, t) in the places of (h1, a) in the two weight-gradient
+// stages, plus one more layer-2 MFMA pass for x.
+template <typename T, int EP, int ACT>
+__global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
+    const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
+    const T* __restrict__ g, const float* __restrict__ tadj, T* __restrict__ gg, float* __restrict__ part, int B, int N,
+    int E, int tiles_per_mol) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* h1 = reinterpret_cast<float*>(smem_raw);                 // [64][64] swizzled
+    float* d2 = h1 + 64 * kHid;                                      // p2, swizzled [64][128]
+    float* hb = d2 + 64 * kC;                                        // q, swizzled like h1
+    float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(hb + 64 * kHid);
+    float(*tt)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(&at[64][0]);
+    int(*ij)[2] = reinterpret_cast<int(*)[2]>(&tt[64][0]);
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NP = N * (N + 1) / 2;
+    const int ut = w & 1, mt = w >> 1;
+    f32x16 aw2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aw2[0][i] = aw2[1][i] = 0.f;
+    float aw1[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) aw1[e] = 0.f;
+    const int total = B * tiles_per_mol;
+    for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
+        const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
+        stage_tile<EP, ACT>(a, w1, b1, N, E, NP, t, ij, at, h1);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        // adjoint rows, in the same (i,j) / (j,i) arrangement as the inputs
+        for (int idx = tid; idx < 64 * EP; idx += 256) {
+            const int row = idx / EP, e = idx % EP;
+            const int pr = row & 31;
+            const int i = ij[pr][0], j = ij[pr][1];
+            float v = 0.f;
+            if (i >= 0 && e < E) {
+                const int64_t r = (static_cast<int64_t>(t.b) * N + (row < 32 ? i : j)) * N + (row < 32 ? j : i);
+                v = tadj[r * E + e];
+            }
+            tt[row][e] = v;
+        }
+        __syncthreads();
+        {   // q = (W1 t) * act'(h1): thread = (unit u, 16 rows), like layer 1
+            const int u = tid & 63, gq = tid >> 6;
+            float wv[EP];
+#pragma unroll
+            for (int e = 0; e < EP; ++e) wv[e] = e < E ? w1[u * E + e] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int row = gq * 16 + r;
+                float sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < EP; ++e) sacc = fmaf(wv[e], tt[row][e], sacc);
+                const int o = row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3);
+                hb[o] = sacc * act_grad_from_output<ACT>(h1[o]);
+            }
+        }
+        __syncthreads();
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int half = lo >> 5, col = lo & 31, n = 32 * w + col;
+        const float bias2 = b2[n];
+        f32x16 acc0, acc1, q0, q1;
+        {
+            float4 bf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lo) * 4);
+            layer2_mfma(h1, bf, acc0, acc1);
+            layer2_mfma(hb, bf, q0, q1);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const int i = ij[pr][0], j = ij[pr][1];
+            float p0 = 0.f, p1 = 0.f;
+            if (i >= 0) {
+                const int64_t base = static_cast<int64_t>(t.b) * N;
+                float gs = 0.5f * (ld1(g + ((base + i) * N + j) * kC + n) + ld1(g + ((base + j) * N + i) * kC + n));
+                if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
+                const float d0 = act_grad_from_output<ACT>(act_fwd<ACT>(acc0[reg] + bias2));
+                const float d1v = act_grad_from_output<ACT>(act_fwd<ACT>(acc1[reg] + bias2));
+                p0 = gs * d0;
+                p1 = gs * d1v;
+                const float x = 0.5f * (q0[reg] * d0 + q1[reg] * d1v);
+                st1(gg + ((base + i) * N + j) * kC + n, x);
+                st1(gg + ((base + j) * N + i) * kC + n, x);
+            }
+            const int c = n >> 2;
+            d2[pr * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p0;
+            d2[(32 + pr) * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p1;
+            if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // gW2 += p2^T q : contraction over the 64 tile rows
+#pragma unroll 4
+        for (int ks = 0; ks < 32; ++ks) {
+            const int r = 2 * ks + half;
+            const int c = n >> 2;
+            const float av = d2[r * kC + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2) + (n & 3)];
+            const float b0 = hb[r * kHid + ((((col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+            const float b1v = hb[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+            aw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, aw2[0], 0, 0, 0);
+            aw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, aw2[1], 0, 0, 0);
+        }
+        // dh1 = p2 W2 for (row block mt, unit tile ut); p1 = dh1 * act'(h1); gW1 += p1^T t
+        f32x16 dh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dh[i] = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * mt + col;
+            const float4 bd = ld4(w2d + (static_cast<size_t>(ut * 16 + q) * 64 + lo) * 4);
+            const float4 av = ld4(d2 + row * kC + (((16 * half + q) ^ (col & 15)) << 2));
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bd.x, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bd.y, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bd.z, dh, 0, 0, 0);
+            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bd.w, dh, 0, 0, 0);
+        }
+        const int u = 32 * ut + col;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const float hv = h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)];
+            const float p = dh[reg] * act_grad_from_output<ACT>(hv);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, tt[row][e], aw1[e]);
+        }
+        __syncthreads();
+    }
+    // ---- workgroup partials (same layout as the first backward; the bias slots stay zero) ------------
+    const int half = lane >> 5, col = lane & 31;
+    float* pw = part + static_cast<size_t>(blockIdx.x) * BwdPart::kTotal;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int nn = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            pw[BwdPart::kW2 + nn * kHid + 32 * t2 + col] = aw2[t2][reg];
+        }
+    __syncthreads();
+    float* red = d2;   // [4 waves][2 halves][32 cols][kMaxE]
+    {
+        float* slot = red + ((w * 2 + half) * 32 + col) * kMaxE;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) slot[e] = e < EP ? aw1[e < EP ? e : 0] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kHid * kMaxE; idx += 256) {
+        const int uu = idx / kMaxE, e = idx % kMaxE;
+        const int utile = uu >> 5, c = uu & 31;
+        float sum = 0.f;
+        for (int mm = 0; mm < 2; ++mm)
+            for (int hh = 0; hh < 2; ++hh) sum += red[(((utile + 2 * mm) * 2 + hh) * 32 + c) * kMaxE + e];
+        pw[BwdPart::kW1 + uu * kMaxE + e] = sum;
+    }
+}
+
 // out[i] = sum_s part[s][i] (fixed order)
 __global__ __launch_bounds__(256) void embed_reduce_kernel(const float* __restrict__ part, int S, int n,
                                                          float* __restrict__ out) {
@@ -365,9 +530,9 @@ __global__ void embed_unpack_kernel(const float* __restrict__ red, float* __rest
                                     float* __restrict__ dw2, float* __restrict__ db2, int E) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < kC * kHid) dw2[i] = red[BwdPart::kW2 + i];
-    if (i < kC) db2[i] = red[BwdPart::kB2 + i];
+    if (db2 && i < kC) db2[i] = red[BwdPart::kB2 + i];
     if (i < kHid * E) dw1[i] = red[BwdPart::kW1 + (i / E) * kMaxE + (i % E)];
-    if (i < kHid) db1[i] = red[BwdPart::kB1 + i];
+    if (db1 && i < kHid) db1[i] = red[BwdPart::kB1 + i];
 }
 
 // ---------------------------------------------------------------- one-hot inputs ----
@@ -559,6 +724,49 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,
                        E);
     return check_launch("dg_embed_sym_bwd");
+}
+
+extern "C" int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b1, const float* w2_packed,
+                                 const float* w2_dgrad_packed, const float* b2, const void* g, const float* t, void* gg,
+                                 float* gw1, float* gw2, void* workspace, size_t workspace_bytes, int B, int N, int E,
+                                 int H, int C, int act, int dtype, dg_stream_t stream_) {
+    if (!a || !w1 || !b1 || !w2_packed || !w2_dgrad_packed || !b2 || !g || !t || !gg || !gw1 || !gw2 || !workspace)
+        return fail(DG_E_ARG, "dg_embed_sym_bwd2: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_embed_sym_bwd2: unknown dtype %d", dtype);
+    if (act != kRelu && act != kLeaky)
+        return fail(DG_E_ARG, "dg_embed_sym_bwd2: only piecewise-linear activations (relu, leaky) have this closed form");
+    if (B < 1 || !embed_shape_ok(N, E, H, C, act))
+        return fail(DG_E_SHAPE, "dg_embed_sym_bwd2: unsupported B=%d N=%d E=%d H=%d C=%d act=%d", B, N, E, H, C, act);
+    if (workspace_bytes < dg_embed_sym_workspace_bytes(B, N))
+        return fail(DG_E_WORKSPACE, "dg_embed_sym_bwd2: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
+    const int grid = embed_grid(B * tpm, kBwdPerCu);
+    float* part = static_cast<float*>(workspace);
+    float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
+    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kHid + 2 * 64 * kMaxE) * 4 + kPairs * 2 * 4;
+    ProfScope prof(DG_K_EMBED_SYM, stream);
+#define BWD2_A(T, EP_, ACT_)                                                                                       \
+    {                                                                                                              \
+        DG_OPT_IN_LDS((&embed_sym_bwd2_kernel<T, EP_, ACT_>), lds_bytes);                                           \
+        hipLaunchKernelGGL((embed_sym_bwd2_kernel<T, EP_, ACT_>), dim3(grid), dim3(256), lds_bytes, stream, a, w1,  \
+                           b1, w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), t, static_cast<T*>(gg),   \
+                           part, B, N, E, tpm);                                                                    \
+    }
+#define BWD2(T, EP_)                                                     \
+    if (act == kRelu) BWD2_A(T, EP_, kRelu) else BWD2_A(T, EP_, kLeaky)
+    if (dtype == DG_DTYPE_BF16) {
+        if (E <= 8) BWD2(bf16_t, 8) else BWD2(bf16_t, 16)
+    } else {
+        if (E <= 8) BWD2(float, 8) else BWD2(float, 16)
+    }
+#undef BWD2
+#undef BWD2_A
+    hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
+                       BwdPart::kTotal, red);
+    hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, gw1,
+                       static_cast<float*>(nullptr), gw2, static_cast<float*>(nullptr), E);
+    return check_launch("dg_embed_sym_bwd2");
 }
 
 extern "C" size_t dg_onehot_embed_workspace_bytes(int E, int C) {

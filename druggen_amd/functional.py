@@ -1155,26 +1155,79 @@ class _EmbedSym(Function):
         act = ctx.act
         if torch.is_grad_enabled():
             odt = ctx.out_dtype
+            if act in _PIECEWISE_LINEAR:       # native second order (gradient penalty)
+                outs = _EmbedSymBwd.apply(a, w1, b1, w2, b2, g, act, odt, ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1] and not _inputs_only())
+                return tuple(outs) + (None, None)
             return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act).to(odt), (a, w1, b1, w2, b2), g) + (None, None)
+        return _embed_bwd_launch(a, w1, b1, w2, b2, g, act, ctx.out_dtype, ctx.needs_input_grad[0],
+                                 ctx.needs_input_grad[1] and not _inputs_only()) + (None, None)
+
+
+_PIECEWISE_LINEAR = ("relu", "leaky")
+
+
+def _embed_bwd_launch(a, w1, b1, w2, b2, g, act, out_dtype, need_da, need_w):
+    B, N, _, E = a.shape
+    H, C = w1.shape[0], w2.shape[0]
+    lib = _lib.load()
+    g = _c(g if g.dtype == out_dtype else g.to(out_dtype))
+    da = torch.empty_like(a) if need_da else None
+    dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+    need = int(lib.dg_embed_sym_workspace_bytes(B, N))
+    with _dev(a):
+        ws = _scratch(a, need, "embed")
+        _lib.check(lib.dg_embed_sym_bwd(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)),
+                                        _lib.fptr(_embed_packed_w2(w2)), _lib.fptr(_embed_packed_w2(w2, True)),
+                                        _lib.fptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
+                                        _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
+                                        _ACT_IDS[act], _lib.dt(g), _lib.stream_of(a)), "dg_embed_sym_bwd")
+    _account("embed_sym", B * N * N * (4 * E * (2 if da is not None else 1) + g.element_size() * C),
+             2 * B * N * N * (E * H + H * C) * 3)
+    if not need_w:
+        dw1 = db1 = dw2 = db2 = None
+    return da, dw1, db1, dw2, db2
+
+
+class _EmbedSymBwd(Function):
+    """First backward of ``_EmbedSym`` as a differentiable node (piecewise-linear activations): its own backward is
+    ``dg_embed_sym_bwd2`` -- the gradient penalty differentiates d out / d a (reference loss.py:32-39).  Only the
+    adjoint of ``da`` is propagated; adjoints of the parameter gradients would need the composite graph."""
+
+    @staticmethod
+    def forward(ctx, a, w1, b1, w2, b2, g, act, out_dtype, need_da, need_w):
+        ctx.save_for_backward(a, w1, b1, w2, b2, g)
+        ctx.act, ctx.out_dtype = act, out_dtype
+        outs = _embed_bwd_launch(a.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), g.detach(), act,
+                                 out_dtype, need_da, need_w)
+        ctx.mark_non_differentiable(*[o for o in outs[1:] if o is not None])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, t_da, t_dw1, t_db1, t_dw2, t_db2):
+        a, w1, b1, w2, b2, g = ctx.saved_tensors
+        if t_da is None:
+            return (None,) * 10
         B, N, _, E = a.shape
         H, C = w1.shape[0], w2.shape[0]
         lib = _lib.load()
         g = _c(g if g.dtype == ctx.out_dtype else g.to(ctx.out_dtype))
-        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+        t = _c(t_da.float())
+        gg = torch.empty_like(g)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
         need = int(lib.dg_embed_sym_workspace_bytes(B, N))
         with _dev(a):
             ws = _scratch(a, need, "embed")
-            _lib.check(lib.dg_embed_sym_bwd(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)),
-                                            _lib.fptr(_embed_packed_w2(w2)), _lib.fptr(_embed_packed_w2(w2, True)),
-                                            _lib.fptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
-                                            _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
-                                            _ACT_IDS[act], _lib.dt(g), _lib.stream_of(a)), "dg_embed_sym_bwd")
-        _account("embed_sym", B * N * N * (4 * E * (2 if da is not None else 1) + g.element_size() * C),
-                 2 * B * N * N * (E * H + H * C) * 3)
-        if not ctx.needs_input_grad[1] or _inputs_only():
-            dw1 = db1 = dw2 = db2 = None
-        return da, dw1, db1, dw2, db2, None, None
+            _lib.check(lib.dg_embed_sym_bwd2(_lib.fptr(_c(a)), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)),
+                                             _lib.fptr(_embed_packed_w2(w2)), _lib.fptr(_embed_packed_w2(w2, True)),
+                                             _lib.fptr(_c(b2)), _lib.ptr(g), _lib.fptr(t), _lib.ptr(gg), _lib.ptr(gw1),
+                                             _lib.ptr(gw2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
+                                             _ACT_IDS[ctx.act], _lib.dt(g), _lib.stream_of(a)), "dg_embed_sym_bwd2")
+        _account("embed_sym", B * N * N * (8 * E + 2 * g.element_size() * C), 2 * B * N * N * (E * H + H * C) * 4)
+        if _inputs_only() or not ctx.needs_input_grad[1]:
+            gw1 = gw2 = None
+        return None, gw1, None, gw2, None, gg, None, None, None, None
 
 
 def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
@@ -1184,7 +1237,7 @@ def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
     ok = (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape[1] == a.shape[2] and act in _ACT_IDS
           and a.shape[-1] <= 16 and tuple(w1.shape) == (64, a.shape[-1]) and tuple(w2.shape) == (128, 64)
           and b1 is not None and b2 is not None)
-    if not ok or in_second_order_forward():
+    if not ok or (in_second_order_forward() and act not in _PIECEWISE_LINEAR):
         return _composite_embed_sym(a, w1, b1, w2, b2, act).to(out_dtype)
     return _EmbedSym.apply(a, w1, b1, w2, b2, act, out_dtype)
 

@@ -238,6 +238,14 @@ int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1, const flo
                      int B, int N, int E, int H, int C, int act, int dtype, dg_stream_t stream);
 /* dtype: storage of `out` / `g` (the [B,N,N,128] edge tensor); the one-hot input `a`, its gradient and
  * the parameters stay float32.                                                                       */
+/* Backward of dg_embed_sym_bwd for the gradient penalty (src/model/loss.py:32-39 differentiates d out / d a):
+ * t [B,N,N,E] is the adjoint of da.  Outputs: gg [B,N,N,C] (dtype) = adjoint of g, gw1 [H,E], gw2 [C,H] (fp32).
+ * Only the piecewise-linear activations (act = relu, leaky): act'' = 0, so nothing reaches a, b1 and b2 and the
+ * adjoints of dw1/db1/dw2/db2 are not taken (they are not differentiated on this path); others: DG_E_ARG.   */
+int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b1, const float* w2_packed,
+                      const float* w2_dgrad_packed, const float* b2, const void* g, const float* t,
+                      void* gg, float* gw1, float* gw2, void* workspace, size_t workspace_bytes,
+                      int B, int N, int E, int H, int C, int act, int dtype, dg_stream_t stream);
 
 /* One-hot fast path of the same op (reference src/data/utils.py:15-23 makes the generator's input and the
  * discriminator's real batch one-hot): with labels l [B,N,N] (int32, 0 <= l < E) and the E x C table

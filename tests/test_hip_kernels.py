@@ -503,11 +503,15 @@ def test_embed_sym_all_orders(act, B, N, E):
         assert _rel(x, y) < 1e-4, name
     # create_graph path (what the reference loss.py would trigger): second-order through the fallback
     ta = _gen((B, N, N, E), 7)
-    ga = torch.autograd.grad(dgf.embed_sym(*dins, act), dins[0], g.float().cuda(), create_graph=True)[0]
-    gr = torch.autograd.grad(orc.embed(Pr, ins[0], torch.zeros(B, N, 4, dtype=torch.float64), cfg)[1], ins[0], g,
+    gd = g.float().cuda().requires_grad_(True)
+    g64 = g.clone().requires_grad_(True)
+    ga = torch.autograd.grad(dgf.embed_sym(*dins, act), dins[0], gd, create_graph=True)[0]
+    gr = torch.autograd.grad(orc.embed(Pr, ins[0], torch.zeros(B, N, 4, dtype=torch.float64), cfg)[1], ins[0], g64,
                              create_graph=True)[0]
     assert _rel(ga, gr.detach()) < 1e-4
-    if act != "relu" and act != "leaky":         # piecewise-linear activations have zero second derivative
-        h1 = torch.autograd.grad((ga * ta.float().cuda()).sum(), dins[3])[0]
-        h2 = torch.autograd.grad((gr * ta).sum(), ins[3])[0]
-        assert _rel(h1, h2) < 2e-4
+    # second order (what the gradient penalty differentiates): adjoints of w1, w2 and of the upstream gradient.
+    # relu / leaky run dg_embed_sym_bwd2 (act'' = 0); sigmoid / tanh the composite fallback
+    h1 = torch.autograd.grad((ga * ta.float().cuda()).sum(), [dins[1], dins[3], gd])
+    h2 = torch.autograd.grad((gr * ta).sum(), [ins[1], ins[3], g64])
+    for name, x, y in zip("gw1 gw2 gg".split(), h1, h2):
+        assert _rel(x, y) < 2e-4, name
