@@ -192,3 +192,34 @@ def test_two_process_hip_data_parallel_step_equals_single_process(tmp_path):
     n_g = len(gp)
     untouched = [k for k, a, s in zip(names, r0["D"], start[n_g:]) if torch.equal(a, s)]
     assert len(untouched) == 10 and all(".attn.out_e." in k or ".ln4." in k or ".mlp2." in k or ".ln6." in k for k in untouched)
+
+
+_NCCL_WORKER = r"""
+import os, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # exactly bench.py's call
+t = torch.arange(8, dtype=torch.float32, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.AVG)                                   # GradBucket's reduction on RCCL
+dist.broadcast(t, src=0)                                                   # broadcast_parameters
+dist.barrier()
+u = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(u, op=dist.ReduceOp.MAX)                                   # bench.py's max-over-ranks timing
+torch.cuda.synchronize()
+assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32)) and float(u) == 1.5
+dist.destroy_process_group()
+print("rccl ok")
+"""
+
+
+def test_rccl_calls_of_the_multi_gpu_path_run_on_this_build(tmp_path):
+    """The N > 1 path cannot run on a one-GPU box, but every RCCL call it makes can: a one-rank `nccl` group with
+    bench.py's init arguments, GradBucket's AVG all-reduce, broadcast_parameters' broadcast, the barrier and the MAX
+    reduction of the timing.  Catches a missing / mismatched RCCL, an unsupported reduce op or init signature."""
+    script = os.path.join(str(tmp_path), "nccl_worker.py")
+    with open(script, "w") as f:
+        f.write(_NCCL_WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"rccl ok" in p.stdout, p.stdout.decode()[-2000:]
