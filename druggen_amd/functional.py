@@ -12,6 +12,8 @@ import contextlib
 import ctypes
 import weakref
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
