@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     float* d1 = d2 + 64 * kC;                                        // dpre1 [64][65]
     float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(d1 + 64 * (kHid + 1));
     int(*ij)[2] = reinterpret_cast<int(*)[2]>(&at[64][0]);
+    float(*w1s)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(&ij[kPairs][0]);   // W1 [64][16] (input-gradient stage)
+    float* gst = d1;   // symmetrised upstream gradient of the tile [32 pairs][128]: dead before d1 is written
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (da) {
+        for (int idx = tid; idx < kHid * kMaxE; idx += 256) w1s[idx / kMaxE][idx % kMaxE] = (idx % kMaxE) < E ? w1[(idx / kMaxE) * E + (idx % kMaxE)] : 0.f;
+    }
     const int half = lane >> 5, col = lane & 31;
     const int NP = N * (N + 1) / 2;
     // weight fragments are re-read per tile (L2 hits) instead of pinning 96 VGPRs for the whole kernel
@@ -221,14 +226,38 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < EP; ++e) aw1[e] = 0.f;
     const int total = B * tiles_per_mol;
+#ifdef DG_EMBED_DBG
+    unsigned long long tl = __builtin_amdgcn_s_memtime(), ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t00 = tl;
+#define ESTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts[i] += t_ - tl; tl = t_; }
+#else
+#define ESTAMP(i)
+#endif
     for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
         stage_tile<EP, ACT>(a, w1, b1, N, E, NP, t, ij, at, h1);
+        ESTAMP(0)
         // Per-iteration opaque copy of the lane id: every swizzled LDS offset below is derived from it, so hipcc cannot
         // hoist the ~200 loop-invariant offsets out of the tile loop (it did, and spilled 150 of them to scratch).
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const int half = lo >> 5, col = lo & 31, n = 32 * w + col;
+        // upstream gradient rows (b,i,j) and (b,j,i) of the tile's 32 pairs: whole rows (one half-wave per row, 8 loads
+        // in flight per lane) requested before the layer-2 MFMAs, symmetrised into LDS after them -- instead of 64
+        // dependent scalar gathers per lane from the accumulator layout
+        typedef typename raw4<T>::type Raw;
+        Raw gr[4][2];
+        {
+            const int hw = lo >> 5 | (w << 1), l32 = lo & 31;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = hw + 8 * it;
+                const int i = ij[pr][0], j = ij[pr][1];
+                const int64_t base = static_cast<int64_t>(t.b) * N;
+                const int ii = i >= 0 ? i : 0, jj = i >= 0 ? j : 0;       // empty pairs read a valid row, result unused
+                gr[it][0] = ld_raw(g + ((base + ii) * N + jj) * kC + 4 * l32);
+                gr[it][1] = ld_raw(g + ((base + jj) * N + ii) * kC + 4 * l32);
+            }
+        }
         f32x16 acc0, acc1;
         {
             float4 bf[8];
@@ -236,6 +265,18 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lane) * 4);
             layer2_mfma(h1, bf, acc0, acc1);
         }
+        {
+            const int hw = lo >> 5 | (w << 1), l32 = lo & 31;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = hw + 8 * it;
+                const bool diag = ij[pr][0] == ij[pr][1];
+                const float4 v = (diag ? 0.25f : 0.5f) * (cvt_raw(gr[it][0]) + cvt_raw(gr[it][1]));   // diagonal: both blocks carry half
+                st4(gst + pr * kC + 4 * l32, ij[pr][0] >= 0 ? v : f4(0.f));
+            }
+        }
+        __syncthreads();
+        ESTAMP(1)
         // dpre2 in the accumulator layout -> LDS (swizzled like a row-GEMM A tile)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -243,21 +284,20 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             const int i = ij[pr][0], j = ij[pr][1];
             float p0 = 0.f, p1 = 0.f;
             if (i >= 0) {
-                const int64_t base = static_cast<int64_t>(t.b) * N;
-                float gs = 0.5f * (ld1(g + ((base + i) * N + j) * kC + n) + ld1(g + ((base + j) * N + i) * kC + n));
-                if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
+                const float gs = gst[pr * kC + n];
                 p0 = gs * act_grad_from_output<ACT>(act_fwd<ACT>(acc0[reg] + bias2));
                 p1 = gs * act_grad_from_output<ACT>(act_fwd<ACT>(acc1[reg] + bias2));
             }
+            (void)j;
             ab2 += p0 + p1;
             const int c = n >> 2;
             d2[pr * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p0;
             d2[(32 + pr) * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p1;
             // four rows at a time: without the fence hipcc hoists all 64 gradient loads (and their addresses) above
             // the loop, 428 registers per lane = one wave per SIMD
-            if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        ESTAMP(2)
         // dW2 += dpre2^T h1 : contraction over the 64 tile rows, operands by ds_read_b32
 #pragma unroll 4
         for (int ks = 0; ks < 32; ++ks) {
@@ -269,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             aw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, aw2[0], 0, 0, 0);
             aw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, aw2[1], 0, 0, 0);
         }
+        ESTAMP(3)
         // dh1 = dpre2 W2 for (row block mt, unit tile ut); dpre1 = dh1 * act'(h1)
         f32x16 dh;
 #pragma unroll
@@ -283,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bd.z, dh, 0, 0, 0);
             dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bd.w, dh, 0, 0, 0);
         }
+        ESTAMP(4)
         const int u = 32 * ut + col;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -294,26 +336,40 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, at[row][e], aw1[e]);
             if (da) d1[row * (kHid + 1) + u] = p;
         }
+        ESTAMP(5)
         if (da) {
             __syncthreads();
-            for (int idx = tid; idx < 64 * E; idx += 256) {
-                const int row = idx / E, e = idx % E;
-                const int pr = row & 31;
-                const int i = ij[pr][0], j = ij[pr][1];
-                if (i < 0 || (row >= 32 && i == j)) continue;      // diagonal: written once below
-                float s = 0.f;
-                for (int uu = 0; uu < kHid; ++uu) s = fmaf(d1[row * (kHid + 1) + uu], w1[uu * E + e], s);
-                if (i == j) {                                       // both blocks carry half of it
-                    float s2 = 0.f;
-                    for (int uu = 0; uu < kHid; ++uu) s2 = fmaf(d1[(32 + pr) * (kHid + 1) + uu], w1[uu * E + e], s2);
-                    s += s2;
-                }
+            // da[row][e] = sum_u dpre1[row][u] W1[u][e]: thread = (tile row, e mod 4); the two halves of a diagonal pair
+            // (rows pr and 32 + pr = lanes pr and 32 + pr of the wave) are summed across the wave
+            const int row = lo, eg = w;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int uu = 0; uu < kHid; ++uu) {
+                const float dv = d1[row * (kHid + 1) + uu];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] = fmaf(dv, w1s[uu][eg + 4 * q], s[q]);
+            }
+            const int pr = row & 31;
+            const int i = ij[pr][0], j = ij[pr][1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float other = __shfl_xor(s[q], 32, 64);
+                const int e = eg + 4 * q;
+                if (i < 0 || e >= E || (row >= 32 && i == j)) continue;
                 const int64_t r = (static_cast<int64_t>(t.b) * N + (row < 32 ? i : j)) * N + (row < 32 ? j : i);
-                da[r * E + e] = s;
+                da[r * E + e] = i == j ? s[q] + other : s[q];
             }
         }
         __syncthreads();
+        ESTAMP(6)
     }
+#ifdef DG_EMBED_DBG
+    if (lane == 0 && blockIdx.x == 17) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(part + static_cast<size_t>(gridDim.x + 1) * BwdPart::kTotal) + 8 * w;
+        for (int i = 0; i < 7; ++i) o[i] = ts[i];
+        o[7] = __builtin_amdgcn_s_memtime() - t00;
+    }
+#endif
     // ---- workgroup partials ----------------------------------------------------------------
     float* pw = part + static_cast<size_t>(blockIdx.x) * BwdPart::kTotal;
 #pragma unroll
@@ -611,7 +667,7 @@ extern "C" size_t dg_embed_sym_packed_floats(void) { return static_cast<size_t>(
 
 extern "C" size_t dg_embed_sym_workspace_bytes(int B, int N) {
     const int tiles = B * ((N * (N + 1) / 2 + kPairs - 1) / kPairs);
-    return (static_cast<size_t>(embed_grid(tiles, kBwdPerCu)) + 1) * BwdPart::kTotal * sizeof(float);
+    return (static_cast<size_t>(embed_grid(tiles, kBwdPerCu)) + 1) * BwdPart::kTotal * sizeof(float) + 256;   // + debug stamps
 }
 
 extern "C" int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream_) {
@@ -697,7 +753,7 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
-    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE) * 4 + kPairs * 2 * 4;
+    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE + kHid * kMaxE) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
 #define BWD_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                             \
