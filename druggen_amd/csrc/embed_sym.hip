@@ -48,16 +48,6 @@ __device__ __forceinline__ float act_grad_from_output(float y) {
     }
 }
 
-// packed W2 for K = 64: P[(t*8 + q)*64 + lane] = { W2[32t + n][32h + 4q + j] }_j, n = lane&31, h = lane>>5
-__global__ void pack_w2_k64_kernel(const float* __restrict__ w2, float* __restrict__ p, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = (C / 32) * 8 * 64;
-    if (idx >= total) return;
-    const int lane = idx & 63, q = (idx >> 6) & 7, t = idx >> 9;
-    const float* src = w2 + static_cast<size_t>(32 * t + (lane & 31)) * kHid + 32 * (lane >> 5) + 4 * q;
-    st4(p + static_cast<size_t>(idx) * 4, ld4(src));
-}
-
 struct PairTile {
     int b;        // molecule
     int p0;       // first pair of the tile
@@ -125,24 +115,97 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ a, const fl
     __syncthreads();
 }
 
-// layer 2 on the MFMA: this wave's 32-column slab for both orientations
-__device__ __forceinline__ void layer2_mfma(const float* h1, const float4 (&bf)[8], f32x16& acc0, f32x16& acc1) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+// ---- bf16 x 3 arithmetic of the MFMA stages (fp32 class) ----------------------------------------------------------
+// Every fp32 operand value is split exactly into three bf16 by truncation (h = top 16 bits, m = top 16 bits of x - h,
+// l = top 16 bits of x - h - m: together all 24 significand bits) and the six cross products with i + j <= 4 run on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the arithmetic of the weight-gradient kernel (linear_wgrad.hip).
+// 48 MFMAs of 32 cycles per stage instead of 64 fp32 MFMAs of 64 cycles.  LDS tiles stay fp32; fragments are split in
+// registers.  Weight operands arrive pre-split ([k-step][plane][lane] x 8 bf16, embed_pack3_kernel).
+typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+struct Planes { bf16x8 p[3]; };
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned a0 = __float_as_uint(x0), a1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(a0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(a1 & 0xFFFF0000u);
+    const unsigned b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(b0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(b1 & 0xFFFF0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ Planes split8(const float (&v)[8]) {
+    u32x4e h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hh, mm, ll;
+        split2(v[2 * i], v[2 * i + 1], hh, mm, ll);
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = ll;
+    }
+    Planes r;
+    r.p[0] = __builtin_bit_cast(bf16x8, h);
+    r.p[1] = __builtin_bit_cast(bf16x8, m);
+    r.p[2] = __builtin_bit_cast(bf16x8, l);
+    return r;
+}
+__device__ __forceinline__ Planes split8(const float4& a, const float4& b) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return split8(v);
+}
+__device__ __forceinline__ f32x16 mfma6(const Planes& a, const Planes& b, f32x16 c) {
+    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[t]], b.p[TB[t]], c, 0, 0, 0);
+    return c;
+}
+// eight consecutive k (chunks c, c + 1 of four floats) of row `row` of an XOR-swizzled fp32 tile with `pitch` floats
+__device__ __forceinline__ Planes frag_row(const float* tile, int row, int c, int pitch) {
+    const float4 a = ld4(tile + row * pitch + ((c ^ (row & 15)) << 2));
+    const float4 b = ld4(tile + row * pitch + (((c + 1) ^ (row & 15)) << 2));
+    return split8(a, b);
+}
+__device__ __forceinline__ Planes load_planes(const bf16x8* p) {   // [plane][lane] of one (tile, k-step)
+    Planes r;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.p[q] = p[q * 64];
+    return r;
+}
+
+// layer 2: this wave's 32-column slab for both orientations, K = 64 = four k-steps.  `w2f` points at the slab's
+// pre-split fragments for this lane.
+__device__ __forceinline__ void layer2_mfma(const float* h1, const bf16x8* w2f, int lane, f32x16& acc0, f32x16& acc1) {
+    const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 a0 = ld4(h1 + col * kHid + (((8 * half + q) ^ (col & 15)) << 2));
-        const float4 a1 = ld4(h1 + (32 + col) * kHid + (((8 * half + q) ^ (col & 15)) << 2));
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf[q].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf[q].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf[q].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf[q].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf[q].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf[q].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf[q].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf[q].w, acc1, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+        const Planes b = load_planes(w2f + ks * 3 * 64);
+        const Planes a0 = frag_row(h1, col, 4 * ks + 2 * half, kHid);
+        const Planes a1 = frag_row(h1, 32 + col, 4 * ks + 2 * half, kHid);
+        acc0 = mfma6(a0, b, acc0);
+        acc1 = mfma6(a1, b, acc1);
     }
+}
+
+// Pre-split layer-2 weight operands: P[((t * KS + ks) * 3 + plane) * 64 + lane] = 8 bf16 { B[16 ks + 8 (lane >> 5) + j][32 t + (lane & 31)] }_j.
+//   dgrad = 0: B[k][n] = W2[n][k]  (forward: k = hidden unit, n = channel; 4 slabs x 4 k-steps)
+//   dgrad = 1: B[k][n] = W2[k][n]  (dh = dz2 W2: k = channel, n = hidden unit; 2 tiles x 8 k-steps)
+__global__ void embed_pack3_kernel(const float* __restrict__ w2, bf16x8* __restrict__ p, int dgrad) {
+    const int KS = dgrad ? 8 : 4, NT = dgrad ? 2 : 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one (t, ks, lane)
+    if (idx >= NT * KS * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % KS, t = (idx >> 6) / KS;
+    const int n = 32 * t + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * ks + 8 * (lane >> 5) + j;
+        v[j] = dgrad ? w2[static_cast<size_t>(k) * kHid + n] : w2[static_cast<size_t>(n) * kHid + k];
+    }
+    const Planes pl = split8(v);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[(static_cast<size_t>(t * KS + ks) * 3 + q) * 64 + lane] = pl.p[q];
 }
 
 template <typename T, int EP, int ACT>
@@ -157,9 +220,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
     const int NP = N * (N + 1) / 2;
-    float4 bf[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lane) * 4);
+    const bf16x8* w2f = reinterpret_cast<const bf16x8*>(w2p) + static_cast<size_t>(w) * 4 * 3 * 64 + lane;
     const int n = 32 * w + col;
     const float bias2 = b2[n];
     const int total = B * tiles_per_mol;
@@ -167,7 +228,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
         const PairTile t{tix / tiles_per_mol, (tix % tiles_per_mol) * kPairs};
         stage_tile<EP, ACT>(a, w1, b1, N, E, NP, t, ij, at, h1);
         f32x16 acc0, acc1;
-        layer2_mfma(h1, bf, acc0, acc1);
+        layer2_mfma(h1, w2f, lane, acc0, acc1);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
@@ -180,6 +241,41 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
         }
         __syncthreads();   // LDS tiles are reused by the next iteration
     }
+}
+
+// W-gradient stage of the backward kernels: aw2[t] += P^T Q over the 64 tile rows (four k-steps of 16 rows), P = the
+// wave's 32 output channels of the [64][128] tile `d2`, Q = unit tiles t = 0, 1 of the [64][64] tile `hq`.  Operands are
+// gathered column-wise (eight ds_read_b32 per fragment: a lane's eight rows of one column) and split in registers.
+__device__ __forceinline__ void aw2_stage(const float* d2, const float* hq, int n, int col, int half, f32x16 (&aw2)[2]) {
+    const int c = n >> 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float av[8], b0[8], b1v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * ks + 8 * half + j;
+            av[j] = d2[r * kC + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2) + (n & 3)];
+            b0[j] = hq[r * kHid + ((((col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+            b1v[j] = hq[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
+        }
+        const Planes pa = split8(av);
+        aw2[0] = mfma6(pa, split8(b0), aw2[0]);
+        aw2[1] = mfma6(pa, split8(b1v), aw2[1]);
+    }
+}
+// dh1 = P W2 for one (32-row block, 32-unit tile): K = 128 channels = eight k-steps, two accumulator chains
+__device__ __forceinline__ f32x16 dh_stage(const float* d2, const bf16x8* w2g, int row, int half) {
+    f32x16 d0, d1v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d0[i] = d1v[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks += 2) {
+        d0 = mfma6(frag_row(d2, row, 4 * ks + 2 * half, kC), load_planes(w2g + ks * 3 * 64), d0);
+        d1v = mfma6(frag_row(d2, row, 4 * (ks + 1) + 2 * half, kC), load_planes(w2g + (ks + 1) * 3 * 64), d1v);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d0[i] += d1v[i];
+    return d0;
 }
 
 // ------------------------------------------------------------------------------- backward ----
@@ -259,12 +355,7 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             }
         }
         f32x16 acc0, acc1;
-        {
-            float4 bf[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lane) * 4);
-            layer2_mfma(h1, bf, acc0, acc1);
-        }
+        layer2_mfma(h1, reinterpret_cast<const bf16x8*>(w2p) + static_cast<size_t>(w) * 4 * 3 * 64 + lo, lo, acc0, acc1);
         {
             const int hw = lo >> 5 | (w << 1), l32 = lo & 31;
 #pragma unroll
@@ -299,31 +390,10 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
         __syncthreads();
         ESTAMP(2)
         // dW2 += dpre2^T h1 : contraction over the 64 tile rows, operands by ds_read_b32
-#pragma unroll 4
-        for (int ks = 0; ks < 32; ++ks) {
-            const int r = 2 * ks + half;
-            const int c = n >> 2;
-            const float av = d2[r * kC + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2) + (n & 3)];
-            const float b0 = h1[r * kHid + ((((col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
-            const float b1v = h1[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
-            aw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, aw2[0], 0, 0, 0);
-            aw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, aw2[1], 0, 0, 0);
-        }
+        aw2_stage(d2, h1, n, col, half, aw2);
         ESTAMP(3)
         // dh1 = dpre2 W2 for (row block mt, unit tile ut); dpre1 = dh1 * act'(h1)
-        f32x16 dh;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = 0.f;
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int row = 32 * mt + col;
-            const float4 bd = ld4(w2d + (static_cast<size_t>(ut * 16 + q) * 64 + lane) * 4);
-            const float4 av = ld4(d2 + row * kC + (((16 * half + q) ^ (col & 15)) << 2));
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bd.x, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bd.y, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bd.z, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bd.w, dh, 0, 0, 0);
-        }
+        const f32x16 dh = dh_stage(d2, reinterpret_cast<const bf16x8*>(w2d) + static_cast<size_t>(ut) * 8 * 3 * 64 + lo, 32 * mt + col, half);
         ESTAMP(4)
         const int u = 32 * ut + col;
 #pragma unroll
@@ -477,11 +547,9 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
         const float bias2 = b2[n];
         f32x16 acc0, acc1, q0, q1;
         {
-            float4 bf[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bf[q] = ld4(w2p + (static_cast<size_t>(w * 8 + q) * 64 + lo) * 4);
-            layer2_mfma(h1, bf, acc0, acc1);
-            layer2_mfma(hb, bf, q0, q1);
+            const bf16x8* w2f = reinterpret_cast<const bf16x8*>(w2p) + static_cast<size_t>(w) * 4 * 3 * 64 + lo;
+            layer2_mfma(h1, w2f, lo, acc0, acc1);
+            layer2_mfma(hb, w2f, lo, q0, q1);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -507,30 +575,9 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
         }
         __syncthreads();
         // gW2 += p2^T q : contraction over the 64 tile rows
-#pragma unroll 4
-        for (int ks = 0; ks < 32; ++ks) {
-            const int r = 2 * ks + half;
-            const int c = n >> 2;
-            const float av = d2[r * kC + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2) + (n & 3)];
-            const float b0 = hb[r * kHid + ((((col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
-            const float b1v = hb[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
-            aw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, aw2[0], 0, 0, 0);
-            aw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1v, aw2[1], 0, 0, 0);
-        }
+        aw2_stage(d2, hb, n, col, half, aw2);
         // dh1 = p2 W2 for (row block mt, unit tile ut); p1 = dh1 * act'(h1); gW1 += p1^T t
-        f32x16 dh;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dh[i] = 0.f;
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int row = 32 * mt + col;
-            const float4 bd = ld4(w2d + (static_cast<size_t>(ut * 16 + q) * 64 + lo) * 4);
-            const float4 av = ld4(d2 + row * kC + (((16 * half + q) ^ (col & 15)) << 2));
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bd.x, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bd.y, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bd.z, dh, 0, 0, 0);
-            dh = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bd.w, dh, 0, 0, 0);
-        }
+        const f32x16 dh = dh_stage(d2, reinterpret_cast<const bf16x8*>(w2d) + static_cast<size_t>(ut) * 8 * 3 * 64 + lo, 32 * mt + col, half);
         const int u = 32 * ut + col;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -663,7 +710,7 @@ bool embed_shape_ok(int N, int E, int H, int C, int act) {
 
 using namespace dg;
 
-extern "C" size_t dg_embed_sym_packed_floats(void) { return static_cast<size_t>(kC / 32) * 8 * 64 * 4; }
+extern "C" size_t dg_embed_sym_packed_floats(void) { return static_cast<size_t>(4) * 4 * 3 * 64 * 4; }   // 16 B per entry
 
 extern "C" size_t dg_embed_sym_workspace_bytes(int B, int N) {
     const int tiles = B * ((N * (N + 1) / 2 + kPairs - 1) / kPairs);
@@ -672,36 +719,17 @@ extern "C" size_t dg_embed_sym_workspace_bytes(int B, int N) {
 
 extern "C" int dg_embed_sym_pack(const float* w2, float* packed, dg_stream_t stream_) {
     if (!w2 || !packed) return fail(DG_E_ARG, "dg_embed_sym_pack: null pointer");
-    const int total = (kC / 32) * 8 * 64;
-    hipLaunchKernelGGL(pack_w2_k64_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), w2,
-                       packed, kC);
+    hipLaunchKernelGGL(embed_pack3_kernel, dim3(4), dim3(256), 0, static_cast<hipStream_t>(stream_), w2,
+                       reinterpret_cast<bf16x8*>(packed), 0);
     return check_launch("dg_embed_sym_pack");
 }
 
-// Input-gradient operand of layer 2 in fp32 MFMA fragment order (independent of the row-GEMM mode):
-// P[(t*16 + q)*64 + lane] = { W2[64h + 4q + j][32t + n] }_j for the 2 output slabs t of dh1 = dz2 . W2.
-__global__ void embed_pack_dgrad_kernel(const float* __restrict__ w2, float* __restrict__ p, int H, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each: (t, q, lane)
-    const int n_tiles = (H + 31) / 32;
-    if (idx >= n_tiles * 16 * 64) return;
-    const int lane = idx & 63, q = (idx >> 6) & 15, t = idx >> 10;
-    const int n = 32 * t + (lane & 31);
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = 64 * (lane >> 5) + 4 * q + j;
-        v[j] = (k < C && n < H) ? w2[static_cast<size_t>(k) * H + n] : 0.f;
-    }
-    st4(p + static_cast<size_t>(idx) * 4, make_float4(v[0], v[1], v[2], v[3]));
-}
-
-extern "C" size_t dg_embed_sym_dgrad_packed_floats(void) { return static_cast<size_t>(kHid / 32) * 16 * 64 * 4; }
+extern "C" size_t dg_embed_sym_dgrad_packed_floats(void) { return static_cast<size_t>(2) * 8 * 3 * 64 * 4; }
 
 extern "C" int dg_embed_sym_pack_dgrad(const float* w2, float* packed, dg_stream_t stream_) {
     if (!w2 || !packed) return fail(DG_E_ARG, "dg_embed_sym_pack_dgrad: null pointer");
-    const int total = (kHid / 32) * 16 * 64;
-    hipLaunchKernelGGL(embed_pack_dgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                       w2, packed, kHid, kC);
+    hipLaunchKernelGGL(embed_pack3_kernel, dim3(4), dim3(256), 0, static_cast<hipStream_t>(stream_), w2,
+                       reinterpret_cast<bf16x8*>(packed), 1);
     return check_launch("dg_embed_sym_pack_dgrad");
 }
 
