@@ -23,6 +23,7 @@ constexpr int kHid = 64;     // hidden width of the embedding MLP (fixed by the 
 constexpr int kC = 128;      // output width handled by this kernel
 constexpr int kPairs = 32;   // atom pairs per tile
 constexpr int kMaxE = 16;
+constexpr int kD1Pitch = 68;   // floats per row of the dpre1 tile (16-byte aligned rows, conflict-free b128 reads)
 
 enum Act { kRelu = 0, kLeaky = 1, kSigmoid = 2, kTanh = 3 };
 
@@ -300,15 +301,20 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* h1 = reinterpret_cast<float*>(smem_raw);                 // [64][64] swizzled
     float* d2 = h1 + 64 * kHid;                                      // dpre2, swizzled [64][128]
-    float* d1 = d2 + 64 * kC;                                        // dpre1 [64][65]
-    float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(d1 + 64 * (kHid + 1));
+    float* d1 = d2 + 64 * kC;                                        // dpre1 [64][kD1Pitch]
+    float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(d1 + 64 * kD1Pitch);
     int(*ij)[2] = reinterpret_cast<int(*)[2]>(&at[64][0]);
-    float(*w1s)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(&ij[kPairs][0]);   // W1 [64][16] (input-gradient stage)
+    float4* w1p = reinterpret_cast<float4*>(&ij[kPairs][0]);   // W1 permuted: w1p[u * 4 + eg] = { W1[u][eg + 4 q] }_q
     float* gst = d1;   // symmetrised upstream gradient of the tile [32 pairs][128]: dead before d1 is written
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (da) {
-        for (int idx = tid; idx < kHid * kMaxE; idx += 256) w1s[idx / kMaxE][idx % kMaxE] = (idx % kMaxE) < E ? w1[(idx / kMaxE) * E + (idx % kMaxE)] : 0.f;
+    if (da) {   // visible after the first barrier of the tile loop
+        const int u = tid >> 2, eg = tid & 3;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = eg + 4 * q < E ? w1[u * E + eg + 4 * q] : 0.f;
+        w1p[tid] = make_float4(v[0], v[1], v[2], v[3]);
     }
+
     const int half = lane >> 5, col = lane & 31;
     const int NP = N * (N + 1) / 2;
     // weight fragments are re-read per tile (L2 hits) instead of pinning 96 VGPRs for the whole kernel
@@ -402,9 +408,15 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             const float hv = h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)];
             const float p = dh[reg] * act_grad_from_output<ACT>(hv);
             ab1 += p;
+            float av[EP];
 #pragma unroll
-            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, at[row][e], aw1[e]);
-            if (da) d1[row * (kHid + 1) + u] = p;
+            for (int e4 = 0; e4 < EP; e4 += 4) {       // the row's inputs as 16-byte LDS reads (broadcast within a half-wave)
+                const float4 t4 = ld4(&at[row][e4]);
+                av[e4] = t4.x; av[e4 + 1] = t4.y; av[e4 + 2] = t4.z; av[e4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, av[e], aw1[e]);
+            if (da) d1[row * kD1Pitch + u] = p;
         }
         ESTAMP(5)
         if (da) {
@@ -413,11 +425,20 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             // (rows pr and 32 + pr = lanes pr and 32 + pr of the wave) are summed across the wave
             const int row = lo, eg = w;
             float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int uu = 0; uu < kHid; ++uu) {
-                const float dv = d1[row * (kHid + 1) + uu];
+            // dpre1 as 16-byte reads (row pitch 68 floats: the eight lanes of a quarter-wave cover all 32 banks), the four
+            // W1 entries of (unit, eg) as one broadcast 16-byte read
+#pragma unroll 4
+            for (int u4 = 0; u4 < kHid; u4 += 4) {
+                const float4 dv = ld4(d1 + row * kD1Pitch + u4);
+                const float dvv[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s[q] = fmaf(dv, w1s[uu][eg + 4 * q], s[q]);
+                for (int uu = 0; uu < 4; ++uu) {
+                    const float4 wv = w1p[(u4 + uu) * 4 + eg];
+                    s[0] = fmaf(dvv[uu], wv.x, s[0]);
+                    s[1] = fmaf(dvv[uu], wv.y, s[1]);
+                    s[2] = fmaf(dvv[uu], wv.z, s[2]);
+                    s[3] = fmaf(dvv[uu], wv.w, s[3]);
+                }
             }
             const int pr = row & 31;
             const int i = ij[pr][0], j = ij[pr][1];
@@ -584,8 +605,14 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
             const int row = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const float hv = h1[row * kHid + (((u >> 2) ^ (row & 15)) << 2) + (u & 3)];
             const float p = dh[reg] * act_grad_from_output<ACT>(hv);
+            float av[EP];
 #pragma unroll
-            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, tt[row][e], aw1[e]);
+            for (int e4 = 0; e4 < EP; e4 += 4) {
+                const float4 t4 = ld4(&tt[row][e4]);
+                av[e4] = t4.x; av[e4 + 1] = t4.y; av[e4 + 2] = t4.z; av[e4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, av[e], aw1[e]);
         }
         __syncthreads();
     }
@@ -781,7 +808,7 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
-    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * (kHid + 1) + 64 * kMaxE + kHid * kMaxE) * 4 + kPairs * 2 * 4;
+    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kD1Pitch + 64 * kMaxE + kHid * 16) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
 #define BWD_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                             \
