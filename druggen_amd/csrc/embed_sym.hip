@@ -209,6 +209,24 @@ __global__ void embed_pack3_kernel(const float* __restrict__ w2, bf16x8* __restr
     for (int q = 0; q < 3; ++q) p[(static_cast<size_t>(t * KS + ks) * 3 + q) * 64 + lane] = pl.p[q];
 }
 
+// A [32 pairs][128] fp32 LDS tile holds one value per (pair, channel); both orientations (b,i,j) and (b,j,i) of a
+// pair receive it as whole rows: one half-wave per row, 16 bytes (fp32) / 8 bytes (bf16) per lane.
+template <typename T>
+__device__ __forceinline__ void store_pair_rows(const float* xt, const int (*ij)[2], int b, int N, T* __restrict__ out,
+                                                int tid) {
+    const int hw = tid >> 5, l32 = tid & 31;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pr = hw + 8 * it;
+        const int i = ij[pr][0], j = ij[pr][1];
+        if (i < 0) continue;
+        const float4 v = ld4(xt + pr * kC + 4 * l32);
+        const int64_t base = static_cast<int64_t>(b) * N;
+        st4(out + ((base + i) * N + j) * kC + 4 * l32, v);
+        if (i != j) st4(out + ((base + j) * N + i) * kC + 4 * l32, v);
+    }
+}
+
 template <typename T, int EP, int ACT>
 __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w1,
                                                           const float* __restrict__ b1,
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
     __shared__ int ij[kPairs][2];
     __shared__ float at[64][kMaxE];
     __shared__ __attribute__((aligned(16))) float h1[64 * kHid];
+    __shared__ __attribute__((aligned(16))) float xt[kPairs * kC];    // symmetrised outputs of the tile
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
     const int NP = N * (N + 1) / 2;
@@ -233,13 +252,10 @@ __global__ __launch_bounds__(256) void embed_sym_fwd_kernel(const float* __restr
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            const int i = ij[pr][0], j = ij[pr][1];
-            if (i < 0) continue;
-            const float s = 0.5f * (act_fwd<ACT>(acc0[reg] + bias2) + act_fwd<ACT>(acc1[reg] + bias2));
-            const int64_t base = static_cast<int64_t>(t.b) * N;
-            st1(out + ((base + i) * N + j) * kC + n, s);
-            st1(out + ((base + j) * N + i) * kC + n, s);
+            xt[pr * kC + n] = 0.5f * (act_fwd<ACT>(acc0[reg] + bias2) + act_fwd<ACT>(acc1[reg] + bias2));
         }
+        __syncthreads();
+        store_pair_rows(xt, ij, t.b, N, out, static_cast<int>(threadIdx.x));
         __syncthreads();   // LDS tiles are reused by the next iteration
     }
 }
@@ -519,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
     float(*at)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(hb + 64 * kHid);
     float(*tt)[kMaxE] = reinterpret_cast<float(*)[kMaxE]>(&at[64][0]);
     int(*ij)[2] = reinterpret_cast<int(*)[2]>(&tt[64][0]);
+    float* gst = reinterpret_cast<float*>(&ij[kPairs][0]);           // symmetrised upstream gradient [32][128], then x
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NP = N * (N + 1) / 2;
     const int ut = w & 1, mt = w >> 1;
@@ -566,35 +583,57 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
         asm volatile("" : "+v"(lo));
         const int half = lo >> 5, col = lo & 31, n = 32 * w + col;
         const float bias2 = b2[n];
+        typedef typename raw4<T>::type Raw;
+        Raw gr[4][2];
+        {   // upstream gradient rows of the 32 pairs, whole rows (see the first backward)
+            const int hw = lo >> 5 | (w << 1), l32 = lo & 31;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = hw + 8 * it;
+                const int i = ij[pr][0], j = ij[pr][1];
+                const int64_t base = static_cast<int64_t>(t.b) * N;
+                const int ii = i >= 0 ? i : 0, jj = i >= 0 ? j : 0;
+                gr[it][0] = ld_raw(g + ((base + ii) * N + jj) * kC + 4 * l32);
+                gr[it][1] = ld_raw(g + ((base + jj) * N + ii) * kC + 4 * l32);
+            }
+        }
         f32x16 acc0, acc1, q0, q1;
         {
             const bf16x8* w2f = reinterpret_cast<const bf16x8*>(w2p) + static_cast<size_t>(w) * 4 * 3 * 64 + lo;
             layer2_mfma(h1, w2f, lo, acc0, acc1);
             layer2_mfma(hb, w2f, lo, q0, q1);
         }
+        {
+            const int hw = lo >> 5 | (w << 1), l32 = lo & 31;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pr = hw + 8 * it;
+                const bool diag = ij[pr][0] == ij[pr][1];
+                const float4 v = (diag ? 0.25f : 0.5f) * (cvt_raw(gr[it][0]) + cvt_raw(gr[it][1]));
+                st4(gst + pr * kC + 4 * l32, ij[pr][0] >= 0 ? v : f4(0.f));
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int pr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const int i = ij[pr][0], j = ij[pr][1];
             float p0 = 0.f, p1 = 0.f;
             if (i >= 0) {
-                const int64_t base = static_cast<int64_t>(t.b) * N;
-                float gs = 0.5f * (ld1(g + ((base + i) * N + j) * kC + n) + ld1(g + ((base + j) * N + i) * kC + n));
-                if (i == j) gs *= 0.5f;      // the diagonal row appears in both 32-row blocks: count it once
+                const float gs = gst[pr * kC + n];   // this (pair, channel) slot belongs to this lane alone: read, then reuse for x
                 const float d0 = act_grad_from_output<ACT>(act_fwd<ACT>(acc0[reg] + bias2));
                 const float d1v = act_grad_from_output<ACT>(act_fwd<ACT>(acc1[reg] + bias2));
                 p0 = gs * d0;
                 p1 = gs * d1v;
-                const float x = 0.5f * (q0[reg] * d0 + q1[reg] * d1v);
-                st1(gg + ((base + i) * N + j) * kC + n, x);
-                st1(gg + ((base + j) * N + i) * kC + n, x);
+                gst[pr * kC + n] = 0.5f * (q0[reg] * d0 + q1[reg] * d1v);
             }
+            (void)j;
             const int c = n >> 2;
             d2[pr * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p0;
             d2[(32 + pr) * kC + (((c & ~15) | ((c & 15) ^ (pr & 15))) << 2) + (n & 3)] = p1;
-            if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        store_pair_rows(gst, ij, t.b, N, gg, tid);
         // gW2 += p2^T q : contraction over the 64 tile rows
         aw2_stage(d2, hb, n, col, half, aw2);
         // dh1 = p2 W2 for (row block mt, unit tile ut); p1 = dh1 * act'(h1); gW1 += p1^T t
@@ -855,7 +894,7 @@ extern "C" int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b
     const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
-    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kHid + 2 * 64 * kMaxE) * 4 + kPairs * 2 * 4;
+    constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kHid + 2 * 64 * kMaxE + kPairs * kC) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
 #define BWD2_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                              \
