@@ -26,6 +26,10 @@
 #include <cstring>
 #include <type_traits>
 
+// Developer builds only (-DDG_DBG=<bits>, loaded through DG_LIB; scripts/gemm_phases.py, scripts/gemm_variants.py;
+// results in profiles/r02_gemm_*_phases.txt).  16: s_memtime phase stamps of workgroup 17 written to ep.rstd;
+// K = 384 kernel ablations: 1 = no MFMAs, 2 = raw LDS writes instead of the fp16 split, 8 = no global fetch.
+// The shipped library is built with DG_DBG = 0: every such block folds away.
 #ifndef DG_DBG
 #define DG_DBG 0
 #endif
@@ -809,7 +813,6 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                         acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[s][TB[t]][ks & 3], acc[s][m], 0, 0, 0);
         }
         GSTAMP(tM)
-        if (DG_DBG & 128) __builtin_amdgcn_s_setprio(2);
         if (!EXCH && kc == KC - 1) {
             // direct epilogue from the accumulator layout, one (slab, 32-row block) at a time
             constexpr bool BITS = NG == 3 || NC == 6;   // ReLU bit masks in / out: only the fc1-shaped launches use them
@@ -940,7 +943,6 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             else finish_rows(std::true_type{});
         }
         GSTAMP(tE)
-        if (DG_DBG & 128) __builtin_amdgcn_s_setprio(0);
         if (pos_g == NG - 1) __syncthreads();   // end of this chunk's iteration
         GSTAMP(tB)
     };
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int it = 4 * hg + j;
-                        if (!(DG_DBG & 4) || yv[j].x == 1.2345e-30f) st4(yrow + it * 256, yv[j]);
+                        st4(yrow + it * 256, yv[j]);
                         if (EXCH && ep.pre && ep.gamma) st4(ep.pre + (r0 + pw * 16 + it * 2 + half) * 128 + col * 4, pv[j]);
                     }
                 } else {
