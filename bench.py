@@ -259,9 +259,11 @@ def main():
                      "into fp16, fp32 accumulate: fp32-class accuracy, tests/test_hip_kernels.py)" if split
                      else "v_mfma_f32_32x32x2_f32"))
         kernels = {}
+        step_bytes = 0.0
         for name in _lib.KERNEL_IDS:
             n, ms = _lib.prof_read(name)
             nbytes = dgf.traffic_bytes(name)
+            step_bytes += float(nbytes)
             if n:
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 kernels[name] = {"launches_per_step": n / detail_steps, "avg_us": 1e3 * ms / n,
@@ -337,6 +339,13 @@ def main():
                          "launches_timed": dom.get("launches"), "avg_us": dom.get("avg_us"),
                          "algorithmic_bytes_per_launch": None if not dom else dom.get("algorithmic_MB_per_launch", 0) * 1e6},
             "roofline_dominant": dominant,
+            # the whole step against the HBM roof: algorithmic bytes of every HIP kernel launch of a step (the per-kernel
+            # formulas of DESIGN.md section 3, accumulated by functional._account) / wall time of the instrumented steps
+            "step_hbm": {"algorithmic_GB_per_step": step_bytes / detail_steps / 1e9,
+                         "achieved_GBps": step_bytes / detail_elapsed / 1e9,
+                         "frac_of_hbm_peak": step_bytes / detail_elapsed / 1e9 / HBM_PEAK_GBS,
+                         "note": "two fully instrumented steps after the timed region (HIP events around every launch: "
+                                 "slightly slower than the timed steps)"},
             "kernels": kernels,
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
