@@ -1254,9 +1254,13 @@ def as_one_hot(a, labels=None):
     discriminator's real batch), false for generated / interpolated tensors.  The int32 labels are attached to the
     tensor object; Generator / Discriminator then evaluate the edge-embedding MLP on the E distinct rows only
     (``dg_onehot_embed_fwd/bwd``).  The check costs one device->host read per NEW tensor object (the result is
-    cached on it), so a resident batch is checked once.  Returns ``a``."""
-    if getattr(a, "_dg_labels", None) is not None or not (torch.is_tensor(a) and a.is_cuda and a.dim() == 4):
+    cached on it together with the tensor's version counter: an in-place write invalidates it), so a resident batch
+    is checked once.  Returns ``a``."""
+    if not (torch.is_tensor(a) and a.is_cuda and a.dim() == 4):
         return a
+    if getattr(a, "_dg_labels", None) is not None and getattr(a, "_dg_labels_version", None) == a._version:
+        return a                      # same object, not written since the check (in-place updates bump _version)
+    a._dg_labels_version = a._version
     if a.requires_grad or a.dtype != torch.float32:
         a._dg_labels = False
         return a
@@ -1271,7 +1275,9 @@ def as_one_hot(a, labels=None):
 def one_hot_labels(a):
     """The int32 labels attached by ``as_one_hot`` (None for tensors that are not declared one-hot)."""
     lab = getattr(a, "_dg_labels", None)
-    return lab if torch.is_tensor(lab) else None
+    if not torch.is_tensor(lab) or getattr(a, "_dg_labels_version", None) != a._version:
+        return None                   # never declared, not one-hot, or written in place since the check
+    return lab
 
 
 class _OneHotEmbed(Function):

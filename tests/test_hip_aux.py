@@ -242,3 +242,10 @@ def test_onehot_embedding_matches_the_dense_kernel(B, N, E, act, dtype):
         assert float((x.double() - y.double()).norm() / y.double().norm()) < (2e-5 if dtype == torch.float32 else 1e-3)
     soft = torch.softmax(torch.randn(B, N, N, E, generator=g), -1).cuda()
     assert dgf.one_hot_labels(dgf.as_one_hot(soft)) is None
+    # a batch buffer that is refilled in place must not keep its old labels: the cache is tied to the version counter
+    a2, _, bonds2, _ = synth.molecule_batch(B, N, E, 7, seed=B * 100 + N + 1)
+    a.copy_(torch.from_numpy(a2))
+    assert dgf.one_hot_labels(a) is None
+    assert torch.equal(dgf.one_hot_labels(dgf.as_one_hot(a)).cpu(), torch.from_numpy(bonds2).to(torch.int32))
+    a.copy_(soft)
+    assert dgf.one_hot_labels(dgf.as_one_hot(a)) is None
