@@ -515,3 +515,14 @@ def test_embed_sym_all_orders(act, B, N, E):
     h2 = torch.autograd.grad((gr * ta).sum(), [ins[1], ins[3], g64])
     for name, x, y in zip("gw1 gw2 gg".split(), h1, h2):
         assert _rel(x, y) < 2e-4, name
+
+
+def test_embed_second_order_entry_rejects_smooth_activations():
+    """dg_embed_sym_bwd2 is the closed form for act'' = 0 only: sigmoid / tanh must be refused (the Python layer then
+    uses the composite graph), never silently mis-differentiated."""
+    lib = _lib().load()
+    x = torch.zeros(64, device="cuda")
+    args = [x.data_ptr()] * 11 + [x.data_ptr(), 1 << 30, 1, 9, 5, 64, 128]
+    for act, want in ((2, -2), (3, -2)):
+        st = lib.dg_embed_sym_bwd2(*args, act, 0, None)
+        assert st == want and b"piecewise-linear" in lib.dg_last_error_string()
