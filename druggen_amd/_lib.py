@@ -26,6 +26,9 @@ SIGNATURES = {
     "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd2": (c_int, [_P] * 16 + [c_int, c_int, c_int, c_float, c_int, _P]),
+    "dg_attn_half_packed_bytes": (c_size_t, [c_int]),
+    "dg_attn_half_pack": (c_int, [_P, _P, _P, c_int, _P]),
+    "dg_attn_half_fwd": (c_int, [_P] * 14 + [c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_int, _P]),
     "dg_ln_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "dg_ln_residual_bwd": (c_int, [_P] * 9 + [_P, c_size_t, c_int64, c_int, c_int, _P]),
@@ -67,7 +70,8 @@ SIGNATURES = {
     "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10}
+KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10,
+              "attn_half_fwd": 11, "attn_half_bwd": 12}
 
 _lock = threading.Lock()
 _lib = None

@@ -78,6 +78,23 @@ int dg_attn_core_bwd2(const void* q, const void* k, const void* v, const void* e
                       void* gq, void* gk, void* gv, void* ge, void* gws, void* gwo,
                       int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
 
+/* ---- fused attention half of the edge branch: src/model/layers.py:116-135 + 186-190 ----
+ *   e  = y We^T + be                       (layers.py:116; never written to HBM)
+ *   s  = alpha q_i k_j (e^2 + e), p = softmax_j s, o_i = sum_j p v_j        (:119-134)
+ *   y2 = LayerNorm(y + s Woe^T + boe) * gamma4 + beta4                       (:127, :188-190)
+ * y, y2, pre4: [B,N,N,C]; q, k, v, o: [B,N,C] (node-level projections :111-113 stay row GEMMs);
+ * mean4, rstd4: [B N N].  One kernel: the tile of one (b, i) -- N rows -- is read once, `e` and `s`
+ * stay on chip; HBM traffic = read y, write y2 + pre4 (3 edge passes instead of 8).
+ * `packed` = dg_attn_half_pack(e.weight, out_e.weight) for the same dtype.  Pass y2 = NULL for the
+ * Discriminator's last block (models.py:202-207: only o is needed; boe / gamma4 / beta4 / pre4 /
+ * mean4 / rstd4 are then ignored).  C == 128, N <= 96; dtype DG_DTYPE_BF16 or DG_DTYPE_F32.   */
+size_t dg_attn_half_packed_bytes(int dtype);
+int dg_attn_half_pack(const float* we, const float* woe, void* packed, int dtype, dg_stream_t stream);
+int dg_attn_half_fwd(const void* y, const void* q, const void* k, const void* v, const void* packed,
+                     const float* be, const float* boe, const float* gamma4, const float* beta4,
+                     void* o, void* y2, void* pre4, float* mean4, float* rstd4,
+                     int B, int N, int C, float alpha, float eps, int dtype, dg_stream_t stream);
+
 /* ---- residual + LayerNorm: src/model/layers.py:185-192 ----------------------
  *   y = LayerNorm(a + r) * gamma + beta, eps = 1e-5, over the last dim C.
  * r may be NULL (ln1, layers.py:185).  a, r, y: [R,C]; mean, rstd: [R] (saved
@@ -299,6 +316,8 @@ enum {
     DG_K_EMBED_SYM = 8,
     DG_K_FFN = 9,          /* fused bf16 feed-forward kernels: forward, dx */
     DG_K_FFN_WGRAD = 10,   /* fused bf16 feed-forward weight-gradient kernels */
+    DG_K_ATTN_HALF_FWD = 11,   /* fused attention half of the edge branch: forward */
+    DG_K_ATTN_HALF_BWD = 12,   /* ... backward */
     DG_K_COUNT = 16
 };
 int dg_prof_enable(int mask);
