@@ -1082,6 +1082,154 @@ class _AttnBlockBwd(Function):
                 None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 11))
 
 
+_half_pack_cache = {}
+
+
+def _attn_half_packed(we, woe, dtype):
+    """Fragment-order copies of (e.weight, out_e.weight) and their transposes for the fused attention-half kernels
+    (dg_attn_half_pack), cached like ``packed_weight``."""
+    key = (id(we), id(woe), dtype)
+    hit = _half_pack_cache.get(key)
+    if (hit is not None and hit[0]() is we and hit[1]() is woe and hit[2] == (we._version, woe._version)
+            and hit[4] == (we.data_ptr(), woe.data_ptr()) and hit[5] == _weights_epoch):
+        return hit[3]
+    if len(_half_pack_cache) > 1024:
+        for k in [k for k, v in _half_pack_cache.items() if v[0]() is None or v[1]() is None]:
+            del _half_pack_cache[k]
+    lib = _lib.load()
+    code = _lib.DTYPES[dtype]
+    packed = torch.empty(int(lib.dg_attn_half_packed_bytes(code)), dtype=torch.uint8, device=we.device)
+    with _dev(we):
+        _lib.check(lib.dg_attn_half_pack(_lib.fptr(_c(we.detach())), _lib.fptr(_c(woe.detach())), packed.data_ptr(), code,
+                                         _lib.stream_of(we)), "dg_attn_half_pack")
+    _half_pack_cache[key] = (weakref.ref(we), weakref.ref(woe), (we._version, woe._version), packed,
+                             (we.data_ptr(), woe.data_ptr()), _weights_epoch)
+    return packed
+
+
+def _fused_attn_half_enabled() -> bool:
+    """DG_ATTN_HALF=unfused keeps the attention half on the separate launches (A/B measurements)."""
+    return os.environ.get("DG_ATTN_HALF", "fused") != "unfused"
+
+
+def attn_half_supported(dtype, N: int, C: int) -> bool:
+    return dtype == torch.bfloat16 and C == 128 and 1 <= N <= 96
+
+
+class _AttnBlockFused(Function):
+    """The same block as ``_AttnBlock`` with the whole EDGE side -- e-projection, Hadamard score, softmax over j, AV,
+    out_e, residual, ln4 (reference layers.py:116-135,186-190) -- in ONE kernel per direction (csrc/attn_half.hip):
+    ``e`` and ``s`` never exist in HBM, the backward recomputes them from the saved layer input ``y`` and accumulates
+    the weight gradients of e / out_e inside the kernel.  The node side (q, k, v, out_n + ln3; R = B N rows) stays on
+    the row GEMMs.  First order only: graphs that will be differentiated twice are built from ``_AttnBlock``."""
+
+    @staticmethod
+    def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4, alpha, eps3, eps4,
+                need_edge):
+        B, N, C = x1.shape
+        x1f = _c(x1).reshape(-1, C)
+        yc = _c(y)
+        adt = x1f.dtype
+        code = _lib.dt(x1f)
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
+        q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
+        k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
+        v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
+        lib = _lib.load()
+        dev = x1f.device
+        o = torch.empty_like(q)
+        y2 = pre4 = mean4 = rstd4 = None
+        if need_edge:
+            y2 = torch.empty_like(yc)
+            pre4 = torch.empty_like(yc)
+            mean4 = torch.empty(B * N * N, dtype=torch.float32, device=dev)
+            rstd4 = torch.empty(B * N * N, dtype=torch.float32, device=dev)
+        packed = _attn_half_packed(we, woe, adt)
+        with _dev(q):
+            _lib.check(lib.dg_attn_half_fwd(_lib.ptr(yc), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), packed.data_ptr(),
+                                            _lib.fptr(_c(be)), _lib.fptr(_c(boe)), _lib.fptr(_c(g4)), _lib.fptr(_c(b4)),
+                                            _lib.ptr(o), _lib.ptr(y2), _lib.ptr(pre4), _lib.ptr(mean4), _lib.ptr(rstd4),
+                                            B, N, C, alpha, eps4, code, _lib.stream_of(q)), "dg_attn_half_fwd")
+        es = q.element_size()
+        _account("attn_half_fwd", es * B * ((3 if need_edge else 1) * N * N * C + 4 * N * C),
+                 2 * B * N * N * C * C * (2 if need_edge else 1))
+        x2, mean3, rstd3, pre3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3),
+                                          want_pre=True)
+        ctx.save_for_backward(x1, yc, wq, wk, wv, we, woe, won, g3, g4, be, q, k, v, o, mean3, rstd3, pre3, mean4, rstd4,
+                              pre4)
+        ctx.cfg = (alpha, need_edge, (B, N, C))
+        ctx.extra = (bq, bk, bv, boe, bon, b3, b4, eps3, eps4)
+        ctx.set_materialize_grads(False)
+        if need_edge:
+            return x2.view(B, N, C), y2
+        return x2.view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, dx2, dy2=None):
+        alpha, need_edge, (B, N, C) = ctx.cfg
+        (x1, y, wq, wk, wv, we, woe, won, g3, g4, be, q, k, v, o, mean3, rstd3, pre3, mean4, rstd4,
+         pre4) = ctx.saved_tensors
+        if torch.is_grad_enabled():      # create_graph=True outside second_order_forward(): composite graph
+            bq, bk, bv, boe, bon, b3, b4, eps3, eps4 = ctx.extra
+            ins = (x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4)
+            gouts = (dx2, dy2) if need_edge else dx2
+            return _double_backward_fallback(
+                lambda *t: _composite_attn_block(*t, alpha, eps3, eps4, need_edge), ins, gouts) + (None,) * 4
+        adt = q.dtype
+        code = _lib.dt(q)
+        dev = q.device
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
+        cast = lambda t: t if t.dtype == adt else t.to(adt)
+        wants_w = ctx.needs_input_grad[2] and not _inputs_only()
+        x1f = _c(x1).reshape(-1, C)
+        if dx2 is None:
+            dx2 = torch.zeros_like(pre3)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C))
+        do = row_gemm(dz3, pw(won, 1), C, C)
+        dz4 = dg4 = db4 = None
+        if need_edge:
+            if dy2 is None:
+                dy2 = torch.zeros_like(pre4)
+            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C))
+        lib = _lib.load()
+        dy = torch.empty_like(y)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dwe = dbe = dwoe = dboe = None
+        if wants_w:
+            dwe = torch.empty_like(we)
+            dbe = torch.empty(C, dtype=torch.float32, device=dev)
+            if need_edge:
+                dwoe = torch.empty_like(woe)
+                dboe = torch.empty(C, dtype=torch.float32, device=dev)
+        need = int(lib.dg_attn_half_bwd_workspace_bytes(B, N))
+        with _dev(q):
+            ws = _scratch(q, need, "half")
+            _lib.check(lib.dg_attn_half_bwd(_lib.ptr(y), _lib.ptr(dz4), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(do),
+                                            _attn_half_packed(we, woe, adt).data_ptr(), _lib.fptr(_c(be)), _lib.ptr(dy),
+                                            _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dwe), _lib.ptr(dbe),
+                                            _lib.ptr(dwoe), _lib.ptr(dboe), ws.data_ptr(), ws.numel(), B, N, C, alpha,
+                                            code, _lib.stream_of(q)), "dg_attn_half_bwd")
+        es = q.element_size()
+        _account("attn_half_bwd", es * B * ((3 if need_edge else 2) * N * N * C + 8 * N * C),
+                 2 * B * N * N * C * C * ((3 if need_edge else 2) + (2 if wants_w and need_edge else (1 if wants_w else 0))))
+        dx1 = None
+        if ctx.needs_input_grad[0]:
+            t = row_gemm(dq, pw(wq, 1), C, C, residual=dz3)                        # + ln3 residual path
+            t = row_gemm(dk, pw(wk, 1), C, C, residual=t)
+            dx1 = row_gemm(dv, pw(wv, 1), C, C, residual=t).view(x1.shape)
+        gw = [None] * 12
+        if wants_w:
+            gw[0], gw[1] = _wgrad(dq, x1f, True)
+            gw[2], gw[3] = _wgrad(dk, x1f, True)
+            gw[4], gw[5] = _wgrad(dv, x1f, True)
+            gw[6], gw[7] = dwe, dbe
+            gw[8], gw[9] = dwoe, dboe
+            gw[10], gw[11] = _wgrad(dz3, o, True)
+        else:
+            dg3 = db3 = dg4 = db4 = None
+        return (dx1, (dy if ctx.needs_input_grad[1] else None), *gw, dg3, db3, dg4, db4, None, None, None, None)
+
+
 def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
     """Attention half of an encoder block for ``attn`` (an MHA module): returns
     (LN3(x1 + out_n(o)), LN4(y + out_e(s)) or None)."""
@@ -1094,6 +1242,10 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
              and all(t is not None for t in args))
     if not fused:
         out = _composite_attn_block(*args, alpha, ln3.eps, ln4.eps, need_edge)
+    elif (not in_second_order_forward() and attn_half_supported(x1.dtype, x1.shape[1], C) and _fused_attn_half_enabled()
+          and tuple(y.shape) == (x1.shape[0], x1.shape[1], x1.shape[1], C)):
+        out = _AttnBlockFused.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
+        return (out[0], out[1]) if need_edge else (out, None)
     else:
         out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
         return (out[0], out[1]) if need_edge else (out[0], None)

@@ -95,6 +95,18 @@ int dg_attn_half_fwd(const void* y, const void* q, const void* k, const void* v,
                      void* o, void* y2, void* pre4, float* mean4, float* rstd4,
                      int B, int N, int C, float alpha, float eps, int dtype, dg_stream_t stream);
 
+/* Backward of dg_attn_half_fwd given dz4 = d loss / d (y + s Woe^T + boe) -- the ln4 backward (dg_ln_residual_bwd on
+ * pre4, mean4, rstd4) runs first and also yields dgamma4 / dbeta4 -- and d_o = d loss / d o.  e, s, p are recomputed
+ * from y;  dy = dz4 + de We;  dq, dk, dv [B,N,C];  dwe/dwoe [C,C], dbe/dboe [C] (float32) are accumulated inside the
+ * kernel (pass dwe = NULL to skip all four: input-gradient-only passes, loss.py:32-39 / the D pass of the G step).
+ * dz4 = NULL: Discriminator's last block (no out_e / ln4: dwoe, dboe untouched).  HBM traffic: read y, dz4, write dy.
+ * workspace >= dg_attn_half_bwd_workspace_bytes(B, N).  Results are bit-reproducible (fixed-order partial sums).       */
+size_t dg_attn_half_bwd_workspace_bytes(int B, int N);
+int dg_attn_half_bwd(const void* y, const void* dz4, const void* q, const void* k, const void* v, const void* d_o,
+                     const void* packed, const float* be, void* dy, void* dq, void* dk, void* dv,
+                     float* dwe, float* dbe, float* dwoe, float* dboe, void* workspace, size_t workspace_bytes,
+                     int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
+
 /* ---- residual + LayerNorm: src/model/layers.py:185-192 ----------------------
  *   y = LayerNorm(a + r) * gamma + beta, eps = 1e-5, over the last dim C.
  * r may be NULL (ln1, layers.py:185).  a, r, y: [R,C]; mean, rstd: [R] (saved
