@@ -10,7 +10,9 @@ namespace {
 
 // ---- densify --------------------------------------------------------------------------------
 // labels[b,i,j] += attr for every COO edge (u -> v), b = u / N, i = u % N, j = v % N: the reference
-// pads every graph to N = max_num_nodes nodes (utils.py:133), to_dense_adj scatter-ADDs duplicates.
+// pads every graph to N = max_num_nodes nodes (utils.py:133), to_dense_adj scatter-ADDs duplicates and
+// indexes (batch[u], u - ptr[batch[u]], v - ptr[batch[v]]): an edge that leaves its graph is written into the
+// SOURCE graph's matrix at column v mod N (oracle/aux_oracle.py::to_dense_adj, tests/test_hip_aux.py).
 __global__ void densify_scatter_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                                        const int64_t* __restrict__ attr, int64_t n_edges, int B, int N,
                                        int* __restrict__ labels) {
@@ -18,7 +20,7 @@ __global__ void densify_scatter_kernel(const int64_t* __restrict__ src, const in
     if (e >= n_edges) return;
     const int64_t u = src[e], v = dst[e];
     const int64_t b = u / N;
-    if (b < 0 || b >= B || v / N != b) return;   // an edge never leaves its graph
+    if (u < 0 || b >= B || v < 0 || v >= static_cast<int64_t>(B) * N) return;   // node ids outside the batch
     atomicAdd(labels + (b * N + u % N) * N + v % N, static_cast<int>(attr[e]));
 }
 

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .functional import _dev
+from .functional import _dev, attach_one_hot_labels
 
 __all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot"]
 
@@ -23,7 +23,11 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
 
     ``check=True`` (default) raises on bond labels outside ``[0, b_dim)`` like the reference's
     ``scatter_`` does (one 4-byte device->host read per batch; the reference's loader syncs per
-    batch anyway).  Pass ``check=False`` on a path that must not synchronise."""
+    batch anyway) and attaches the int32 labels to the result, so that Generator / Discriminator take the
+    table-gather edge embedding without re-validating the tensor.  Pass ``check=False`` on a path that must
+    not synchronise (the result then carries no labels: it is not known to be one-hot).
+    An edge whose endpoints lie in different graphs lands in the SOURCE graph's matrix at column
+    ``dst mod N`` -- what ``to_dense_adj`` does with ``dst - ptr[batch[dst]]``."""
     if not edge_index.is_cuda:
         raise RuntimeError("druggen_amd.data runs on the GPU (no CPU fallback)")
     lib = _lib.load()
@@ -38,8 +42,13 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
         _lib.check(lib.dg_densify(src.data_ptr(), dst.data_ptr(), attr.data_ptr(), src.numel(), batch_size, vertexes,
                                   b_dim, labels.data_ptr(), a.data_ptr(), bad.data_ptr(), _lib.stream_of(a)),
                    "dg_densify")
-    if check and int(bad.item()):
-        raise RuntimeError(f"{int(bad.item())} adjacency entries have a bond label outside [0, {b_dim})")
+    if check:
+        n_bad = int(bad.item())
+        if n_bad:
+            raise RuntimeError(f"{n_bad} adjacency entries have a bond label outside [0, {b_dim})")
+        # one-hot by construction: hand the labels to the model (table-gather edge embedding) without the
+        # per-tensor validation sync of ``functional.as_one_hot``
+        attach_one_hot_labels(a, labels)
     return a
 
 

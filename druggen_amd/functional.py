@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-__all__ = ["attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
+__all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops",
            "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot"]
 
@@ -1421,6 +1421,17 @@ def as_one_hot(a, labels=None):
             labels = a.argmax(-1).to(torch.int32)
         ok = ((a.amax(-1) == 1) & (a.sum(-1) == 1) & (a.amin(-1) == 0)).all() if a.shape[-1] > 1 else (a == 1).all()
     a._dg_labels = labels.contiguous() if bool(ok) else False     # the only host sync: once per tensor object
+    return a
+
+
+def attach_one_hot_labels(a, labels):
+    """Declare WITHOUT checking that ``a`` [B,N,N,E] is one-hot with the given int32 ``labels`` [B,N,N] -- for producers
+    that build ``a`` from the labels (``data.dense_one_hot_adjacency``: reference utils.py:15-23,130-137) or refresh both
+    together (``GraphedGANStep``).  No device->host sync.  Returns ``a``."""
+    if labels.dtype != torch.int32 or tuple(labels.shape) != tuple(a.shape[:-1]) or labels.device != a.device:
+        raise ValueError("labels must be an int32 tensor on a's device with a's shape minus the last dim")
+    a._dg_labels = labels if labels.is_contiguous() else labels.contiguous()
+    a._dg_labels_version = a._version
     return a
 
 

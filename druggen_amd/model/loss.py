@@ -30,6 +30,16 @@ def _has_active_dropout(module) -> bool:
     return any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in module.modules())
 
 
+def _accepts_edge_parts(discriminator) -> bool:
+    """True for this package's Discriminator (possibly behind DistributedDataParallel's ``.module``): its trunk takes
+    the edge batch as a tuple of parts.  nn.DataParallel is excluded on purpose."""
+    from .models import _Trunk
+    inner = discriminator
+    if isinstance(inner, torch.nn.parallel.DistributedDataParallel):
+        inner = inner.module
+    return isinstance(inner, _Trunk)
+
+
 def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, mol_annot, batch_size, device,
                        lambda_gp, *, eps=None, generator_outputs=None):
     """Reference loss.py:52-72 -> (node, edge, d_loss).
@@ -47,10 +57,11 @@ def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, 
         # D(real) and D(fake) as one pass over the concatenated batch: every molecule is processed
         # independently (no cross-sample op in D), so the logits are the reference's; half the launches,
         # and each weight gradient is accumulated once instead of twice.
-        if isinstance(discriminator, torch.nn.DataParallel):      # scatter() would split the two halves differently
-            edges = torch.cat([drug_adj, edge_sample])
-        else:       # the halves stay separate tensors up to the edge embedding: a one-hot real batch takes the table path
+        if _accepts_edge_parts(discriminator):
+            # the halves stay separate tensors up to the edge embedding: a one-hot real batch takes the table path
             edges = (drug_adj, edge_sample)
+        else:       # any other critic (user module, nn.DataParallel: scatter() would split the halves differently)
+            edges = torch.cat([drug_adj, edge_sample])
         logits = discriminator(edges, torch.cat([drug_annot, node_sample]))
         n_real = drug_adj.shape[0]
         prediction_real = -torch.mean(logits[:n_real])

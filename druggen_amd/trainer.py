@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .model.loss import discriminator_loss, generator_loss
-from .functional import as_one_hot, bump_weights_epoch
+from .functional import as_one_hot, attach_one_hot_labels, bump_weights_epoch, one_hot_labels
 from .optim import FlatAdamW
 
 __all__ = ["GANStep", "GraphedGANStep", "GradBucket", "broadcast_parameters"]
@@ -128,6 +128,9 @@ class GANStep:
         # per GPU in fp32 needs > 288 GB on the fast path).
         if memory not in ("auto", "fast", "low"):
             raise ValueError("memory must be 'auto', 'fast' or 'low'")
+        if memory == "low" and (d_loss_fn is not discriminator_loss or g_loss_fn is not generator_loss):
+            raise ValueError("memory='low' differentiates the terms of the default discriminator_loss one by one: it "
+                             "cannot run a custom d_loss_fn / g_loss_fn (use memory='fast' or 'auto')")
         self.memory = memory
 
     def _low_memory(self, gen_edge) -> bool:
@@ -227,13 +230,26 @@ class GraphedGANStep:
     shape: 13.7 ms eager -> 3.3 ms replayed on MI355X); at configs[1] the GPU is already saturated.
 
     Single-GPU only (the all-reduce is not captured).  New batches are copied into the static input
-    buffers; ``eps`` is drawn on the device inside the graph like the reference does."""
+    buffers; ``eps`` is drawn on the device inside the graph like the reference does.
+
+    One-hot edge batches (dataset graphs) are embedded through their int32 LABELS (table gather): the
+    captured kernels read static label buffers owned by this object, and ``step`` refreshes them together
+    with the dense buffers -- a replay never sees the labels of an older batch."""
 
     def __init__(self, stepper: GANStep, disc_edge, disc_node, gen_edge, gen_node, warmup: int = 3):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(stepper.group) > 1:
             raise RuntimeError("GraphedGANStep is single-GPU: use GANStep under torchrun for data parallelism")
         self.stepper = stepper
         self.static = [t.clone() for t in (disc_edge, disc_node, gen_edge, gen_node)]
+        # static label buffers of the two edge batches (index 0: D's real batch, 2: the generator input): validated
+        # HERE, outside the graph (as_one_hot syncs once); None when the capture batch is not one-hot -- the graph then
+        # records the dense embedding kernels and needs no labels
+        self._labels = {}
+        for idx, src in ((0, disc_edge), (2, gen_edge)):
+            lab = one_hot_labels(as_one_hot(src))
+            if lab is not None:
+                self._labels[idx] = lab.clone()
+                attach_one_hot_labels(self.static[idx], self._labels[idx])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up off the default stream: allocator pools, packed
@@ -251,10 +267,23 @@ class GraphedGANStep:
             self.losses = stepper.step(*self.static)
         bump_weights_epoch()    # cache entries made during capture point into the graph's private pool
 
-    def step(self, disc_edge=None, disc_node=None, gen_edge=None, gen_node=None):
-        for dst, src in zip(self.static, (disc_edge, disc_node, gen_edge, gen_node)):
-            if src is not None and src.data_ptr() != dst.data_ptr():
-                dst.copy_(src)
+    def step(self, disc_edge=None, disc_node=None, gen_edge=None, gen_node=None, check_one_hot: bool = True):
+        """Replay on a new batch (``None`` keeps the previous tensor).  Edge batches captured as one-hot must be one-hot
+        again: labels attached by ``data.load_molecules`` are trusted, other tensors are validated by ``as_one_hot``
+        (one device->host read per new tensor object; ``check_one_hot=False`` skips it and trusts ``argmax``)."""
+        for idx, (dst, src) in enumerate(zip(self.static, (disc_edge, disc_node, gen_edge, gen_node))):
+            if src is None or src.data_ptr() == dst.data_ptr():
+                continue
+            dst.copy_(src)
+            if idx in self._labels:
+                lab = one_hot_labels(as_one_hot(src)) if check_one_hot else one_hot_labels(src)
+                if lab is None:
+                    if check_one_hot:
+                        raise RuntimeError("GraphedGANStep was captured with a one-hot edge batch (table-gather embedding); "
+                                           "the new batch is not one-hot: capture a new graph for dense inputs")
+                    lab = src.argmax(-1)
+                self._labels[idx].copy_(lab)      # in place: the captured kernels read this buffer
+                attach_one_hot_labels(dst, self._labels[idx])
         self.graph.replay()
         # the replay updated G and D in place without bumping tensor versions: an eager forward after
         # it must not reuse packs keyed on the old versions

@@ -53,6 +53,37 @@ def test_densify_edge_cases():
     assert np.array_equal(a.cpu().numpy(), ref)
     with pytest.raises(RuntimeError, match="outside"):
         data.dense_one_hot_adjacency(ei, torch.tensor([2, 2, 2], device="cuda"), 2, 4, 3, check=True)
+    # an edge that leaves its graph (node 1 of graph 0 -> node 2 of graph 1): to_dense_adj indexes
+    # (batch[src], src - ptr, dst - ptr[batch[dst]]) -> graph 0, row 1, column 2; node ids outside the batch are ignored
+    ei = torch.tensor([[1, 2, 7, 99], [6, 3, 0, 1]], device="cuda")
+    ea = torch.tensor([2, 1, 1, 1], device="cuda")
+    a = data.dense_one_hot_adjacency(ei, ea, 2, 4, 3)
+    ref = aux.label2onehot(aux.to_dense_adj(ei.cpu().numpy()[:, :3], np.repeat(np.arange(2), 4), ea.cpu().numpy()[:3], 4), 3)
+    assert np.array_equal(a.cpu().numpy(), ref) and a[0, 1, 2, 2] == 1 and a[1, 3, 0, 1] == 1
+
+
+def test_loader_attaches_labels_and_the_model_takes_the_table_path_without_a_sync():
+    """data.dense_one_hot_adjacency hands its int32 labels to the model: Generator / Discriminator then embed the batch
+    by table gather with NO validation pass (as_one_hot synced once per new tensor, i.e. every step with a
+    real DataLoader)."""
+    from druggen_amd import data, functional as dgf
+    ei, ea, x, batch, a_want, x_want = _coo_batch(4, 9, 5, seed=3)
+    a = data.dense_one_hot_adjacency(torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda(), 4, 9, 5)
+    lab = dgf.one_hot_labels(a)
+    assert lab is not None and lab.dtype == torch.int32 and torch.equal(lab.long(), a.argmax(-1))
+    calls = []
+    real_argmax = torch.Tensor.argmax
+    try:
+        torch.Tensor.argmax = lambda self, *a_, **k_: (calls.append(1), real_argmax(self, *a_, **k_))[1]
+        assert dgf.as_one_hot(a) is a and not calls                 # trusted labels: no re-validation
+        dgf.as_one_hot(a.clone())
+        assert calls                                                # unknown origin: validated (one sync)
+    finally:
+        torch.Tensor.argmax = real_argmax
+    a.mul_(1.0)                                                     # an in-place write invalidates the declaration
+    assert dgf.one_hot_labels(a) is None
+    with pytest.raises(ValueError):
+        dgf.attach_one_hot_labels(a, lab.long())
 
 
 def test_flat_adamw_matches_torch_and_oracle_and_skips_dead_parameters():
