@@ -1265,7 +1265,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 r4 = ld4(rsp + 32 * m + 8 * q + 4 * half);
+                    // inverse row scale of the chunk TIMES this lane's inverse column scale: folding with the row scale alone
+                    // overflows for rows above ~2^90 although the result is representable (tests: max 2^120 row)
+                    const float4 r4 = cs * ld4(rsp + 32 * m + 8 * q + 4 * half);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[m][4 * q + i] = fmaf(part[m][4 * q + i], comp(r4, i), acc[m][4 * q + i]);
                 }
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rr = 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    float v = fmaf(acc[m][reg], cs, bias);
+                    float v = acc[m][reg] + bias;
                     if (ep.relu) v = fmaxf(v, 0.f);
                     ex[rr * 128 + 32 * w + col] = v;
                 }

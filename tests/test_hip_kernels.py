@@ -273,8 +273,9 @@ def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (384, 128)])
 def test_row_gemm_split_bf16_is_fp32_class_accurate(K, N, data):
     """The row GEMM splits its fp32 operands into 16-bit planes and runs MFMA cross products with fp32
-    accumulation: K = 128 -- rows and weight columns scaled by a power of two, two fp16 planes, three products;
-    K = 384 -- three bf16 planes, six products.  Neither is a reduced-precision GEMM: measured against fp64,
+    accumulation: every 128-wide row chunk and every weight column is scaled by a power of two, split into two fp16
+    planes, three products per k-step (K = 384: one scale per (row, 128-chunk), each chunk accumulated on its own and
+    folded with its inverse scale).  It is not a reduced-precision GEMM: measured against fp64,
     the element-wise error (relative to sum_k |a_k w_k|, the natural scale of a dot product) must be at the level
     of an fp32 GEMM of the same data -- torch's fp32 matmul here -- and orders of magnitude below bf16.  The
     scaled cases multiply rows by 2^-60..2^60 and weight columns by 1e-6..1e6 (the per-row / per-column scales
@@ -306,6 +307,58 @@ def test_row_gemm_split_bf16_is_fp32_class_accurate(K, N, data):
           f" | bf16 matmul rms {bf_rms:.2e}")
     assert mine_rms < 1.5 * ref_rms and mine_max < 2.0 * ref_max
     assert (mine_rms < 1e-7 or data == "heavy_tailed") and bf_rms > 1e3 * mine_rms
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (384, 128)])
+def test_row_gemm_split_edge_rows(K, N):
+    """Corners of the power-of-two scaling: all-zero rows (and one all-zero 128-chunk of a K = 384 row),
+    rows of fp32 denormals, rows whose maximum is 2^120 (scale and inverse scale must stay inside the fp32 range),
+    rows / weight columns containing inf or NaN.  Semantics of ``addmm`` in fp32: a zero row gives exactly the bias;
+    finite rows are fp32-class accurate at any magnitude; a non-finite operand poisons exactly the outputs the
+    reference poisons (its row, or its weight's output column) and nothing else.  One documented difference: a row
+    containing +-inf yields NaN in that row (hi = inf, lo = inf - inf), where addmm yields +-inf or NaN."""
+    from druggen_amd import functional as dgf
+    R = 256
+    a = _gen((R, K), 21).float()
+    w = (_gen((N, K), 22) * 0.1).float()
+    bias = _gen((N,), 23).float()
+    a[3] = 0.0                                            # all-zero row
+    a[4, :128] = 0.0                                      # one all-zero 128-chunk (K = 384: its own scale)
+    a[5] = a[5] * 2.0 ** -140                             # fp32 denormals (|x| < 2^-126)
+    a[6] = a[6] * 2.0 ** -126                             # straddles the normal / denormal boundary
+    a[7] = a[7] / a[7].abs().max() * 2.0 ** 120           # maximum 2^120
+    a[8, 5] = 3.0e38                                      # near FLT_MAX next to O(1) entries
+    a[9] = 0.0
+    a[9, 17] = 1.0                                        # a single non-zero
+    finite_rows = list(range(3, 10)) + [0, 1, 2, 100, 255]
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    y = dgf.row_gemm(ad, dgf.packed_weight(wd, 0), K, N, bias=bd).cpu()
+    want = a.double() @ w.double().t() + bias.double()
+    scale = a.double().abs() @ w.double().abs().t() + bias.double().abs()
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[3], bias)                                                 # zero row -> exactly the bias
+    err = ((y.double() - want).abs() / scale.clamp_min(1e-300))[finite_rows]
+    assert err.max() < 1e-6, err.max()                                             # fp32 class at every magnitude
+    assert ((y[5].double() - want[5]).abs() <= 1e-6 * bias.double().abs() + 1e-37).all()   # denormal inputs: |error| ~ 0
+    # non-finite activations: row 11 holds +inf, row 12 NaN, row 13 -inf and +inf
+    a2 = a.clone()
+    a2[11, 3] = float("inf")
+    a2[12, 77 % K] = float("nan")
+    a2[13, 0], a2[13, K - 1] = float("-inf"), float("inf")
+    y2 = dgf.row_gemm(a2.cuda(), dgf.packed_weight(wd, 0), K, N, bias=bd).cpu()
+    ref2 = (a2 @ w.t() + bias)
+    assert torch.equal(torch.isfinite(y2), torch.isfinite(ref2))                    # the same rows, nothing else
+    assert torch.equal(y2[torch.isfinite(ref2)], y[torch.isfinite(ref2)])           # other rows untouched, bit for bit
+    assert torch.isnan(y2[12]).all() and not torch.isfinite(y2[11]).any() and not torch.isfinite(y2[13]).any()
+    # non-finite weights: output column 2 sees an inf weight, column 5 a NaN weight
+    w3 = w.clone()
+    w3[2, 9] = float("inf")
+    w3[5, 0] = float("nan")
+    y3 = dgf.row_gemm(ad, dgf.packed_weight(w3.cuda(), 0), K, N, bias=bd).cpu()
+    ref3 = (a @ w3.t() + bias)
+    assert torch.equal(torch.isfinite(y3), torch.isfinite(ref3))
+    keep = torch.isfinite(ref3)
+    assert ((y3[keep].double() - y[keep].double()).abs() <= 1e-6 * scale[keep]).all()
 
 
 @pytest.mark.parametrize("R", [5, 64, 1000, 2025 * 7])
