@@ -60,19 +60,23 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="storage of the encoder activations (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="N > 1: after the timed steps compare a per-tensor checksum of G and D across ranks "
+                         "(reports replicas_identical; exits non-zero on a mismatch)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (single GPU)")
     ap.add_argument("--vertexes", type=int, default=0, help="override N (parity-case shapes; not the headline)")
     ap.add_argument("--depth", type=int, default=0, help="override L")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary measurement (BASELINE configs[2]: bf16 activations, batch 2048) that the "
                          "default single-GPU run appends as `bf16_configs2` after the timed region")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's own setting (train.py:16: 5 threads)")
     return ap.parse_args()
 
 
-def _cpu_gan_step_rate(workload, batch, threads, max_steps=3, budget_s=8.0):
-    """molecules/s of the oracle's GAN step (torch CPU restatement of src/model + train.py:351-384)."""
+def _cpu_gan_step_rate(workload, batch, threads, steps=5, budget_s=60.0):
+    """molecules/s of the oracle's GAN step (torch CPU restatement of src/model + train.py:351-384): MEDIAN step time of
+    `steps` steps after one warm-up (fewer only if `budget_s` runs out; at least one)."""
     from oracle import druggen_oracle as orc
     from druggen_amd import synth
     cfg = orc.NetConfig(**workload)
@@ -89,11 +93,13 @@ def _cpu_gan_step_rate(workload, batch, threads, max_steps=3, budget_s=8.0):
     args = (t(da), t(dx), t(a), t(x), 10.0, t(ee), t(en))
     torch.set_num_threads(threads)
     orc.gan_step(G, D, g_opt, d_opt, *args)          # warm-up
-    steps, t0 = 0, time.perf_counter()
-    while steps < max_steps and (steps < 1 or time.perf_counter() - t0 < budget_s):
+    times, t_all = [], time.perf_counter()
+    while len(times) < steps and (not times or time.perf_counter() - t_all < budget_s):
+        t0 = time.perf_counter()
         orc.gan_step(G, D, g_opt, d_opt, *args)
-        steps += 1
-    return batch * steps / (time.perf_counter() - t0), steps
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return batch / times[len(times) // 2], len(times)
 
 
 def cpu_baseline(workload, batch: int, threads: int = 0):
@@ -106,17 +112,23 @@ def cpu_baseline(workload, batch: int, threads: int = 0):
     c1 = dict(WORKLOAD, vertexes=9, nodes=5, depth=1)
     ref_threads = threads or min(5, logical)
     variants = []
-    for name, wl, b, thr in (("bench workload shape", workload, batch, ref_threads),
-                             ("bench workload shape", workload, batch, min(physical, 64)),
-                             ("BASELINE configs[0] (N=9, L=1)", c1, 32, ref_threads),
-                             ("BASELINE configs[0] (N=9, L=1)", c1, 32, min(physical, 64))):
-        rate, steps = _cpu_gan_step_rate(wl, b, thr)
-        variants.append({"workload": name, "batch": b, "threads": thr, "value": rate, "steps": steps})
+    for name, wl, b, thr, n, budget in (("bench workload shape", workload, batch, ref_threads, 5, 60.0),
+                                        ("bench workload shape", workload, batch, min(physical, 64), 2, 15.0),
+                                        ("BASELINE configs[0] (N=9, L=1)", c1, 32, ref_threads, 5, 10.0),
+                                        ("BASELINE configs[0] (N=9, L=1)", c1, 32, min(physical, 64), 5, 10.0)):
+        rate, steps = _cpu_gan_step_rate(wl, b, thr, n, budget)
+        variants.append({"workload": name, "batch": b, "threads": thr, "value": rate, "steps": steps,
+                         "statistic": "median step time"})
     head = variants[0]
+    note = ""
+    if variants[1]["value"] < head["value"]:
+        note = (f"; the all-cores variant ({variants[1]['threads']} threads) is SLOWER than the reference's 5-thread setting at "
+                f"this size ({variants[1]['value']:.2f} vs {head['value']:.2f} molecules/s): the oracle's eager ops are too "
+                f"small to scale past a few cores")
     return {"value": head["value"], "unit": "molecules/s", "cores": head["threads"], "kind": "port",
             "sample": f"oracle (torch CPU restatement of src/model) GAN step at the bench workload's shape, batch "
-                      f"{head['batch']}, {head['steps']} step(s) after 1 warm-up, {head['threads']} threads "
-                      f"(the reference's train.py:16 setting) of {logical} logical cores",
+                      f"{head['batch']}, median of {head['steps']} step(s) after 1 warm-up, {head['threads']} threads "
+                      f"(the reference's train.py:16 setting) of {logical} logical cores" + note,
             "variants": variants, "logical_cores": logical}
 
 
@@ -215,9 +227,14 @@ def main():
         run = graphed.step
     _lib.prof_reset()
     dgf.traffic_reset()
-    # timed region: HIP events only around the attention-core launches (the roofline kernel; ~70 per
-    # step) so that the timing of the other ~2 k launches is not perturbed
-    attn_kernels = ("attn_fwd", "attn_bwd", "attn_bwd2")
+    # timed region: HIP events only around the EDGE-level launches that can be the roofline kernel (attention core,
+    # fused attention half, the three row-GEMM shapes, fused feed-forward: ~300 of the ~1.7 k launches of a step), so
+    # that the timing of the small launches is not perturbed
+    all_edge_kernels = ("attn_fwd", "attn_bwd", "attn_bwd2", "attn_half_fwd", "attn_half_bwd", "row_gemm_e128",
+                        "row_gemm_e_n384", "row_gemm_e_k384", "ffn", "ffn_wgrad")
+    # ... and of those only the time-dominant kernel of this dtype plus the attention kernel north_star names (~50
+    # launches per step: every pair of events costs a few microseconds of stream time)
+    attn_kernels = ("ffn", "attn_half_fwd") if act_dtype == "bf16" else ("row_gemm_e_k384", "attn_fwd")
     if not args.graph:
         _lib.prof_enable(kernels=attn_kernels)
     sync()
@@ -243,6 +260,16 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    replicas_identical = None
+    if args.check_replicas and world > 1:
+        sums = torch.stack([p.detach().double().sum() for p in list(G.parameters()) + list(D.parameters())] +
+                           [p.detach().double().abs().sum() for p in list(G.parameters()) + list(D.parameters())])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+        if not replicas_identical:
+            raise SystemExit("bench.py --check-replicas: parameters differ across ranks after the timed steps")
     d_loss, g_loss = (float(v.item()) for v in losses)
     if not (d_loss == d_loss and g_loss == g_loss):
         raise SystemExit(f"non-finite losses d={d_loss} g={g_loss}")
@@ -281,41 +308,61 @@ def main():
                     kernels[name]["bound"] = "hbm" if kernels[name]["frac_of_hbm_peak"] >= tf / peak else "mfma"
                 else:
                     kernels[name]["bound"] = "hbm"
-        (n_f, ms_f), bytes_f = attn_stats["attn_fwd"]
-        dom = {}
-        if n_f and ms_f > 0:        # measured inside the timed region
-            gbs = bytes_f / (ms_f * 1e-3) / 1e9
-            dom = {"achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "launches": n_f,
-                   "avg_us": 1e3 * ms_f / n_f, "algorithmic_MB_per_launch": bytes_f / n_f / 1e6}
-        elif "attn_fwd" in kernels:  # --graph: events cannot sit inside a replayed graph
-            dom = dict(kernels["attn_fwd"])
-        # HBM bytes per attention-forward launch from a PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their
-        # own runs, scripts/pmc_traffic.py): only reported when that pass was taken on THIS workload and dtype,
-        # together with the commit it was measured at
-        traffic, traffic_src = None, None
+        # ---- roofline blocks, measured INSIDE the timed region (HIP events on the launch stream)
+        SHAPES = {"row_gemm_e128": "row GEMM 128->128 (+bias / residual / LayerNorm epilogues), edge-level launches",
+                  "row_gemm_e_n384": "row GEMM 128->384 (fc1 + ReLU; dh = dz W2), edge-level launches",
+                  "row_gemm_e_k384": "row GEMM 384->128 (fc2 + residual + LayerNorm; dx = dh W1), edge-level launches",
+                  "attn_fwd": "attention core forward", "attn_bwd": "attention core backward",
+                  "attn_bwd2": "attention core second order", "attn_half_fwd": "fused attention half forward "
+                  "(e-proj + score/softmax/AV + out_e + residual + LN4)", "attn_half_bwd": "fused attention half backward",
+                  "ffn": "fused bf16 feed-forward (forward, dx)", "ffn_wgrad": "fused bf16 feed-forward weight gradients"}
+
+        def timed_block(name):
+            (n, ms), nbytes = attn_stats[name]
+            if not n or ms <= 0:
+                return None
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            blk = {"kernel": name, "what": SHAPES[name], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": n, "avg_us": 1e3 * ms / n,
+                   "algorithmic_bytes_per_launch": nbytes / n, "share_of_step": ms * 1e-3 / elapsed}
+            fl = kernels.get(name, {}).get("achieved_TFLOPs")
+            if fl is not None:      # GEMM-shaped: report the MFMA side too and name the binding roof
+                kt = kernels[name]
+                blk.update({"frac_of_mfma_peak": kt["frac_of_mfma_peak"], "mfma_peak_TFLOPs": kt["mfma_peak_TFLOPs"],
+                            "achieved_TFLOPs": kt["achieved_TFLOPs"], "mfma": kt["mfma"]})
+            return blk
+
+        blocks = [b for b in (timed_block(k) for k in attn_kernels) if b]
+        # every edge-level kernel from the two extra instrumented steps (not the timed region)
+        all_blocks = [dict(kernel=k, what=SHAPES.get(k, k), bound="hbm", achieved=v["achieved_GBps"], peak=HBM_PEAK_GBS,
+                           unit="GB/s", frac=v["frac_of_hbm_peak"], launches_timed=None, avg_us=v["avg_us"],
+                           algorithmic_bytes_per_launch=v["algorithmic_MB_per_launch"] * 1e6,
+                           share_of_step=v["share_of_step"], measured="instrumented steps after the timed region")
+                      for k, v in kernels.items() if k in SHAPES]
+        if args.graph or not blocks:        # --graph: events cannot sit inside a replayed graph
+            blocks = all_blocks
+        top_all = max(all_blocks, key=lambda b: b["share_of_step"])["kernel"] if all_blocks else None
+        dominant = max(blocks, key=lambda b: b["share_of_step"]) if blocks else {}
+        if dominant:
+            dominant["is_time_dominant_edge_kernel"] = bool(top_all == dominant["kernel"])
+        attn_name = "attn_half_fwd" if any(b["kernel"] == "attn_half_fwd" for b in blocks) else "attn_fwd"
+        attention = next((b for b in blocks if b["kernel"] == attn_name), None)
+        # HBM bytes per launch from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
+        # scripts/pmc_traffic.py): only reported when the pass was taken on THIS workload, dtype and batch; the record
+        # names the commit it was measured at
         side = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic_rec = {}
         if os.path.exists(side):
             try:
-                rec = json.load(open(side))
-                if rec.get("config") == args.config and rec.get("dtype") == act_dtype and rec.get("batch") == B:
-                    traffic = rec.get("attn_fwd_bytes_per_launch")
-                    traffic_src = {k: rec.get(k) for k in ("commit", "measured", "method")}
+                for rec in json.load(open(side)).get("records", []):
+                    if rec.get("config") == args.config and rec.get("dtype") == act_dtype and rec.get("batch") == B:
+                        traffic_rec = rec
             except Exception:
-                traffic = None
-        # the kernel family that decides the step time (largest share), next to the attention line
-        top = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
-        dominant = None
-        if top:
-            kt = kernels[top]
-            by_mfma = kt.get("bound") == "mfma"
-            dominant = {"kernel": top, "share_of_step": kt["share_of_step"], "bound": kt["bound"],
-                        "achieved": kt["achieved_TFLOPs"] if by_mfma else kt["achieved_GBps"],
-                        "peak": kt["mfma_peak_TFLOPs"] if by_mfma else HBM_PEAK_GBS,
-                        "unit": "TFLOP/s" if by_mfma else "GB/s",
-                        "frac": kt["frac_of_mfma_peak"] if by_mfma else kt["frac_of_hbm_peak"],
-                        "frac_of_hbm_peak": kt["frac_of_hbm_peak"], "frac_of_mfma_peak": kt.get("frac_of_mfma_peak"),
-                        "launches_per_step": kt["launches_per_step"], "avg_us": kt["avg_us"],
-                        "note": "measured in two extra fully instrumented steps after the timed region"}
+                traffic_rec = {}
+        for blk in blocks + [b for b in all_blocks if b not in blocks]:
+            t = traffic_rec.get("kernels", {}).get(blk["kernel"])
+            blk["traffic"] = None if not t else t["bytes_per_launch"]
+            blk["traffic_source"] = None if not t else {k: traffic_rec.get(k) for k in ("commit", "measured", "method")}
         out = {
             "metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs" if w["vertexes"] == 45 else
                       f"molecules/sec GAN step (G+D fwd+bwd), N={w['vertexes']} graphs",
@@ -333,12 +380,11 @@ def main():
                        "gemm_arithmetic": gemm_how,
                        "activations": "bf16 in HBM; fp32 parameters, optimizer state, weight gradients, softmax and "
                                       "LayerNorm statistics" if bf16 else "fp32"},
-            "roofline": {"kernel": "attn_core_fwd", "bound": "hbm", "achieved": dom.get("achieved_GBps"),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom.get("frac_of_hbm_peak"), "traffic": traffic, "traffic_source": traffic_src,
-                         "launches_timed": dom.get("launches"), "avg_us": dom.get("avg_us"),
-                         "algorithmic_bytes_per_launch": None if not dom else dom.get("algorithmic_MB_per_launch", 0) * 1e6},
-            "roofline_dominant": dominant,
+            # the time-dominant kernel AND shape of the step (largest share of the timed region among the edge-level
+            # kernels), then the attention kernel north_star names, then every timed kernel
+            "roofline": dominant,
+            "roofline_attention": attention,
+            "roofline_all": all_blocks,
             # the whole step against the HBM roof: algorithmic bytes of every HIP kernel launch of a step (the per-kernel
             # formulas of DESIGN.md section 3, accumulated by functional._account) / wall time of the instrumented steps
             "step_hbm": {"algorithmic_GB_per_step": step_bytes / detail_steps / 1e9,
@@ -348,6 +394,7 @@ def main():
                                  "slightly slower than the timed steps)"},
             "kernels": kernels,
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
+            "replicas_identical": replicas_identical,
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
         }

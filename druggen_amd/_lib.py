@@ -73,7 +73,9 @@ SIGNATURES = {
 }
 
 KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10,
-              "attn_half_fwd": 11, "attn_half_bwd": 12}
+              "attn_half_fwd": 11, "attn_half_bwd": 12,
+              "row_gemm_e128": 13, "row_gemm_e_n384": 14, "row_gemm_e_k384": 15}
+EDGE_ROWS = 65536        # DG_EDGE_ROWS of include/druggen_hip.h
 
 _lock = threading.Lock()
 _lib = None
@@ -152,6 +154,8 @@ def prof_enable(on=True, kernels=None) -> None:
         mask = 0
         for k in kernels:
             mask |= 1 << KERNEL_IDS[k]
+        if mask & (1 << 31):
+            mask -= 1 << 32
     else:
         mask = -1 if on else 0
     check(load().dg_prof_enable(mask), "dg_prof_enable")

@@ -57,6 +57,13 @@ __device__ __forceinline__ float xor_vmax16(float x) {     // max over lane bits
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// Workgroup barrier that orders LDS traffic only: the kernels below wait for their LDS-DMA BEFORE issuing a tile's
+// global stores (the DMA of the next tile was issued a whole tile earlier, so that wait is free), and must not sit on
+// `vmcnt(0)` at the next barrier until those stores have been acknowledged (PMC: waves parked > 50 % of their cycles).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
 constexpr float kLog2e = 1.4426950408889634f;
 // two-wide fp32 arithmetic: hipcc maps <2 x float> mul / add / fma to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (one
 // issue slot for two lanes' worth of work) -- the fused kernels are VALU-issue bound, not MFMA or HBM bound
@@ -202,13 +209,14 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
         if (w == 3 && lane < 16) dma16_async(reinterpret_cast<const float*>(a.q + tile * kC + lane * 8), qdst + bufi * 256);
     };
     dma_tile(static_cast<size_t>(t), 0);
+    wait_all_vmem_visible();
     int buf = 0;
     for (;; buf ^= 1, ++t) {
         const size_t node = static_cast<size_t>(t);
         const bool more = t + 1 < t_end;
         const int nb_ = static_cast<int>((t + 1) / N);      // molecule of the next tile
-        wait_all_vmem_visible();  // (through the builtin: hipcc then knows that k / v reloads have landed as well)
-        __syncthreads();          // tile i landed for every wave; s / exchange tiles and the other y buffer are free
+        lds_barrier();            // tile i landed for every wave (each waited for its share before its last stores);
+                                  // s / exchange tiles and the other y buffer are free
         if (more) dma_tile(node + 1, buf ^ 1);
         float aq[2];
 #pragma unroll
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
                     for (int r = 0; r < 4; ++r)
                         *reinterpret_cast<bf16_t*>(st + sw_base[r & 1] + (16 * mb + r) * 256 + ((nb ^ (r >> 1)) << 5)) =
                             static_cast<__bf16>(acc[mb][nb][r]);
-            __syncthreads();
+            lds_barrier();
             // ---- s Woe^T + boe (swapped): lane = row 16 mb + r16, channels 32 w + 16 nb + 4 kq + {0..3}
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
@@ -297,7 +305,10 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
                 for (int nb = 0; nb < 2; ++nb)
                     *reinterpret_cast<float4*>(xch + mb * (16 * 512) + xw_off[nb]) =
                         make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
-            __syncthreads();
+            // the next tile's DMA (issued a whole tile ago) and any k / v reload: waited for HERE, before this tile's
+            // stores go out, so that the barrier at the top of the next tile does not have to drain the stores
+            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) and lgkmcnt(0): DMA landed, exchange tile written
+            __builtin_amdgcn_s_barrier();
             if (a.abl & 2) goto next_tile;
             // ---- row phase: 16 lanes per row (8 channels each), 4 rows per pass.  The lane id is made opaque so that
             // the per-pass LDS offsets are recomputed here instead of living in registers across the whole tile loop.
@@ -352,6 +363,7 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
         }
     next_tile:
         if (!more) break;
+        if (!EDGE || (a.abl & 4)) wait_all_vmem_visible();
         b = nb_;
     }
 }
@@ -571,6 +583,7 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
         const int b0 = item / a.CH, i00 = (item % a.CH) * a.RPC;
         __syncthreads();
         dma_tile(static_cast<size_t>(b0) * N + i00, 0);
+        wait_all_vmem_visible();
     }
     int buf = 0;
     for (; item < item_end; ++item) {
@@ -605,8 +618,8 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
                 const int ni = item + 1;
                 nnode = static_cast<size_t>(ni / a.CH) * N + (ni % a.CH) * a.RPC;
             }
-            wait_all_vmem_visible();
-            __syncthreads();      // tile landed everywhere; de / staging tiles and the other buffers are free
+            lds_barrier();        // tile landed everywhere (each wave waited for its share before its last stores); de /
+                                  // staging tiles and the other buffers are free
             if (more) dma_tile(nnode, buf ^ 1);
             const char* yt = smem + buf * (2 * YB);
             const char* zt = yt + YB;
@@ -726,7 +739,7 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
             }
             // ---- dWe += de^T y
             if (WGRAD) wg_stream<MB>(tr0 + buf * (2 * YB), deA, accWe);
-            __syncthreads();
+            lds_barrier();
             // ---- dy = de We (+ dz4), swapped: lane = row 16 mb + r16, channels 16 w + 4 kq + {0..3}
             char* ot = smem + buf * (2 * YB);      // staging tile = this tile's y buffer
             f32x4 oa[MB];
@@ -753,7 +766,8 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
                 pk2[1] = pack_bf16(oa[mb][2], oa[mb][3]);
                 *reinterpret_cast<u32x2_t*>(ot + mb * (16 * 256) + ow_off) = pk2;      // (every wave is past its reads of y)
             }
-            __syncthreads();
+            wait_all_vmem_visible();      // next tile's DMA (issued a tile ago): before the stores below, not after them
+            lds_barrier();
             // ---- whole rows out: 16 lanes per row, 4 rows per instruction
 #pragma unroll
             for (int ii0 = 0; ii0 < 4 * MB; ii0 += 8) {

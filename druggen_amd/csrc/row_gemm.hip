@@ -1381,7 +1381,7 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Epilogue ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
-    ProfScope prof(DG_K_ROW_GEMM, stream);
+    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : (K == 384 ? DG_K_ROW_GEMM_E_K384 : (N == 384 ? DG_K_ROW_GEMM_E_N384 : DG_K_ROW_GEMM_E_128)), stream);
     if (use_x6()) {
         const int ng = N / 128;
         const int64_t tiles = (R + kTR - 1) / kTR;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import threading
 import weakref
 
 import os
@@ -41,6 +42,13 @@ def _account(kernel: str, nbytes: int, flops: int = 0) -> None:
     _traffic[kernel] = _traffic.get(kernel, 0) + nbytes
     if flops:
         _traffic[kernel + ":flops"] = _traffic.get(kernel + ":flops", 0) + flops
+
+
+def _gemm_key(R: int, K: int, N: int) -> str:
+    """Profiler / traffic key of a row GEMM launch: edge-level launches by shape (DG_K_ROW_GEMM_E_*), the rest together."""
+    if R < _lib.EDGE_ROWS:
+        return "row_gemm"
+    return "row_gemm_e_k384" if K == 384 else ("row_gemm_e_n384" if N == 384 else "row_gemm_e128")
 
 
 def traffic_flops(kernel: str) -> int:
@@ -156,8 +164,10 @@ _ws_cache = {}
 
 
 def _scratch(ref, need, tag="ln"):
-    """Per (device, stream, tag) scratch buffer owned by the caller side (PyTorch)."""
-    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream, tag)
+    """Per (device, stream, thread, tag) scratch buffer owned by the caller side (PyTorch).  The thread is part of the key
+    because nn.DataParallel replicas are threads: two of them on ONE device and stream (device_ids=[0, 0]) would
+    otherwise interleave a kernel of one call with the reduction of another over the same workspace."""
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream, threading.get_ident(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ref.device)
@@ -291,9 +301,11 @@ class _Flags:
     """Process-wide (NOT thread-local) pass flags.  A backward node of a CUDA tensor runs on the
     autograd engine's device thread, and nn.DataParallel runs every replica forward on its own thread:
     neither sees a ``threading.local`` set by the thread that entered the context manager (round-1
-    bug: the gradient penalty's first-order pass still computed every weight gradient).  The two
-    contexts below are entered by one thread at a time (``gradient_penalty`` is synchronous), so a
-    plain counter is enough."""
+    bug: the gradient penalty's first-order pass still computed every weight gradient).  The contexts
+    are entered by the CALLER of the model (``gradient_penalty``), never by a replica: the caller blocks
+    until every replica thread / engine thread has finished, so all of them see one consistent value
+    (``tests/test_hip_scale.py::test_dataparallel_replicas_on_one_device...`` runs two replica threads
+    through the gradient penalty).  Two independent training loops in ONE process would race them."""
     inputs_only = 0
     second_order = 0
     act_dtype = torch.float32
@@ -497,7 +509,7 @@ def row_gemm(a2, packed, K, N, bias=None, relu=False, want_relu_bits=False, mask
                                    None if mask_bits is None else mask_bits.data_ptr(), _lib.ptr(residual),
                                    _lib.fptr(gamma), _lib.fptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
                                    float(eps), code, _lib.stream_of(a2)), "dg_row_gemm")
-    _account("row_gemm", es * R * (K + N * (1 + (residual is not None))), 2 * R * K * N)
+    _account(_gemm_key(R, K, N), es * R * (K + N * (1 + (residual is not None) + (pre is not None))), 2 * R * K * N)
     if ln is not None:
         return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
     return (y, bits) if want_relu_bits else y
@@ -610,7 +622,8 @@ class _FFNLN(Function):
                                               _lib.fptr(_c(beta)), _lib.ptr(y), _lib.ptr(h), bits.data_ptr(),
                                               _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
                                               _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
-        _account("row_gemm", es * R * (C + H) + es * R * (H + 2 * C), 4 * R * C * H)
+        _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+        _account(_gemm_key(R, H, C), es * R * (H + 3 * C), 2 * R * C * H)
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         ctx.set_materialize_grads(False)
@@ -669,8 +682,9 @@ class _FFNLNBwd(Function):
                                               ws.data_ptr(), ws.numel(), R, C, H, code, _lib.stream_of(pre)),
                        "dg_edge_ffn_ln_bwd")
         _account("ln_bwd", es * R * C * 3)
-        _account("row_gemm", es * R * (C + H) + (es * R * (H + 2 * C) if dx is not None else 0),
-                 2 * R * C * H * (2 if dx is not None else 1))
+        _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+        if dx is not None:
+            _account(_gemm_key(R, H, C), es * R * (H + 2 * C), 2 * R * C * H)
         if want_w:
             _account("linear_wgrad", 2 * es * R * (C + H), 4 * R * C * H)
         ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)

@@ -43,6 +43,7 @@ extern "C" {
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */
+#define DG_EDGE_ROWS 65536        /* profiler only: row GEMMs with at least this many rows count as edge-level */
 
 typedef void* dg_stream_t;        /* hipStream_t */
 
@@ -330,7 +331,11 @@ enum {
     DG_K_FFN_WGRAD = 10,   /* fused bf16 feed-forward weight-gradient kernels */
     DG_K_ATTN_HALF_FWD = 11,   /* fused attention half of the edge branch: forward */
     DG_K_ATTN_HALF_BWD = 12,   /* ... backward */
-    DG_K_COUNT = 16
+    /* row GEMMs over EDGE-level row counts (R >= DG_EDGE_ROWS), by shape; smaller launches stay in DG_K_ROW_GEMM */
+    DG_K_ROW_GEMM_E_128 = 13,      /* 128 -> 128 (q/k/v/e/out projections and their input gradients) */
+    DG_K_ROW_GEMM_E_N384 = 14,     /* 128 -> 384 (fc1; dh = dz W2) */
+    DG_K_ROW_GEMM_E_K384 = 15,     /* 384 -> 128 (fc2 [+ residual + LayerNorm]; dx = dh W1) */
+    DG_K_COUNT = 24
 };
 int dg_prof_enable(int mask);
 int dg_prof_reset(void);

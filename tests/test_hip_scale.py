@@ -223,3 +223,68 @@ def test_rccl_calls_of_the_multi_gpu_path_run_on_this_build(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode == 0 and b"rccl ok" in p.stdout, p.stdout.decode()[-2000:]
+
+
+def test_two_gpu_rccl_bench_keeps_replicas_identical(tmp_path):
+    """On a box with >= 2 GPUs (the driver's 8-GPU scaling node; skipped on the 1-GPU test boxes): bench.py under
+    torch.distributed.run with the `nccl` backend, one rank per GPU, two timed steps; every rank must end on the same
+    parameters (bench.py --check-replicas compares per-tensor checksums with MIN / MAX all-reduces) and rank 0 must
+    report n_gpus = 2 with weak scaling."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extra", "--check-replicas", "--batch", "64"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["replicas_identical"] is True
+    assert out["config"]["global_batch"] == 128
+
+
+def test_dataparallel_replicas_on_one_device_run_the_gradient_penalty():
+    """The reference's --parallel path (train.py:220-223) wraps D in nn.DataParallel: replicas are THREADS.  Two replicas
+    on cuda:0 (device_ids=[0, 0]) go through discriminator_loss -- the batched D(real, fake) forward, the gradient
+    penalty's second-order forward, its inputs-only first backward and the double backward -- concurrently; the
+    process-wide pass flags and the per-thread workspaces must give the gradients of the unwrapped module."""
+    import cases
+    import harness
+    from druggen_amd.model import Discriminator, Generator, discriminator_loss
+    case = cases.CASES["c1_b4"]
+    cfg = cases.net_config(case)
+    gp, dp = cases.build_params(case)
+    args = (cfg.act, cfg.vertexes, cfg.edges, cfg.nodes, cfg.dropout)
+    kw = dict(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, mlp_ratio=cfg.mlp_ratio)
+    inp = harness.torch_inputs(case, torch.float32, "cuda")
+    eps = (inp["eps_edge"], inp["eps_node"])
+    grads = []
+    for parallel in (False, True):
+        G, D = Generator(*args, **kw), Discriminator(*args, **kw)
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in gp.items()})
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+        G, D = G.cuda(), D.cuda()
+        Dw = torch.nn.DataParallel(D, device_ids=[0, 0]) if parallel else D
+        for _ in range(3 if parallel else 1):          # repeat: a race would not show up every time
+            D.zero_grad(set_to_none=True)
+            _, _, d_loss = discriminator_loss(G, Dw, inp["disc_edge"], inp["disc_node"], inp["gen_edge"], inp["gen_node"],
+                                              case["batch"], inp["gen_node"].device, case["lambda_gp"], eps=eps)
+            d_loss.backward()
+            torch.cuda.synchronize()
+            cur = {k: (None if p.grad is None else p.grad.clone()) for k, p in D.named_parameters()}
+            if parallel:
+                grads.append((float(d_loss), cur))
+        if not parallel:
+            ref = (float(d_loss), cur)
+    for loss, cur in grads:
+        assert abs(loss - ref[0]) <= 1e-4 * max(1.0, abs(ref[0]))
+        # nn.DataParallel's Broadcast backward materialises zeros for parameters no replica used: the Discriminator's
+        # dead last-block edge branch (grad None on the bare module, reference models.py:202-207) reads all-zero here
+        for k, v in ref[1].items():
+            if v is None:
+                assert cur[k] is None or float(cur[k].abs().max()) == 0.0, k
+        num = sum(float(((cur[k] - v) ** 2).sum()) for k, v in ref[1].items() if v is not None)
+        den = sum(float((v ** 2).sum()) for v in ref[1].values() if v is not None)
+        assert num <= (1e-3 ** 2) * den, (num, den)
