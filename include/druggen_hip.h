@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 200            /* 0.2.0 */
+#define DG_VERSION 210            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -244,6 +244,7 @@ int dg_ffn_ln_bwd_bf16(const void* x, const void* pre_ln, const float* mean, con
                        const void* dy, void* dz, void* dx, float* dgamma, float* dbeta,
                        float* dw1, float* db1, float* dw2, float* db2, unsigned* bits_scratch,
                        void* workspace, size_t workspace_bytes, int64_t R, dg_stream_t stream);
+
 
 /* ---- edge embedding + symmetrisation: src/model/models.py:57-61,92-94 (Generator) and
  * :159-163,197-199 (Discriminator) ---------------------------------------------------
