@@ -393,6 +393,19 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
 //     dboe falls out of one extra MFMA with an all-ones A operand;
 //   * de -> LDS (bf16, row-major) -> de We swapped, with dz4 added by one more MFMA against an identity fragment
 //     -> bf16 staging tile -> whole 256-byte rows out.
+// Chunk swizzle of the backward kernel's [rows][128] bf16 tiles: the 16-byte chunk c of row r sits at position
+// c ^ bswz(r).  The tiles are read three ways -- ds_read_b128 MFMA fragments (16 rows x 16 B per hardware lane group
+// {0-3,12-15,20-27}, ...), ds_read_b64_tr_b16 weight-gradient operands (per 32 lanes: 8 rows x 32 B) and 2-byte / 8-byte
+// stores -- and `r & 15` (what the forward kernel uses) makes rows 2p and 2p + 1 share a 32-byte slot for the
+// transposing reads (PMC: 24 % of the LDS cycles of this kernel were bank conflicts).  bswz keeps the fragment reads
+// conflict-free (rows {0-3,12-15} map to chunks 0..7, rows {4..11} to 8..15) and gives rows 0..7 / 8..15 eight
+// distinct 32-byte slots each.
+__device__ __forceinline__ int bswz(int row) {
+    const int r = row & 15;
+    const int p = (r & 3) | ((((r >> 2) ^ (r >> 3)) & 1) << 2);
+    return (p << 1) | (r >> 3);
+}
+
 struct HalfBwdArgs {
     const bf16_t* y;       // [B,N,N,C]
     const bf16_t* dz;      // [B,N,N,C]  (EDGE)
@@ -534,20 +547,19 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
         for (int r = 0; r < 4; ++r) negm[mb - FM][r] = (16 * mb + 4 * kq + r < N) ? 0.f : kNegBig;
     unsigned af_off[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) af_off[ks] = r16 * 256 + (((4 * ks + kq) ^ r16) << 4);
+    for (int ks = 0; ks < 4; ++ks) af_off[ks] = r16 * 256 + (((4 * ks + kq) ^ bswz(r16)) << 4);
     // de tile store (attention layout, 2-byte elements): element (j = 16 mb + 4 kq + r, c = 16 w + r16) lives at
-    // j * 256 + ((chunk ^ (j & 15)) << 4) + (c & 7) * 2, chunk = 2 w + (r16 >> 3): one base per r, row blocks are immediates
+    // j * 256 + ((chunk ^ bswz(j)) << 4) + (c & 7) * 2, chunk = 2 w + (r16 >> 3): one base per r, row blocks are immediates
     unsigned dw_base[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        dw_base[r] = (4 * kq + r) * 256 + ((((w >> 1) ^ kq) & 3) << 6) + ((((w & 1) ^ (r >> 1)) & 1) << 5) +
-                     ((((r16 >> 3) ^ r) & 1) << 4) + (r16 & 7) * 2;
+        dw_base[r] = (4 * kq + r) * 256 + (((2 * w + (r16 >> 3)) ^ bswz(4 * kq + r)) << 4) + (r16 & 7) * 2;
     // ds_read_b64_tr_b16 source of this lane for k-block 0: row 4 kq + (r16 >> 2) of a 16-row block, channels 4 (r16 & 3)..;
     // k-block nbk flips bits 5..7 (XOR with nbk << 5), row blocks and buffers are immediates
     const int trr = 4 * kq + (r16 >> 2);
-    const unsigned tr0 = lds_byte_address(smem) + trr * 256 + (((((r16 >> 1) & 1) ^ trr) & 15) << 4) + (r16 & 1) * 8;
+    const unsigned tr0 = lds_byte_address(smem) + trr * 256 + (((((r16 >> 1) & 1) ^ bswz(trr)) & 15) << 4) + (r16 & 1) * 8;
     // staging-tile store of the last product: row 16 mb + r16, channels 16 w + 4 kq ..
-    const unsigned ow_off = r16 * 256 + (((2 * w + (kq >> 1)) ^ r16) << 4) + (kq & 1) * 8;
+    const unsigned ow_off = r16 * 256 + (((2 * w + (kq >> 1)) ^ bswz(r16)) << 4) + (kq & 1) * 8;
     const u32x2_t ones = {0x3F803F80u, 0x3F803F80u};
     wait_all_vmem_visible();
 
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
             const int L = ii * 64 + lane;
             const int row = L >> 4, cpos = L & 15;
             if (ii < 4 * MB && row < N) {
-                const size_t src = tile * N * kC + row * kC + ((cpos ^ (row & 15)) << 3);
+                const size_t src = tile * N * kC + row * kC + ((cpos ^ bswz(row)) << 3);
                 dma16_async(reinterpret_cast<const float*>(a.y + src), ydst + ii * 1024);
                 if (EDGE) dma16_async(reinterpret_cast<const float*>(a.dz + src), zdst + ii * 1024);
             }
@@ -755,7 +767,7 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
             if (EDGE) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const bf16x8 zf = *reinterpret_cast<const bf16x8*>(zt + mb * (16 * 256) + r16 * 256 + (((4 * (w >> 1) + kq) ^ r16) << 4));
+                    const bf16x8 zf = *reinterpret_cast<const bf16x8*>(zt + mb * (16 * 256) + r16 * 256 + (((4 * (w >> 1) + kq) ^ bswz(r16)) << 4));
                     oa[mb] = mfma16(idf, zf, oa[mb]);
                 }
             }
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
                 const int ii = ii0 + w;
                 const int row = 4 * ii + kq;
                 if (ii < 4 * MB && row < N) {
-                    const u32x4_t vrow = *reinterpret_cast<const u32x4_t*>(ot + row * 256 + ((r16 ^ (row & 15)) << 4));
+                    const u32x4_t vrow = *reinterpret_cast<const u32x4_t*>(ot + row * 256 + ((r16 ^ bswz(row)) << 4));
                     *reinterpret_cast<u32x4_t*>(a.dy + (node * N + row) * kC + 8 * r16) = vrow;
                 }
             }
