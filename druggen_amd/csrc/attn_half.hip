@@ -60,9 +60,13 @@ __device__ __forceinline__ float xor_vmax16(float x) {     // max over lane bits
 // Workgroup barrier that orders LDS traffic only: the kernels below wait for their LDS-DMA BEFORE issuing a tile's
 // global stores (the DMA of the next tile was issued a whole tile earlier, so that wait is free), and must not sit on
 // `vmcnt(0)` at the next barrier until those stores have been acknowledged (PMC: waves parked > 50 % of their cycles).
+// (The two empty asm statements are COMPILER barriers: s_barrier is IntrNoMem for LLVM, which is otherwise free to move
+// LDS loads / stores across it.)
 __device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 constexpr float kLog2e = 1.4426950408889634f;
 // two-wide fp32 arithmetic: hipcc maps <2 x float> mul / add / fma to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (one
@@ -307,8 +311,10 @@ __global__ __launch_bounds__(256, (MB <= 3 ? 2 : 1)) void attn_half_fwd_bf16_ker
                         make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
             // the next tile's DMA (issued a whole tile ago) and any k / v reload: waited for HERE, before this tile's
             // stores go out, so that the barrier at the top of the next tile does not have to drain the stores
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) and lgkmcnt(0): DMA landed, exchange tile written
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (a.abl & 2) goto next_tile;
             // ---- row phase: 16 lanes per row (8 channels each), 4 rows per pass.  The lane id is made opaque so that
             // the per-pass LDS offsets are recomputed here instead of living in registers across the whole tile loop.
@@ -466,6 +472,9 @@ __device__ __forceinline__ void wg_issue(unsigned tb, u32x2_t (&r)[4]) {
         for (int h = 0; h < 4; ++h) r[h] = tr_read<(MB - 1) * 4096>(tb ^ ((n0 + h) << 5));
     }
 }
+// (Never issue a 16x16x16 MFMA right behind a 16x16x32 one on the SAME accumulator: ROCm 7.2 hipcc emits no wait states
+// between the two opcodes and the sum comes out wrong on gfx950 -- observed when the transposing reads were compiler
+// builtins and hipcc scheduled the two back to back; the batches below keep them at least two MFMAs apart.)
 template <int MB, int BI>
 __device__ __forceinline__ void wg_mfma(const u32x2_t (&aop)[MB], const u32x2_t (&r)[4], f32x4 (&acc)[8]) {
     constexpr int NP = MB / 2;
@@ -740,9 +749,10 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
                 deA[mb][0] = pack_bf16(de[0][0], de[0][1]);
                 deA[mb][1] = pack_bf16(de[1][0], de[1][1]);
                 // de -> LDS (row-major bf16): rows 16 mb + 4 kq + r, channel 16 w + r16
-                const unsigned short* hw = reinterpret_cast<const unsigned short*>(&deA[mb]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) *reinterpret_cast<unsigned short*>(dt + dw_base[r] + mb * (16 * 256)) = hw[r];
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<unsigned short*>(dt + dw_base[r] + mb * (16 * 256)) =
+                        static_cast<unsigned short>(deA[mb][r >> 1] >> (16 * (r & 1)));
             }
             dbe += dbe2[0] + dbe2[1];
             {

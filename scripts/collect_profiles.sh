@@ -29,10 +29,11 @@ for cfg in c2 c3; do
 done
 cd $R
 cp profiles/traffic.json $O/traffic.json 2>/dev/null || echo '{"records": []}' > $O/traffic.json
-python scripts/pmc_traffic.py $(find $O/pmc_c2_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c2_WRITE_SIZE -name "*counter_collection.csv") c2 f32 256 $commit $O/traffic.json > $O/traffic_c2.txt
-python scripts/pmc_traffic.py $(find $O/pmc_c3_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c3_WRITE_SIZE -name "*counter_collection.csv") c3 bf16 2048 $commit $O/traffic.json > $O/traffic_c3.txt
+python scripts/pmc_traffic.py $(find $O/pmc_c2_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c2_WRITE_SIZE -name "*counter_collection.csv") c2 f32 256 $commit $O/traffic.json 150e6 > $O/traffic_c2.txt
+python scripts/pmc_traffic.py $(find $O/pmc_c3_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c3_WRITE_SIZE -name "*counter_collection.csv") c3 bf16 2048 $commit $O/traffic.json 600e6 > $O/traffic_c3.txt
 # the raw traces / counter dumps are large: keep only the summaries
-rm -rf $O/trace_c2 $O/trace_c3 $O/pmc_c2_FETCH_SIZE $O/pmc_c2_WRITE_SIZE $O/pmc_c3_FETCH_SIZE $O/pmc_c3_WRITE_SIZE
+rm -rf $O/trace_c2 $O/trace_c3
+find $O -name '*counter_collection.csv' | while read f; do gzip -9 "$f"; done; find $O -name '*.csv' -delete
 for f in bench_c2 bench_c3 bench_c4 bench_c5 bench_c5_bf16; do
   python - <<PY
 import json

@@ -6,12 +6,13 @@ Run on the GPU box (separate passes for FETCH_SIZE and WRITE_SIZE, kernel trace 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_r -o r --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o w --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra
-    python scripts/pmc_traffic.py <fetch csv> <write csv> c2 f32 256 <commit> [profiles/traffic.json]
+    python scripts/pmc_traffic.py <fetch csv> <write csv> c2 f32 256 <commit> [profiles/traffic.json] [edge_min_bytes]
 
 FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the
 bytes of a wide coalesced 16 B/lane read stream, so read bytes = 2 * FETCH_SIZE * 1024.  Launches are matched to
-bench.py's kernel keys by name; row-GEMM kernels serve node-level launches too, so only dispatches that move more than
-`EDGE_MIN_BYTES` count as edge-level (the same split as DG_EDGE_ROWS in the library's profiler).
+bench.py's kernel keys by name; row-GEMM / LayerNorm / weight-gradient kernels serve node-level launches too, so only
+dispatches that move more than `edge_min_bytes` count as edge-level (the same split as DG_EDGE_ROWS in the library's
+profiler; default: a quarter of one [B,N,N,128] tensor pass of the configuration, 8th argument).
 With a 7th argument the record is merged into that JSON file (one record per (config, dtype, batch))."""
 import collections
 import csv
@@ -19,7 +20,6 @@ import json
 import re
 import sys
 
-EDGE_MIN_BYTES = 20e6
 # bench.py key -> regex on the (mangled or demangled) kernel name
 KEYS = [
     ("attn_half_fwd", r"attn_half_fwd"),
@@ -49,6 +49,7 @@ def main():
     rd = per_dispatch(sys.argv[1], 2.0 * 1024)       # gfx950: FETCH_SIZE counts 64 B per 128 B request
     wr = per_dispatch(sys.argv[2], 1024.0)
     meta = sys.argv[3:7] + [None] * 4
+    edge_min = float(sys.argv[8]) if len(sys.argv) > 8 else 20e6
     # the two passes run the same deterministic launch sequence: pair the n-th launch of a kernel name in each
     seq_r, seq_w = collections.defaultdict(list), collections.defaultdict(list)
     for name, v in rd.values():
@@ -63,7 +64,7 @@ def main():
             continue
         for i, rbytes in enumerate(reads):
             wbytes = writes[i] if i < len(writes) else 0.0
-            if rbytes + wbytes < EDGE_MIN_BYTES:
+            if rbytes + wbytes < edge_min:
                 continue
             a = acc[key]
             a[0] += rbytes
@@ -72,7 +73,7 @@ def main():
     rec = {"config": meta[0], "dtype": meta[1], "batch": int(meta[2]) if meta[2] else None, "commit": meta[3],
            "measured": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) on bench.py --steps 3 --warmup 1",
            "method": "read = 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128 B request), write = WRITE_SIZE*1024; "
-                     "per-launch averages over the launch mix of the GAN step; dispatches under 20 MB (node-level) excluded",
+                     f"per-launch averages over the launch mix of the GAN step; dispatches under {edge_min / 1e6:.0f} MB (node-level) excluded",
            "kernels": {k: {"bytes_per_launch": (v[0] + v[1]) / v[2], "read_bytes_per_launch": v[0] / v[2],
                            "write_bytes_per_launch": v[1] / v[2], "launches": v[2]} for k, v in sorted(acc.items()) if v[2]}}
     if len(sys.argv) > 7:
