@@ -59,6 +59,8 @@ SIGNATURES = {
     "dg_embed_sym_pack": (c_int, [_P, _P, _P]),
     "dg_embed_sym_fwd": (c_int, [_P] * 6 + [c_int] * 7 + [_P]),
     "dg_embed_sym_bwd": (c_int, [_P] * 12 + [_P, c_size_t] + [c_int] * 7 + [_P]),
+    "dg_embed_sym_bwd_bf16_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dg_embed_sym_bwd_bf16": (c_int, [_P] * 11 + [_P, c_size_t] + [c_int] * 6 + [_P]),
     "dg_embed_sym_bwd2": (c_int, [_P] * 11 + [_P, c_size_t] + [c_int] * 7 + [_P]),
     "dg_onehot_embed_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dg_onehot_embed_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -1346,6 +1346,21 @@ def _embed_bwd_launch(a, w1, b1, w2, b2, g, act, out_dtype, need_da, need_w):
     g = _c(g if g.dtype == out_dtype else g.to(out_dtype))
     da = torch.empty_like(a) if need_da else None
     dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+    if (out_dtype == torch.bfloat16 and act in _PIECEWISE_LINEAR and E <= 8 and N <= 48
+            and os.environ.get("DG_EMBED_BF16", "fast") != "general"):
+        # bf16 gradients, relu / leaky: row-block streaming kernel (csrc/embed_bf16.hip)
+        need = int(lib.dg_embed_sym_bwd_bf16_workspace_bytes(B, N))
+        with _dev(a):
+            ws = _scratch(a, need, "embed16")
+            _lib.check(lib.dg_embed_sym_bwd_bf16(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)), _lib.fptr(_c(w2)),
+                                                 _lib.fptr(_c(b2)), _lib.ptr(g), _lib.ptr(da), _lib.ptr(dw1), _lib.ptr(db1),
+                                                 _lib.ptr(dw2), _lib.ptr(db2), ws.data_ptr(), ws.numel(), B, N, E, H, C,
+                                                 _ACT_IDS[act], _lib.stream_of(a)), "dg_embed_sym_bwd_bf16")
+        _account("embed_sym", B * N * N * (4 * E * (2 if da is not None else 1) + 2 * g.element_size() * C),
+                 2 * B * N * N * (E * H + H * C) * 3)
+        if not need_w:
+            dw1 = db1 = dw2 = db2 = None
+        return da, dw1, db1, dw2, db2
     need = int(lib.dg_embed_sym_workspace_bytes(B, N))
     with _dev(a):
         ws = _scratch(a, need, "embed")
