@@ -23,7 +23,7 @@ from . import _lib
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops",
-           "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot"]
+           "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -1303,14 +1303,60 @@ def _composite_embed_sym(a, w1, b1, w2, b2, act):
     return (e + e.permute(0, 2, 1, 3)) / 2
 
 
+class OutSlot:
+    """A destination buffer handed to an embedding Function as a plain Python object (autograd never sees it): the
+    kernel writes into ``tensor`` and the Function returns a fresh alias of it.  Used to let the parts of a batch (a
+    one-hot real half, a dense generated half) land in ONE [sum B, N, N, C] buffer without a concatenation copy."""
+    __slots__ = ("tensor",)
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+def _take_slot(slot, shape, dtype, device):
+    if slot is None:
+        return torch.empty(*shape, dtype=dtype, device=device)
+    t = slot.tensor
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+        raise RuntimeError("OutSlot does not match the embedding's output")
+    return t.view(shape)          # a fresh alias (forward runs with grad mode off)
+
+
+class _JoinParts(Function):
+    """The buffer whose dim-0 slices were filled by ``parts`` as ONE tensor of the graph: forward returns an alias of the
+    buffer (no copy), backward hands each part its slice of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, slot, *parts):
+        ctx.sizes = [p.shape[0] for p in parts]
+        off = 0
+        for p_ in parts:
+            if p_.data_ptr() != slot.tensor[off:off + p_.shape[0]].data_ptr():
+                raise RuntimeError("join_parts: a part does not live in its slice of the buffer")
+            off += p_.shape[0]
+        return slot.tensor.view(slot.tensor.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for n in ctx.sizes:
+            outs.append(g[off:off + n])
+            off += n
+        return (None, *outs)
+
+
+def join_parts(slot, parts):
+    return _JoinParts.apply(slot, *parts)
+
+
 class _EmbedSym(Function):
     @staticmethod
-    def forward(ctx, a, w1, b1, w2, b2, act, out_dtype):
+    def forward(ctx, a, w1, b1, w2, b2, act, out_dtype, slot=None):
         a = _c(a)
         B, N, _, E = a.shape
         H, C = w1.shape[0], w2.shape[0]
         lib = _lib.load()
-        out = torch.empty(B, N, N, C, dtype=out_dtype, device=a.device)
+        out = _take_slot(slot, (B, N, N, C), out_dtype, a.device)
         with _dev(a):
             _lib.check(lib.dg_embed_sym_fwd(_lib.fptr(a), _lib.fptr(_c(w1)), _lib.fptr(_c(b1)), _lib.fptr(_embed_packed_w2(w2)),
                                             _lib.fptr(_c(b2)), _lib.ptr(out), B, N, E, H, C, _ACT_IDS[act],
@@ -1330,10 +1376,10 @@ class _EmbedSym(Function):
             if act in _PIECEWISE_LINEAR:       # native second order (gradient penalty)
                 outs = _EmbedSymBwd.apply(a, w1, b1, w2, b2, g, act, odt, ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1] and not _inputs_only())
-                return tuple(outs) + (None, None)
-            return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act).to(odt), (a, w1, b1, w2, b2), g) + (None, None)
+                return tuple(outs) + (None, None, None)
+            return _double_backward_fallback(lambda *t: _composite_embed_sym(*t, act).to(odt), (a, w1, b1, w2, b2), g) + (None, None, None)
         return _embed_bwd_launch(a, w1, b1, w2, b2, g, act, ctx.out_dtype, ctx.needs_input_grad[0],
-                                 ctx.needs_input_grad[1] and not _inputs_only()) + (None, None)
+                                 ctx.needs_input_grad[1] and not _inputs_only()) + (None, None, None)
 
 
 _PIECEWISE_LINEAR = ("relu", "leaky")
@@ -1417,7 +1463,7 @@ class _EmbedSymBwd(Function):
         return None, gw1, None, gw2, None, gg, None, None, None, None
 
 
-def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
+def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32, slot=None):
     """(f(a) + f(a)^T(i<->j)) / 2 with f = act(W2 act(W1 a + b1) + b2): the edge embedding MLP and the
     symmetrisation of Generator / Discriminator in one kernel per direction (hidden 64, dim 128).
     The input graph ``a`` is float32; the [B,N,N,dim] result is stored as ``out_dtype``."""
@@ -1425,8 +1471,11 @@ def embed_sym(a, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
           and a.shape[-1] <= 16 and tuple(w1.shape) == (64, a.shape[-1]) and tuple(w2.shape) == (128, 64)
           and b1 is not None and b2 is not None)
     if not ok or (in_second_order_forward() and act not in _PIECEWISE_LINEAR):
-        return _composite_embed_sym(a, w1, b1, w2, b2, act).to(out_dtype)
-    return _EmbedSym.apply(a, w1, b1, w2, b2, act, out_dtype)
+        out = _composite_embed_sym(a, w1, b1, w2, b2, act).to(out_dtype)
+        if slot is not None:
+            slot.tensor = None          # the caller falls back to a concatenation
+        return out
+    return _EmbedSym.apply(a, w1, b1, w2, b2, act, out_dtype, slot)
 
 
 # --------------------------------------------------------------------------
@@ -1478,12 +1527,12 @@ def one_hot_labels(a):
 
 class _OneHotEmbed(Function):
     @staticmethod
-    def forward(ctx, labels, table, out_dtype):
+    def forward(ctx, labels, table, out_dtype, slot=None):
         B, N = labels.shape[0], labels.shape[1]
         E, C = table.shape
         lib = _lib.load()
         table = _c(table)
-        out = torch.empty(B, N, N, C, dtype=out_dtype, device=labels.device)
+        out = _take_slot(slot, (B, N, N, C), out_dtype, labels.device)
         with _dev(labels):
             _lib.check(lib.dg_onehot_embed_fwd(labels.data_ptr(), _lib.fptr(table), _lib.ptr(out), B, N, E, C, _lib.dt(out),
                                                _lib.stream_of(out)), "dg_onehot_embed_fwd")
@@ -1507,12 +1556,12 @@ class _OneHotEmbed(Function):
             _lib.check(lib.dg_onehot_embed_bwd(labels.data_ptr(), _lib.ptr(g), _lib.ptr(dtable), ws.data_ptr(), ws.numel(),
                                                B, N, E, C, _lib.dt(g), _lib.stream_of(g)), "dg_onehot_embed_bwd")
         _account("embed_sym", B * N * N * (8 + g.element_size() * C))
-        return None, dtable, None
+        return None, dtable, None, None
 
 
-def embed_sym_onehot(labels, w1, b1, w2, b2, act: str, out_dtype=torch.float32):
+def embed_sym_onehot(labels, w1, b1, w2, b2, act: str, out_dtype=torch.float32, slot=None):
     """``embed_sym`` for a one-hot input given by its labels [B,N,N]: the MLP runs on the E unit vectors (plain torch
     ops on [E,64] / [E,128] tensors, differentiated by autograd), the [B,N,N,dim] result is a symmetrised gather."""
     f = _ACT_FNS[act]
     table = f(torch.nn.functional.linear(f(w1.t() + b1), w2, b2))      # [E, dim]: row c = f(one_hot(c))
-    return _OneHotEmbed.apply(labels, table, out_dtype)
+    return _OneHotEmbed.apply(labels, table, out_dtype, slot)

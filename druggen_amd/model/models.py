@@ -40,19 +40,22 @@ class _Trunk(nn.Module):
         h = self._act(dgf.linear(h, seq[2].weight, seq[2].bias))
         return seq[4](h)
 
-    def _embed_edges(self, z_e, adt):
-        """Linear(E,64) - act - Linear(64,dim) - act - symmetrise (models.py:57-61,92-94)."""
+    def _embed_edges(self, z_e, adt, slot=None):
+        """Linear(E,64) - act - Linear(64,dim) - act - symmetrise (models.py:57-61,92-94).  ``slot``: write the result
+        into that buffer (``dgf.OutSlot``); paths that cannot set ``slot.tensor = None``."""
         el = self.edge_layers
         if self._act_name is None or (self.training and self.dropout > 0.0):
             edge = self._embed(el, z_e)
+            if slot is not None:
+                slot.tensor = None
             return ((edge + edge.permute(0, 2, 1, 3)) / 2).to(adt)
         labels = dgf.one_hot_labels(z_e)
         if (labels is not None and not z_e.requires_grad and not dgf.in_second_order_forward()
                 and el[2].weight.shape[0] == 128 and z_e.shape[-1] <= 16):
             # one-hot graph (dataset batch): E distinct embeddings -> table gather (dg_onehot_embed_fwd)
-            return dgf.embed_sym_onehot(labels, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
+            return dgf.embed_sym_onehot(labels, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt, slot)
         # one kernel per direction (dg_embed_sym_fwd / _bwd)
-        return dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt)
+        return dgf.embed_sym(z_e, el[0].weight, el[0].bias, el[2].weight, el[2].bias, self._act_name, adt, slot)
 
     def _encode(self, z_e, z_n, need_edge):
         """``z_e`` may be a tuple of edge tensors that together form the batch (e.g. a one-hot real batch and a
@@ -65,8 +68,22 @@ class _Trunk(nn.Module):
         node = self._embed(self.node_layers, z_n)
         if node.dtype != adt:
             node = node.to(adt)
-        edges = [self._embed_edges(p, adt) for p in parts]
-        edge = edges[0] if len(edges) == 1 else torch.cat(edges)
+        if len(parts) == 1:
+            edge = self._embed_edges(parts[0], adt)
+        else:
+            # every part writes its embedding into its dim-0 slice of ONE buffer: no concatenation copy of [B,N,N,C] tensors
+            N, C = parts[0].shape[1], self.edge_layers[2].weight.shape[0]
+            total = sum(p.shape[0] for p in parts)
+            full = torch.empty(total, N, N, C, dtype=adt, device=parts[0].device)
+            slots, edges, off = [], [], 0
+            for p in parts:
+                slots.append(dgf.OutSlot(full[off:off + p.shape[0]]))
+                edges.append(self._embed_edges(p, adt, slots[-1]))
+                off += p.shape[0]
+            if all(sl.tensor is not None for sl in slots):
+                edge = dgf.join_parts(dgf.OutSlot(full), edges)
+            else:
+                edge = torch.cat(edges)
         return self.TransformerEncoder(node, edge, need_edge)
 
 
