@@ -60,9 +60,50 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m
     l = __builtin_bit_cast(bf16x8, lp);
 }
 
-// X6: operands split into bf16 planes in registers, 6 MFMAs per 16-row step and tile pair instead of 8
-// fp32 MFMAs (6/16 of the matrix time per flop); same LDS traffic (one ds_read_b32 per operand row).
-template <typename T, int NT, int KT, int WN, int WK, int TR, bool MASK, bool X6 = false>
+// fp16 hi + lo split of 8 scaled fp32 values: hi = s rounded toward zero to fp16 (11 significant bits), lo = s - hi
+// (exact in fp32) rounded toward zero; hi_a hi_b + hi_a lo_b + lo_a hi_b on v_mfma_f32_32x32x16_f16 leaves a relative
+// error of 2^-22 per product, fp32 accumulate (row_gemm.hip uses the same split for the forward / dgrad GEMMs).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one pair of values: packed hi and lo words
+__device__ __forceinline__ void split2_f16(float v0, float v1, float sc, unsigned& hw, unsigned& lw) {
+    const float s0 = v0 * sc, s1 = v1 * sc;
+    hw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s0, s1));      // hi = s rounded toward zero
+    // lo = s - hi, exact in fp32: v_fma_mix_f32 reads the fp16 halves of `hw` directly (hipcc emits cvt + sub)
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hw), "v"(s0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hw), "v"(s1));
+    lw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
+// 2^(8 - floor(log2 m)) for a finite m > 0: the scale that maps m into [2^8, 2^9).  A column's scale moves again
+// only when a later value is 64-128 times larger than the one that set it (fp16 holds 2^16): on real gradients a
+// tighter window (2^12: 4-8 times) had some column of nearly every 16-row step of a wave moving, and every move
+// costs the wave ~2 steps.  Elements more than 2^11 below their column's running maximum lose relative (not
+// absolute) accuracy: absolute error 2^-25 scaled units = 2^-33 of that maximum.
+__device__ __forceinline__ float scale_for(float m) {
+    const int e = static_cast<int>((__float_as_uint(m) >> 23) & 255u);      // biased exponent (0 for denormals)
+    int be = 127 + 8 - (e - 127);
+    be = be > 253 ? 253 : (be < 1 ? 1 : be);
+    return __uint_as_float(static_cast<unsigned>(be) << 23);
+}
+
+// exact quotient / reciprocal of powers of two by exponent arithmetic (v_rcp_f32 is a 1-ulp approximation)
+__device__ __forceinline__ float pow2_ratio(float num, float den) {      // num <= den
+    const int d = static_cast<int>(__float_as_uint(num) >> 23) - static_cast<int>(__float_as_uint(den) >> 23) + 127;
+    return d < 1 ? 0.f : __uint_as_float(static_cast<unsigned>(d) << 23);
+}
+__device__ __forceinline__ float pow2_inv(float p) {                      // p in [2^-126, 2^126]
+    return __uint_as_float((254u - (__float_as_uint(p) >> 23)) << 23);
+}
+
+// SPLIT 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  SPLIT 1: operands split into three bf16 planes in registers, 6 MFMAs
+// per 16-row step and tile pair (6/16 of the fp32 matrix time per flop).  SPLIT 2 (default for fp32): fp16 hi + lo,
+// 3 MFMAs per step and tile pair.  fp16 has 5 exponent bits, so every COLUMN of dy and of x carries a running
+// power-of-two scale: before a 16-row step is converted, the step's column maxima (8 values per lane + the partner
+// lane) are compared with what the scale can hold; when a column outgrows it, the scale drops so that the new maximum
+// lands in [2^8, 2^9) and the accumulators of that column are multiplied by the (exact) ratio -- a handful of times
+// per launch.  Nothing overflows, the partial sums are un-scaled exactly at the end, and an element far below its
+// column's running maximum keeps an ABSOLUTE error of 2^-25 scaled units, i.e. 2^-33 of that maximum.
+template <typename T, int NT, int KT, int WN, int WK, int TR, bool MASK, int SPLIT = 0, int NBUF = 2>
 __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict__ dy,
                                                            const T* __restrict__ dymask,
                                                            const T* __restrict__ x,
@@ -75,8 +116,14 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
     static_assert(NT % WN == 0 && KT % WK == 0, "wave grid must divide the tile grid");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
-    // buffers: [2][TR*(N+K)] (dy tile, x tile) or [2][TR*(2N+K)] (dy, x, mask tiles), elements of T
+    // buffers: [NBUF][TR*(N+K)] (dy tile, x tile) or [NBUF][TR*(2N+K)] (dy, x, mask tiles), elements of T.  NBUF > 2: a
+    // ring with NBUF - 1 tiles in flight -- one 16-row tile per CU (32 KB) is 8 MB in flight on the whole chip, which at
+    // ~2 us of loaded HBM latency caps the stream near 4 TB/s; the waits count the DMA instructions of the tiles behind
+    // the one being consumed (the same number in every wave: the chunk counts are multiples of the block size).
     constexpr int BUF = TR * (N + K + (MASK ? N : 0));
+    constexpr int W4 = 4 * EPF;                 // elements per 16-byte chunk
+    constexpr int PER_TILE = (TR * N / W4) / THREADS * (MASK ? 2 : 1) + (TR * K / W4) / THREADS;
+    static_assert(NBUF == 2 || ((TR * N / W4) % THREADS == 0 && (TR * K / W4) % THREADS == 0), "ring needs uniform DMA counts");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave % WN, wk = wave / WN;
@@ -95,6 +142,12 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
     constexpr int H = THREADS >= 2 * N ? 2 : 1;   // row halves for the bias column sums
     static_assert(THREADS >= N, "bias reduction needs one thread per column");
     float bacc = 0.f;   // bias partial: thread t owns column t % N, row part t / N
+    // SPLIT 2: running scales of this lane's column in every dy / x tile of the wave (2^126: nothing seen yet)
+    float scy[TN], scx[TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) scy[i] = 8.507059e37f;
+#pragma unroll
+    for (int j = 0; j < TK; ++j) scx[j] = 8.507059e37f;
 
     auto issue = [&](int64_t t, int buf) {
         const int64_t r0 = t * TR;
@@ -114,12 +167,189 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
                                 N / EPF, TR, valid);
     };
 
-    if (t_lo < t_hi) issue(t_lo, 0);
-    for (int64_t t = t_lo; t < t_hi; ++t) {
-        const int buf = static_cast<int>((t - t_lo) & 1);
-        wait_all_vmem();
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (t_lo + s < t_hi) issue(t_lo + s, s);
+    auto sync_tile = [&](int64_t t, int buf) {
+        if (NBUF > 2 && t + NBUF - 2 < t_hi - 1) {      // the tiles behind this one are full tiles: leave them in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE * (NBUF - 2)) : "memory");
+        } else {
+            wait_all_vmem();
+        }
         __syncthreads();                       // tile t landed for every wave; tile t-1 fully consumed
-        if (t + 1 < t_hi) issue(t + 1, buf ^ 1);
+        if (t + NBUF - 1 < t_hi) issue(t + NBUF - 1, (buf + NBUF - 1) % NBUF);
+    };
+    auto bias_tile = [&](int buf) {
+        const T* ldy = lds + buf * BUF;
+        const T* lx = ldy + TR * N;
+        if (threadIdx.x < N * H) {   // (column, row part)
+            const int c = threadIdx.x % N, h = threadIdx.x / N;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TR / H; ++r) {
+                const int o = (h * (TR / H) + r) * N + c;
+                s += (MASK && !(ld1(lx + TR * K + o) > 0.f)) ? 0.f : ld1(ldy + o);
+            }
+            bacc += s;
+        }
+    };
+    if constexpr (SPLIT == 2 && !BF) {
+        // The accumulators are only touched by MFMAs inside the hot loop: a step whose column maxima outgrow the running
+        // scales leaves the loop, the scales move and the accumulators are multiplied OUTSIDE it, and the loop is
+        // re-entered at the same 16-row step (hipcc otherwise copies all 96 accumulator registers around the branch
+        // in every iteration).
+        constexpr int STEPS = TR / 16;
+        const int half = lane >> 5, col = lane & 31;
+        int64_t t = t_lo;
+        int s16 = 0;
+        bool need_sync = true, just_moved = false;
+        float my[TN], mx[TK];
+        while (t < t_hi) {
+            bool moved = false;
+            while (t < t_hi) {
+                const int buf = static_cast<int>((t - t_lo) % NBUF);
+                if (need_sync) {
+                    sync_tile(t, buf);
+                    need_sync = false;
+                }
+                const float* ldy = lds + buf * BUF + 16 * s16 * N;
+                const float* lx = lds + buf * BUF + TR * N + 16 * s16 * K;
+                const float* lm = lds + buf * BUF + TR * (N + K) + 16 * s16 * N;
+                // phase A: this step's operands (every LDS read is issued before the first use: one latency, not one
+                // per operand tile) and their column maxima (8 rows per lane + the partner lane)
+                float vy[TN][8], vx[TK][8];
+                float vm[MASK ? TN : 1][8];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = (8 * half + j) * N + (wn * TN + i) * 32 + col;
+                        vy[i][j] = ldy[o];
+                        if (MASK) vm[MASK ? i : 0][j] = lm[o];
+                    }
+#pragma unroll
+                for (int j2 = 0; j2 < TK; ++j2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vx[j2][j] = lx[(8 * half + j) * K + (wk * TK + j2) * 32 + col];
+                __builtin_amdgcn_sched_barrier(0);
+                bool grow = false;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (MASK) vy[i][j] = vm[MASK ? i : 0][j] > 0.f ? vy[i][j] : 0.f;
+                        m = fmaxf(m, fabsf(vy[i][j]));
+                    }
+                    my[i] = xor_step<true>(m, 32);
+                    grow |= my[i] * scy[i] >= 32768.f;
+                }
+#pragma unroll
+                for (int j2 = 0; j2 < TK; ++j2) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(vx[j2][j]));
+                    mx[j2] = xor_step<true>(m, 32);
+                    grow |= mx[j2] * scx[j2] >= 32768.f;
+                }
+                // wave-uniform, a few times per launch.  A step re-entered after its scales moved is not checked again
+                // (an inf maximum cannot be scaled into range; it goes through as inf)
+                if (__builtin_expect(!just_moved && __builtin_amdgcn_ballot_w64(grow) != 0, 0)) {
+                    moved = true;
+                    break;
+                }
+                just_moved = false;
+                // phase B: split with the running scales, 3 MFMAs per tile pair (small terms first).  The waves of a
+                // block run in lock step behind the tile barrier, so VALU and matrix work only overlap if they
+                // alternate INSIDE a wave: operand tiles are split in the order y0, x0, x1.., y1.., and the split of
+                // each one is interleaved (scheduling fences) with the MFMAs of the tile pairs the previous split
+                // completed; the pairs of the last split run at the end.
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 yh[TN], yl[TN], xh[TK], xl[TK];
+                auto split_pair = [&](int job, int pr) {      // job: 0 = y0, 1..TK = x(job-1), TK+1.. = y(job-TK)
+                    if (job == 0 || job > TK) {
+                        const int i = job == 0 ? 0 : job - TK;
+                        unsigned hw, lw;
+                        split2_f16(vy[i][2 * pr], vy[i][2 * pr + 1], scy[i], hw, lw);
+                        yh[i][pr] = hw;
+                        yl[i][pr] = lw;
+                    } else {
+                        const int j2 = job - 1;
+                        unsigned hw, lw;
+                        split2_f16(vx[j2][2 * pr], vx[j2][2 * pr + 1], scx[j2], hw, lw);
+                        xh[j2][pr] = hw;
+                        xl[j2][pr] = lw;
+                    }
+                };
+                auto mfma_part = [&](int i, int j2, int part) {
+                    const f16x8 a = __builtin_bit_cast(f16x8, part == 0 ? yl[i] : yh[i]);
+                    const f16x8 bq = __builtin_bit_cast(f16x8, part == 1 ? xl[j2] : xh[j2]);
+                    acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acc[i][j2], 0, 0, 0);
+                };
+#pragma unroll
+                for (int job = 0; job < TN + TK; ++job) {
+                    if (job < 2) {
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) split_pair(job, pr);
+                        continue;
+                    }
+                    // tile pairs completed by the previous split: x(j) -> (0, j); y(i) -> (i, 0..TK-1)
+                    const int prev = job - 1;
+                    const int ng = prev <= TK ? 1 : TK;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 3 * ng; ++m) {
+                        const int g = m / 3;
+                        mfma_part(prev <= TK ? 0 : prev - TK, prev <= TK ? prev - 1 : g, m % 3);
+#pragma unroll
+                        for (int pr = 4 * m / (3 * ng); pr < 4 * (m + 1) / (3 * ng); ++pr) split_pair(job, pr);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                {
+                    const int prev = TN + TK - 1;      // the last split: y(TN-1), or x(TK-1) when TN == 1
+#pragma unroll
+                    for (int m = 0; m < 3 * (prev <= TK ? 1 : TK); ++m)
+                        mfma_part(prev <= TK ? 0 : prev - TK, prev <= TK ? prev - 1 : m / 3, m % 3);
+                }
+                if (++s16 == STEPS) {
+                    if (part_b) bias_tile(buf);
+                    s16 = 0;
+                    ++t;
+                    need_sync = true;
+                }
+            }
+            if (!moved) break;
+            just_moved = true;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const float nsc = my[i] * scy[i] >= 32768.f ? scale_for(my[i]) : scy[i];
+                const float ratio = pow2_ratio(nsc, scy[i]);
+                scy[i] = nsc;
+                // dy columns are accumulator ROWS: row (reg & 3) + 8 (reg >> 2) + 4 half is held by lane `row`
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    const float rr = __int_as_float(__builtin_amdgcn_ds_bpermute(row * 4, __float_as_int(ratio)));
+#pragma unroll
+                    for (int j2 = 0; j2 < TK; ++j2) acc[i][j2][reg] *= rr;
+                }
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < TK; ++j2) {
+                const float nsc = mx[j2] * scx[j2] >= 32768.f ? scale_for(mx[j2]) : scx[j2];
+                const float ratio = pow2_ratio(nsc, scx[j2]);      // x columns are accumulator COLUMNS: this lane's own
+                scx[j2] = nsc;
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[i][j2][reg] *= ratio;
+            }
+        }
+    } else
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int buf = static_cast<int>((t - t_lo) % NBUF);
+        sync_tile(t, buf);
         const T* ldy = lds + buf * BUF;
         const T* lx = ldy + TR * N;
         const int half = lane >> 5, col = lane & 31;
@@ -166,7 +396,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
                         acc[i][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j2], acc[i][j2], 0, 0, 0);
             }
         } else
-        if constexpr (X6) {
+        if constexpr (SPLIT == 1) {
 #pragma unroll
             for (int s16 = 0; s16 < TR / 16; ++s16) {
                 bf16x8 af[TN][3], bfg[TK][3];
@@ -215,18 +445,7 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
                 for (int j = 0; j < TK; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (part_b) {
-            if (threadIdx.x < N * H) {   // (column, row part)
-                const int c = threadIdx.x % N, h = threadIdx.x / N;
-                float s = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < TR / H; ++r) {
-                    const int o = (h * (TR / H) + r) * N + c;
-                    s += (MASK && !(ld1(lx + TR * K + o) > 0.f)) ? 0.f : ld1(ldy + o);
-                }
-                bacc += s;
-            }
-        }
+        if (part_b) bias_tile(buf);
     }
     // partial tile -> workspace
     float* pw = part_w + static_cast<size_t>(blockIdx.x) * N * K;
@@ -238,7 +457,13 @@ __global__ __launch_bounds__(WN* WK * 64) void wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                pw[((wn * TN + i) * 32 + row) * K + (wk * TK + j) * 32 + col] = acc[i][j][reg];
+                float val = acc[i][j][reg];
+                if constexpr (SPLIT == 2 && !BF) {      // un-scale: two exact multiplications (each factor within fp32 range)
+                    const float iy = pow2_inv(scy[i]);
+                    val = val * __int_as_float(__builtin_amdgcn_ds_bpermute(row * 4, __float_as_int(iy)));
+                    val = val * pow2_inv(scx[j]);
+                }
+                pw[((wn * TN + i) * 32 + row) * K + (wk * TK + j) * 32 + col] = val;
             }
     if (part_b) {
         // combine the two row halves in a fixed order through LDS
@@ -396,9 +621,11 @@ bool wgrad_plan(int N, int K, WgradPlan* p) {
     return false;
 }
 
-int wgrad_blocks(int64_t R, const WgradPlan& p, int* tiles_per_block) {
+// `ring`: the launch keeps a 3-4 deep tile ring in LDS (fp32, 384-wide shapes): one block per CU.  The workspace query
+// passes false (more blocks -> the larger workspace serves both).
+int wgrad_blocks(int64_t R, const WgradPlan& p, int* tiles_per_block, bool ring = false) {
     const int64_t tiles = (R + p.tr - 1) / p.tr;
-    const int per_cu = p.lds > 64 * 1024 ? 1 : 2;
+    const int per_cu = (ring || p.lds > 64 * 1024) ? 1 : 2;
     int64_t target = 256 * per_cu;
     if (target > tiles) target = tiles < 1 ? 1 : tiles;
     const int64_t tpb = (tiles + target - 1) / target;
@@ -469,26 +696,35 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
         return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // fp32 operands: fp16 hi + lo with running column scales by default; DG_WGRAD=x6 / mfma32 select the bf16x6 split
+    // or the plain fp32 MFMA (A/B measurements, tests)
+    static const int split = [] {
+        const char* e = getenv("DG_WGRAD");
+        return (e && strcmp(e, "mfma32") == 0) ? 0 : (e && strcmp(e, "x6") == 0) ? 1 : 2;
+    }();
     int tpb;
-    const int S = wgrad_blocks(R, p, &tpb);
+    const int S = wgrad_blocks(R, p, &tpb, !bf && split != 0 && p.nt + p.kt == 16 && p.tr % 16 == 0);
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(DG_K_LINEAR_WGRAD, stream);
-    static const bool x6 = !(getenv("DG_WGRAD") && strcmp(getenv("DG_WGRAD"), "mfma32") == 0);   // bf16x6 split by default
 #define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \
     {                                                                                                            \
-        constexpr int lds_bytes = 2 * TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * static_cast<int>(sizeof(T));        \
-        DG_OPT_IN_LDS((&wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_>), lds_bytes);                            \
-        hipLaunchKernelGGL((wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_>), dim3(S), dim3(WN_* WK_ * 64),      \
+        constexpr int tile_bytes = TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * static_cast<int>(sizeof(T));           \
+        /* fp32 384-wide shapes: one block per CU (registers), so a deeper ring instead of a second block */     \
+        constexpr int nbuf = (sizeof(T) == 4 && X_ != 0 && NT_ + KT_ == 16) ? (4 * tile_bytes <= 131072 ? 4 : (3 * tile_bytes <= 131072 ? 3 : 2)) : 2; \
+        constexpr int lds_bytes = nbuf * tile_bytes;                                                              \
+        DG_OPT_IN_LDS((&wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_, nbuf>), lds_bytes);                      \
+        hipLaunchKernelGGL((wgrad_kernel<T, NT_, KT_, WN_, WK_, TR_, M_, X_, nbuf>), dim3(S), dim3(WN_* WK_ * 64), \
                            lds_bytes, stream, static_cast<const T*>(dy_), static_cast<const T*>(dy_mask_),       \
                            static_cast<const T*>(x_), part_w, part_b, R, tpb);                                   \
     }
 #define LAUNCH_M(NT_, KT_, WN_, WK_, TR_, M_)                                            \
     {                                                                                   \
-        if (bf) LAUNCH_X(bf16_t, NT_, KT_, WN_, WK_, TR_, M_, false)                     \
-        else if (x6 && (TR_) % 16 == 0) LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, true)    \
-        else LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, false)                         \
+        if (bf) LAUNCH_X(bf16_t, NT_, KT_, WN_, WK_, TR_, M_, 0)                         \
+        else if (split == 2 && (TR_) % 16 == 0) LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, 2) \
+        else if (split == 1 && (TR_) % 16 == 0) LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, 1) \
+        else LAUNCH_X(float, NT_, KT_, WN_, WK_, TR_, M_, 0)                             \
     }
 #define LAUNCH(NT_, KT_, WN_, WK_, TR_)                                   \
     if (p.nt == NT_ && p.kt == KT_) {                                     \

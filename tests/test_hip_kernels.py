@@ -251,8 +251,8 @@ def test_row_gemm_forward_and_dgrad_modes(R, K, N):
 
 @pytest.mark.parametrize("N,K", [(128, 128), (384, 128), (128, 384)])
 def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
-    """Same claim for the weight-gradient kernel (dW = dy^T x on the bf16x6 split): its error against fp64,
-    relative to sum_r |dy x|, stays at the level of torch's fp32 matmul of the same data."""
+    """Same claim for the weight-gradient kernel (dW = dy^T x on the fp16 hi + lo split with running column scales):
+    its error against fp64, relative to sum_r |dy x|, stays at the level of torch's fp32 matmul of the same data."""
     from druggen_amd import functional as dgf
     R = 8192
     dy, x = _gen((R, N), 21), _gen((R, K), 22)
@@ -267,6 +267,84 @@ def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
     ref_max, ref_rms = err(dyd.t() @ xd)
     print(f"N={N} K={K}: wgrad max {mine_max:.2e} rms {mine_rms:.2e} | fp32 matmul max {ref_max:.2e} rms {ref_rms:.2e}")
     assert mine_rms < 1.5 * ref_rms + 2e-9 and mine_max < 2.5 * ref_max
+
+
+WGRAD_RANGE_CASES = ["tiny_gradients", "huge_activations", "growing_rows", "shrinking_rows", "column_scales", "heavy_tailed",
+                     "zero_columns", "denormals", "one_spike"]
+
+
+@pytest.mark.parametrize("case", WGRAD_RANGE_CASES)
+@pytest.mark.parametrize("N,K", [(128, 128), (384, 128), (128, 384)])
+def test_wgrad_running_column_scales_hold_fp32_accuracy_over_the_fp32_range(N, K, case):
+    """The fp16 operands of the weight-gradient kernel carry one running power-of-two scale per COLUMN of dy and of x
+    (csrc/linear_wgrad.hip, SPLIT 2).  Data that forces the scales to move -- gradients of 1e-20, activations of 1e15,
+    rows that grow or shrink by 2^40 through the launch, columns 2^30 apart, Cauchy tails, all-zero columns, fp32
+    denormals, one spike 2^25 above the rest of its column -- must give the accuracy of an fp32 matmul of the same data:
+    error against fp64, relative to sum_r |dy x| per output, no worse than 2 x torch's fp32 result (+ 2^-24)."""
+    from druggen_amd import functional as dgf
+    R = 6000
+    g = torch.Generator().manual_seed(N + K + len(case))
+    dy = torch.randn(R, N, generator=g, dtype=torch.float64)
+    x = torch.randn(R, K, generator=g, dtype=torch.float64)
+    ramp = torch.linspace(-20, 20, R, dtype=torch.float64)[:, None]
+    if case == "tiny_gradients":
+        dy = dy * 1e-20
+    elif case == "huge_activations":
+        x = x * 1e15
+    elif case == "growing_rows":
+        dy, x = dy * torch.exp2(ramp), x * torch.exp2(0.5 * ramp)
+    elif case == "shrinking_rows":
+        dy, x = dy * torch.exp2(-ramp), x * torch.exp2(-0.5 * ramp)
+    elif case == "column_scales":
+        dy = dy * torch.exp2(torch.randint(-15, 16, (1, N), generator=g).double())
+        x = x * torch.exp2(torch.randint(-15, 16, (1, K), generator=g).double())
+    elif case == "heavy_tailed":
+        dy = dy / torch.randn(R, N, generator=g, dtype=torch.float64).abs().clamp_min(1e-4)
+        x = x / torch.randn(R, K, generator=g, dtype=torch.float64).abs().clamp_min(1e-4)
+    elif case == "zero_columns":
+        dy[:, ::3] = 0
+        x[:, 1::4] = 0
+        dy[: R // 2, 1] = 0          # a column that starts only half way through the rows
+    elif case == "denormals":
+        dy = dy * 1e-39
+    elif case == "one_spike":
+        dy[R // 3, :] *= 2.0 ** 25
+        x[2 * R // 3, :] *= 2.0 ** 25
+    dyd, xd = dy.float().cuda(), x.float().cuda()
+    dy, x = dyd.double().cpu(), xd.double().cpu()          # the fp32-rounded operands are the ground truth's inputs
+    want = dy.t() @ x
+    scale = (dy.abs().t() @ x.abs()).clamp_min(1e-300)
+    dw, db = dgf._wgrad(dyd, xd, True)
+    assert torch.isfinite(dw).all()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    ref = (dyd.t() @ xd).double().cpu()
+    e_mine = ((dw.double().cpu() - want).abs() / scale)
+    e_ref = ((ref - want).abs() / scale)
+    assert e_mine.max().item() <= 2 * e_ref.max().item() + 2.0 ** -24, (case, e_mine.max().item(), e_ref.max().item())
+    assert e_mine.pow(2).mean().sqrt().item() <= 2 * e_ref.pow(2).mean().sqrt().item() + 1e-8
+    zero = scale < 1e-290
+    assert (dw.double().cpu()[zero] == 0).all()          # all-zero columns give exact zeros
+    assert _rel(db, dy.sum(0)) < 1e-5 or case in ("heavy_tailed", "one_spike")
+
+
+def test_wgrad_propagates_inf_and_nan_like_a_matmul():
+    """dy^T x with an inf / a NaN in one row: the reference's `mm` puts non-finite values in exactly the outputs that row
+    feeds; the split kernel must not spread them to other outputs or swallow them.  As in the row GEMM (below), an inf
+    operand comes out as NaN (hi = inf, lo = inf - inf) where `mm` gives +-inf: non-finite either way."""
+    from druggen_amd import functional as dgf
+    R, N, K = 700, 128, 128
+    g = torch.Generator().manual_seed(9)
+    dy, x = torch.randn(R, N, generator=g), torch.randn(R, K, generator=g)
+    dy[100, 5] = float("inf")
+    dy[400, 77] = float("nan")
+    x[600, 9] = float("-inf")
+    dyd, xd = dy.cuda(), x.cuda()
+    dw, _ = dgf._wgrad(dyd, xd, True)
+    want = dy.double().t() @ x.double()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(dw).cpu(), fin)
+    assert torch.isnan(dw).cpu()[torch.isnan(want)].all()
+    assert _rel(dw.cpu()[fin], want[fin]) < TOL
 
 
 @pytest.mark.parametrize("data", ["normal", "scaled_rows_and_columns", "heavy_tailed"])
