@@ -44,12 +44,18 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
                                   float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes,
                                   int64_t R, int C, int H, int dtype, dg_stream_t stream) {
     if (!x || !h || !relu_bits || !pre_ln || !mean || !rstd || !gamma || !w1_dgrad_packed || !w2_dgrad_packed ||
-        !dy || !dz || !dh || !workspace)
+        !dz || !dh || !workspace)
         return fail(DG_E_ARG, "dg_edge_ffn_ln_bwd: null pointer");
+    if (!dy && dz_add != dz)
+        return fail(DG_E_ARG, "dg_edge_ffn_ln_bwd: dy == NULL means dz already holds the LayerNorm input gradient (pass it as dz_add too)");
     if (C != 128 || H != 384) return fail(DG_E_SHAPE, "dg_edge_ffn_ln_bwd: needs dim 128, hidden 384 (got %d, %d)", C, H);
     if (workspace_bytes < dg_edge_ffn_ln_workspace_bytes(R, C, H))
         return fail(DG_E_WORKSPACE, "dg_edge_ffn_ln_bwd: workspace too small");
-    int st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
+    int st = 0;
+    // dy == NULL: the LayerNorm backward ran in the epilogue of the GEMM that produced its output gradient
+    // (dg_row_gemm_ln_bwd) and dz holds the result; dgamma / dbeta are not touched
+    if (dy)
+        st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
                                     workspace_bytes, R, C, dtype, stream);
     if (st) return st;
     // dh = (dz @ W2) masked by the forward's ReLU bits

@@ -26,6 +26,10 @@ namespace dg {
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract);
 int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
 size_t row_gemm_f32_mask_words(int64_t R, int K, int N);
+size_t row_gemm_f32_ln_bwd_workspace_bytes();
+int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t R, int K, const float* residual,
+                        const float* pre, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                        float* dbeta, void* workspace, size_t workspace_bytes, dg_stream_t stream);
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
                  unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
                  const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream);
@@ -287,4 +291,19 @@ extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R
     return row_gemm_f32(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y), R, K, N,
                         bias, relu, relu_bits_out, mask_bits, static_cast<const float*>(residual), gamma, beta, mean, rstd,
                         static_cast<float*>(pre_ln), eps, stream_);
+}
+
+extern "C" size_t dg_row_gemm_ln_bwd_workspace_bytes(int dtype) {
+    return dtype == DG_DTYPE_F32 ? row_gemm_f32_ln_bwd_workspace_bytes() : 0;
+}
+
+extern "C" int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, int64_t R, int K, const void* residual,
+                                  const void* ln_pre, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int dtype,
+                                  dg_stream_t stream_) {
+    if (dtype != DG_DTYPE_F32)
+        return fail(DG_E_ARG, "dg_row_gemm_ln_bwd: float32 only (the bf16 configuration fuses this LayerNorm backward elsewhere)");
+    return row_gemm_f32_ln_bwd(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(dz), R, K,
+                               static_cast<const float*>(residual), static_cast<const float*>(ln_pre), ln_mean, ln_rstd,
+                               ln_gamma, dgamma, dbeta, workspace, workspace_bytes, stream_);
 }

@@ -300,6 +300,11 @@ int ln_grid(int64_t R, int G) {
 #define DG_FOR_LN(M) M(8, 1) M(16, 1) M(32, 1) M(64, 1) M(64, 2) M(64, 4)
 
 }  // namespace
+
+// out_k[c] = sum_b part[b][k][c] in a fixed order (shared with the LayerNorm-backward epilogue of row_gemm.hip)
+void launch_ln_finish(const float* part, int nblocks, int K, int C, float* out0, float* out1, hipStream_t stream) {
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, K), dim3(1024), 0, stream, part, nblocks, K, C, out0, out1);
+}
 }  // namespace dg
 
 using namespace dg;

@@ -79,6 +79,12 @@ struct Epilogue {
     float* pre;             // optional [R,N]: the pre-LayerNorm sum, saved for the backward
     float eps;
     int relu;
+    // LayerNorm-BACKWARD epilogue (LNB kernels): v = a B + residual is the gradient of a LayerNorm output; the row
+    // leaves as dz = rstd (v gamma - mean(v gamma) - xhat mean(v gamma xhat)), xhat = (lnb_pre - mean) rstd, with
+    // `gamma`, `mean`, `rstd` above read as that LayerNorm's saved parameters / statistics.  Per half-wave partial sums
+    // of dgamma = sum_rows v xhat and dbeta = sum_rows v go to lnb_part[(block * 8 + half-wave)][2][128].
+    const float* lnb_pre = nullptr;
+    float* lnb_part = nullptr;
 };
 
 // Sum over the 32 lanes of a half-wave, result in every lane.  DPP adds inside each 16-lane row
@@ -610,7 +616,7 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 // tile accumulate into the same registers; N = 384: the three column groups of a tile run back to back on
 // the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
 // per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
-template <int KC, int NG, bool EXCH, int NC = 4>
+template <int KC, int NG, bool EXCH, int NC = 4, bool LNB = false>
 __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
     // NC = 6 (N = 384 only): six consumer waves, each with two resident 32-column slabs (w and w + 6: 128 VGPRs
@@ -622,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     constexpr int NS = NC == 6 ? 2 : 1;            // slabs per consumer wave
     static_assert(NC == 4 || (NC == 6 && KC == 1 && NG == 1 && !EXCH), "6 consumers: resident-B 128 -> 384 only");
     static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
+    static_assert(!LNB || (EXCH && NC == 4 && NG == 1), "LayerNorm-backward epilogue: 128 -> 128 exchange kernel");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* lds = smem_raw;                              // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
     float* xb = reinterpret_cast<float*>(smem_raw + kH3Lds);   // direct epilogue: one 32 x 32 fp32 tile per consumer wave
@@ -733,6 +740,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             cs_g[g * NS + s] = inv_cs[n];
         }
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
+    float4 lpre[LNB ? 4 : 1];      // LNB: rows of the saved pre-LayerNorm sum (four at a time)
+    float4 dgam = f4(0.f), dbet = f4(0.f);      // LNB: this lane's four columns, summed over every row it finishes
     f32x16 acc[NS][2];
 #if DG_DBG & 16
     unsigned long long tl = 0, tM = 0, tE = 0, tB = 0, t00 = 0, tC = 0, tS = 0;
@@ -878,6 +887,15 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             float4 rs[2][4];
             row_scales(rs[0], 0, cs_g[0]);
             row_scales(rs[1], 1, cs_g[0]);
+            if (LNB) {      // rows of the saved pre-LayerNorm sum: requested here (the fragment registers are free now),
+                            // they arrive during the exchange
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int64_t rrow = r0 + w * 16 + it * 2 + half;
+                    if (rrow > R - 1) rrow = R - 1;
+                    lpre[LNB ? it : 0] = ld4(ep.lnb_pre + rrow * 128 + col * 4);
+                }
+            }
             __syncthreads();   // every consumer has finished its fragment reads
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -890,6 +908,54 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                 }
             __syncthreads();
             // rows of this wave: w * 16 + it * 2 + half.  `CHECK` only for the tail tile (uniform branch)
+            auto finish_rows_lnb = [&](auto check_tag) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                float* yrow = y + (r0 + w * 16 + half) * 128 + col * 4;
+                const float4 gam = ld4(ep.gamma + col * 4);
+                // two groups of four rows (register budget): the second group's rows of the saved pre-LayerNorm sum are
+                // requested before the first group is finished
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg) {
+                    float4 pn[4];
+                    if (hg == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int64_t rrow = r0 + w * 16 + (4 + j) * 2 + half;
+                            if (rrow > R - 1) rrow = R - 1;
+                            pn[j] = ld4(ep.lnb_pre + rrow * 128 + col * 4);
+                        }
+                    }
+                    float mu4[4], rs4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {      // one address per half-wave: broadcast loads
+                        int64_t rrow = r0 + w * 16 + (4 * hg + j) * 2 + half;
+                        if (CHECK && rrow > R - 1) rrow = R - 1;
+                        mu4[j] = ep.mean[rrow];
+                        rs4[j] = ep.rstd[rrow];
+                    }
+                    float4 yv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = 4 * hg + j, rr = w * 16 + it * 2 + half;
+                        float4 v = ld4(ex + rr * 128 + col * 4);
+                        if (ep.residual) v += res[it];
+                        if (CHECK && r0 + rr >= R) v = f4(0.f);
+                        const float4 xh = rs4[j] * (lpre[LNB ? j : 0] - f4(mu4[j]));
+                        const float4 u = v * gam;
+                        const float c1 = half_sum((u.x + u.y) + (u.z + u.w)) * (1.0f / 128.0f);
+                        const float c2 = half_sum((u.x * xh.x + u.y * xh.y) + (u.z * xh.z + u.w * xh.w)) * (1.0f / 128.0f);
+                        yv[j] = rs4[j] * (u - f4(c1) - c2 * xh);
+                        dgam = fma4(v, xh, dgam);
+                        dbet += v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = 4 * hg + j, rr = w * 16 + it * 2 + half;
+                        if (!CHECK || r0 + rr < R) st4(yrow + it * 256, yv[j]);
+                        if (hg == 0) lpre[LNB ? j : 0] = pn[j];
+                    }
+                }
+            };
             auto finish_rows = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
                 float* yrow = y + (r0 + w * 16 + half) * 128 + col * 4;
@@ -939,8 +1005,13 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                     }
                 }
             };
-            if (r0 + kTR <= R) finish_rows(std::false_type{});
-            else finish_rows(std::true_type{});
+            if constexpr (LNB) {
+                if (r0 + kTR <= R) finish_rows_lnb(std::false_type{});
+                else finish_rows_lnb(std::true_type{});
+            } else {
+                if (r0 + kTR <= R) finish_rows(std::false_type{});
+                else finish_rows(std::true_type{});
+            }
         }
         GSTAMP(tE)
         if (pos_g == NG - 1) __syncthreads();   // end of this chunk's iteration
@@ -961,6 +1032,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         }
     }
     for (int64_t c = nchunks; c < padded; ++c) __syncthreads();   // match the producers' padded iterations
+    if (LNB) {      // per half-wave partials of dgamma / dbeta (reduced in a fixed order by ln_finish)
+        float* pp = ep.lnb_part + (static_cast<size_t>(blockIdx.x) * 8 + 2 * w + half) * 256 + col * 4;
+        st4(pp, dgam);
+        st4(pp + 128, dbet);
+    }
 #if DG_DBG & 16
     if (lane == 0 && blockIdx.x == 17 && ep.rstd) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(ep.rstd) + 8 * w;
@@ -1444,6 +1520,39 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
 #undef LAUNCH
 #undef LAUNCHX
     return check_launch("dg_row_gemm");
+}
+
+
+void launch_ln_finish(const float* part, int nblocks, int K, int C, float* out0, float* out1, hipStream_t stream);
+
+size_t row_gemm_f32_ln_bwd_workspace_bytes() { return static_cast<size_t>(256) * 8 * 256 * sizeof(float); }
+
+// dz = LayerNormBackward(a B + residual; pre, mean, rstd, gamma), dgamma, dbeta: see Epilogue::lnb_pre
+int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t R, int K, const float* residual,
+                        const float* pre, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                        float* dbeta, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!a || !packed || !dz || !pre || !mean || !rstd || !gamma || !workspace)
+        return fail(DG_E_ARG, "dg_row_gemm_ln_bwd: null pointer");
+    // (384 -> 128: the epilogue of that kernel runs in its producer waves, which already hold three A chunks in
+    // registers: built, 593 us against 302 + 161 us for the two launches at R = 518 400 -- not kept)
+    if (R < 0 || K != 128) return fail(DG_E_SHAPE, "dg_row_gemm_ln_bwd: unsupported K=%d (K = N = 128)", K);
+    if (!use_x6()) return fail(DG_E_ARG, "dg_row_gemm_ln_bwd: needs the fp16 hi+lo row GEMM (DG_ROW_GEMM=mfma32 is set)");
+    if (workspace_bytes < row_gemm_f32_ln_bwd_workspace_bytes()) return fail(DG_E_WORKSPACE, "dg_row_gemm_ln_bwd: workspace too small");
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Epilogue ep{nullptr, nullptr, nullptr, residual, gamma, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, 0.f, 0};
+    ep.lnb_pre = pre;
+    ep.lnb_part = static_cast<float*>(workspace);
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
+    {
+        ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, true, 4, true>), kH3Lds);
+        hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, true, 4, true>), dim3(seqs), dim3(512), kH3Lds, stream, a,
+                           reinterpret_cast<const f16x8*>(packed), dz, R, ep);
+    }
+    if (dgamma || dbeta) launch_ln_finish(ep.lnb_part, seqs * 8, 2, 128, dgamma, dbeta, stream);
+    return check_launch("dg_row_gemm_ln_bwd");
 }
 
 }  // namespace dg

@@ -569,6 +569,30 @@ def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None):
     return dz, dgamma, dbeta
 
 
+def row_gemm_ln_bwd_supported(a2, K: int) -> bool:
+    """dg_row_gemm_ln_bwd serves float32 rows, K = N = 128 (DG_LN_BWD_EPILOGUE=off: A/B measurements)."""
+    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128
+            and os.environ.get("DG_LN_BWD_EPILOGUE", "on") != "off")
+
+
+def row_gemm_ln_bwd(a2, packed, K, residual, pre, gamma, mean, rstd):
+    """(dz, dgamma, dbeta) of a LayerNorm whose output gradient is ``a2 @ B + residual``: the input-gradient GEMM
+    with the LayerNorm backward as its epilogue (dg_row_gemm_ln_bwd) -- the gradient itself never reaches HBM."""
+    R = a2.shape[0]
+    lib = _lib.load()
+    dz = torch.empty(R, 128, dtype=a2.dtype, device=a2.device)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    code = _lib.dt(a2)
+    with _dev(a2):
+        ws = _scratch(a2, int(lib.dg_row_gemm_ln_bwd_workspace_bytes(code)), "lnb")
+        _lib.check(lib.dg_row_gemm_ln_bwd(_lib.ptr(a2), packed.data_ptr(), _lib.ptr(dz), R, K, _lib.ptr(residual),
+                                          _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), _lib.fptr(_c(gamma)),
+                                          _lib.ptr(dgamma), _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), code,
+                                          _lib.stream_of(a2)), "dg_row_gemm_ln_bwd")
+    _account(_gemm_key(R, K, 128), a2.element_size() * R * (K + 128 * (2 + (residual is not None))), 2 * R * K * 128)
+    return dz, dgamma, dbeta
+
+
 def _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, tz):
     """Backward of ``_ln_bwd_rows`` w.r.t. the adjoint ``tz`` of dz -> (gz, gdy, ggamma)."""
     R, N = pre.shape
@@ -627,17 +651,20 @@ class _FFNLN(Function):
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         ctx.set_materialize_grads(False)
-        # `pre` (the pre-LayerNorm sum) is a second output only so that the gradient penalty's second
-        # order can hand its adjoint back to THIS node: it then joins the LayerNorm gradient inside one
-        # backward pass instead of triggering a second walk through fc2 / fc1.
-        return y.view(x.shape), pre
+        ctx.mark_non_differentiable(mean, rstd)
+        # `pre` (the pre-LayerNorm sum) is a second output so that (1) the gradient penalty's second order can hand
+        # its adjoint back to THIS node: it then joins the LayerNorm gradient inside one backward pass instead of
+        # triggering a second walk through fc2 / fc1; (2) the consumer of y can run this LayerNorm's backward in
+        # the epilogue of its own input-gradient GEMM (``LNHandle``) and return the result as the gradient of `pre`.
+        return y.view(x.shape), pre, mean, rstd
 
     @staticmethod
-    def backward(ctx, dy, dpre):
+    def backward(ctx, dy, dpre, _dmean=None, _drstd=None):
         x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = ctx.saved_tensors
         want_w = ctx.needs_input_grad[1] and not _inputs_only()
-        if dy is None:
+        if dy is None and (dpre is None or torch.is_grad_enabled()):
             dy = torch.zeros_like(pre)
+        # dy None, dpre given, no graph recorded: the LayerNorm backward already happened in the consumer's GEMM
         dx, dw1, db1, dw2, db2, dgamma, dbeta = _FFNLNBwd.apply(x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits,
                                                                  dy, dpre, ctx.needs_input_grad[0], want_w)
         return dx, dw1, db1, dw2, db2, dgamma, dbeta, None
@@ -658,12 +685,16 @@ class _FFNLNBwd(Function):
         lib = _lib.load()
         dev = pre.device
         adt, code, es = pre.dtype, _lib.dt(pre), pre.element_size()
-        dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
         x2 = _c(x).reshape(-1, C)
-        dz = torch.empty(R, C, dtype=adt, device=dev)
         dh = torch.empty(R, H, dtype=adt, device=dev)
         dx = torch.empty(R, C, dtype=adt, device=dev) if want_x else None
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        if dy is None:      # dz_add IS the LayerNorm input gradient (made by dg_row_gemm_ln_bwd in the consumer of y)
+            dy2 = dgamma = dbeta = None
+            dz_add = dz = _c(dz_add if dz_add.dtype == adt else dz_add.to(adt)).reshape(-1, C)
+        else:
+            dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
+            dz = torch.empty(R, C, dtype=adt, device=dev)
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
             dw1 = torch.empty_like(w1)
@@ -681,14 +712,15 @@ class _FFNLNBwd(Function):
                                               _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
                                               ws.data_ptr(), ws.numel(), R, C, H, code, _lib.stream_of(pre)),
                        "dg_edge_ffn_ln_bwd")
-        _account("ln_bwd", es * R * C * 3)
+        if dy2 is not None:
+            _account("ln_bwd", es * R * C * 3)
         _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
         if dx is not None:
             _account(_gemm_key(R, H, C), es * R * (H + 2 * C), 2 * R * C * H)
         if want_w:
             _account("linear_wgrad", 2 * es * R * (C + H), 4 * R * C * H)
         ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)
-        ctx.had_add = dz_add is not None
+        ctx.had_add = dz_add is not None      # (includes the dy-None case: never differentiated again)
         ctx.set_materialize_grads(False)
         ctx.xshape = x.shape
         return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta
@@ -816,17 +848,33 @@ class _FFNLNFusedBF16(Function):
         return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta, None
 
 
-def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5):
+class LNHandle:
+    """What the consumer of a LayerNorm output needs to run that LayerNorm's backward in the epilogue of its own
+    input-gradient GEMM (dg_row_gemm_ln_bwd): the saved pre-LayerNorm sum (an autograd output of the producing node:
+    the consumer returns dz as ITS gradient), the row statistics and the affine parameters."""
+    __slots__ = ("pre", "mean", "rstd", "gamma", "beta")
+
+    def __init__(self, pre, mean, rstd, gamma, beta):
+        self.pre, self.mean, self.rstd, self.gamma, self.beta = pre, mean, rstd, gamma, beta
+
+
+def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5, want_handle: bool = False):
     """LayerNorm(x + fc2(relu(fc1(x)))) with everything elementwise fused into the GEMM
-    epilogues (dim 128, hidden 384); other shapes / second-order graphs use the composite."""
+    epilogues (dim 128, hidden 384); other shapes / second-order graphs use the composite.
+    ``want_handle``: returns (y, LNHandle or None) -- see ``attn_block(y_ln=...)``."""
     H, C = w1.shape
     ok = (x.is_cuda and x.dtype in _lib.DTYPES and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
           and b1 is not None and b2 is not None)
+    handle = None
     if not ok:
-        return _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, float(eps))
-    if x.dtype == torch.bfloat16 and not in_second_order_forward() and _fused_ffn_enabled():
-        return _FFNLNFusedBF16.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
-    return _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))[0]
+        y = _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, float(eps))
+    elif x.dtype == torch.bfloat16 and not in_second_order_forward() and _fused_ffn_enabled():
+        y = _FFNLNFusedBF16.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
+    else:
+        y, pre, mean, rstd = _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
+        if want_handle and x.dtype == torch.float32 and pre.requires_grad:
+            handle = LNHandle(pre, mean, rstd, gamma, beta)
+    return (y, handle) if want_handle else y
 
 
 def linear_relu(x, weight, bias):
@@ -899,7 +947,9 @@ class _AttnBlock(Function):
 
     @staticmethod
     def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, b3, g4, b4, alpha, eps3, eps4,
-                need_edge):
+                need_edge, ppre=None, pmean=None, prstd=None, pgamma=None, pbeta=None):
+        # ppre .. pbeta: LNHandle of the LayerNorm that produced y (or None): its backward can then run in the
+        # epilogue of this node's dy GEMM, the result leaving as the gradient of `ppre` instead of `y`
         B, N, C = x1.shape
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         adt = x1f.dtype
@@ -924,6 +974,9 @@ class _AttnBlock(Function):
                                               ln=(_c(g4), _c(b4), eps4), want_pre=True)
             outs.append(y2.view(B, N, N, C))
             saved += [mean4, rstd4, pre4]
+        ctx.has_prev = ppre is not None
+        if ctx.has_prev:
+            saved += [ppre, pmean, prstd, pgamma]
         ctx.save_for_backward(*saved)
         ctx.cfg = (alpha, eps3, eps4, need_edge, (B, N, C))
         ctx.extra = (bq, bk, bv, be, boe, bon, b3, b4)
@@ -950,13 +1003,24 @@ class _AttnBlock(Function):
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
         wants_w = ctx.needs_input_grad[2] and not _inputs_only()
+        ppre = pmean = prstd = pgamma = None
+        if ctx.has_prev:
+            ppre, pmean, prstd, pgamma = sv[-4:]
+        # y is the output of a LayerNorm whose handle came with it, and no graph is being recorded: that LayerNorm's
+        # backward runs as the epilogue of the dy GEMM (its result is the gradient of `ppre`, y itself gets none)
+        fuse_prev = bool(ctx.has_prev and not torch.is_grad_enabled() and ctx.needs_input_grad[1]
+                         and ctx.needs_input_grad[22] and row_gemm_ln_bwd_supported(q, C)
+                         and tuple(ppre.shape) == (B * N * N, C))
         outs = _AttnBlockBwd.apply(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4,
                                    q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
                                    add3, add4, aq, ak, av, ae,
-                                   alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w)
-        (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4) = outs
+                                   alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w,
+                                   ppre if fuse_prev else None, pmean, prstd, pgamma)
+        (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4, dzp, dgp, dbp) = outs
+        if not (ctx.needs_input_grad[25] and not _inputs_only()):
+            dgp = dbp = None
         return (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4,
-                None, None, None, None)
+                None, None, None, None, dzp, None, None, dgp, dbp)
 
 
 def _attn_bwd_launch(q, k, v, e, ws, wo, alpha):
@@ -999,7 +1063,7 @@ class _AttnBlockBwd(Function):
     @staticmethod
     def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
                 mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
-                alpha, need_edge, want_x, want_y, wants_w):
+                alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None):
         B, N, C = x1.shape
         adt = q.dtype
         pw = lambda w_, m_: packed_weight(w_, m_, adt)
@@ -1021,8 +1085,10 @@ class _AttnBlockBwd(Function):
                 got.add_(extra.view(got.shape))
         ctx.third = any(t is not None for t in (add3, add4, aq, ak, av, ae))
         dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
-        dy = dx1 = None
-        if want_y:
+        dy = dx1 = dzp = dgp = dbp = None
+        if want_y and ppre is not None:      # + ln4 residual path, then the backward of the LayerNorm that made y
+            dzp, dgp, dbp = row_gemm_ln_bwd(def_, pw(we, 1), C, dz4, ppre, pgamma, pmean, prstd)
+        elif want_y:
             dy = row_gemm(def_, pw(we, 1), C, C, residual=dz4).view(y.shape)      # + ln4 residual path
         if want_x:
             t = row_gemm(dqf, pw(wq, 1), C, C, residual=dz3)                       # + ln3 residual path
@@ -1041,7 +1107,7 @@ class _AttnBlockBwd(Function):
                               mean4, rstd4, pre4, dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de)
         ctx.cfg = (alpha, need_edge, (B, N, C), dx2.shape, None if dy2 is None else dy2.shape)
         ctx.set_materialize_grads(False)
-        return (dx1, dy, *gw, dg3, db3, dg4, db4)
+        return (dx1, dy, *gw, dg3, db3, dg4, db4, dzp, dgp, dbp)
 
     @staticmethod
     @once_differentiable
@@ -1090,10 +1156,10 @@ class _AttnBlockBwd(Function):
         # The outputs depend on x1 / y only through the forward intermediates: their adjoints
         # (z3bar, z4bar at the pre-LayerNorm sums; gq, gk, gv, ge) go to the forward node.
         # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, q,k,v,e, s,o,
-        #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags
+        #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags, 4 LNHandle fields
         return (None, None, *gW, g3bar, g4bar, gq.view_as(q), gk.view_as(k), gv.view_as(v), ge.view_as(e), None, None,
                 None, None, z3bar, None, None, z4bar, dx2bar.view(dx2_shape),
-                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 11))
+                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 15))
 
 
 _half_pack_cache = {}
@@ -1248,9 +1314,10 @@ class _AttnBlockFused(Function):
         return (dx1, (dy if ctx.needs_input_grad[1] else None), *gw, dg3, db3, dg4, db4, None, None, None, None)
 
 
-def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
+def attn_block(x1, y, attn, ln3, ln4, need_edge=True, y_ln=None):
     """Attention half of an encoder block for ``attn`` (an MHA module): returns
-    (LN3(x1 + out_n(o)), LN4(y + out_e(s)) or None)."""
+    (LN3(x1 + out_n(o)), LN4(y + out_e(s)) or None).  ``y_ln``: the LNHandle of the LayerNorm whose output y is
+    (``ffn_ln(..., want_handle=True)``), or None."""
     C = x1.shape[-1]
     alpha = 1.0 / (attn.d_k ** 0.5)
     args = (x1, y, attn.q.weight, attn.q.bias, attn.k.weight, attn.k.bias, attn.v.weight, attn.v.bias,
@@ -1265,7 +1332,8 @@ def attn_block(x1, y, attn, ln3, ln4, need_edge=True):
         out = _AttnBlockFused.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
         return (out[0], out[1]) if need_edge else (out, None)
     else:
-        out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge)
+        prev = (None,) * 5 if y_ln is None else (y_ln.pre, y_ln.mean, y_ln.rstd, y_ln.gamma, y_ln.beta)
+        out = _AttnBlock.apply(*args, alpha, ln3.eps, ln4.eps, need_edge, *prev)
         return (out[0], out[1]) if need_edge else (out[0], None)
     return out if need_edge else (out, None)
 

@@ -31,13 +31,15 @@ class MLP(nn.Module):
         h = dgf.linear_relu(x, self.fc1.weight, self.fc1.bias)
         return self.droprateout(dgf.linear(h, self.fc2.weight, self.fc2.bias))
 
-    def forward_residual_ln(self, x, ln):
+    def forward_residual_ln(self, x, ln, want_handle=False):
         """ln(x + self(x)) -- Encoder_Block lines 191-192 of the reference -- with fc2, the
-        residual add and the LayerNorm in one kernel when dropout is inactive."""
+        residual add and the LayerNorm in one kernel when dropout is inactive.  ``want_handle``: also returns
+        the ``dgf.LNHandle`` of that LayerNorm (or None) for the next block's attention node."""
         if self.droprateout.p > 0.0 and self.training:
-            return dgf.ln_residual(x, self.forward(x), ln.weight, ln.bias, ln.eps)
+            y = dgf.ln_residual(x, self.forward(x), ln.weight, ln.bias, ln.eps)
+            return (y, None) if want_handle else y
         return dgf.ffn_ln(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                          ln.weight, ln.bias, ln.eps)
+                          ln.weight, ln.bias, ln.eps, want_handle=want_handle)
 
 
 class MHA(nn.Module):
@@ -96,15 +98,17 @@ class Encoder_Block(nn.Module):
     def _ln(ln, a, r=None):
         return dgf.ln_residual(a, r, ln.weight, ln.bias, ln.eps)
 
-    def forward(self, x, y, need_edge=True):
+    def forward(self, x, y, need_edge=True, y_ln=None, want_ln=False):
+        """``y_ln`` / ``want_ln`` (TransformerEncoder): the handle of the LayerNorm that produced ``y`` goes in, the
+        handle of ln6 comes out as a third result -- the next block runs ln6's backward inside its own dy GEMM."""
         x1 = self._ln(self.ln1, x)
         # q/k/v/e projections, attention core, out_n/out_e + residual + ln3/ln4: one autograd node
-        x2, y2 = dgf.attn_block(x1, y, self.attn, self.ln3, self.ln4, need_edge)
+        x2, y2 = dgf.attn_block(x1, y, self.attn, self.ln3, self.ln4, need_edge, y_ln=y_ln)
         x = self.mlp.forward_residual_ln(x2, self.ln5)
         if not need_edge:
-            return x, None
-        y = self.mlp2.forward_residual_ln(y2, self.ln6)
-        return x, y
+            return (x, None, None) if want_ln else (x, None)
+        y, handle = self.mlp2.forward_residual_ln(y2, self.ln6, want_handle=True)
+        return (x, y, handle) if want_ln else (x, y)
 
 
 class TransformerEncoder(nn.Module):
@@ -120,6 +124,7 @@ class TransformerEncoder(nn.Module):
         """``need_edge=False`` skips the edge branch of the LAST block (its output
         is dropped by the Discriminator, reference models.py:202-207)."""
         last = len(self.Encoder_Blocks) - 1
+        y_ln = None
         for idx, block in enumerate(self.Encoder_Blocks):
-            x, y = block(x, y, need_edge or idx != last)
+            x, y, y_ln = block(x, y, need_edge or idx != last, y_ln=y_ln, want_ln=True)
         return x, y

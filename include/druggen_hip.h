@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 210            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 211            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -190,6 +190,18 @@ int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, in
                 const void* residual,
                 const float* gamma, const float* beta, float* mean, float* rstd, void* pre_ln,
                 float eps, int dtype, dg_stream_t stream);
+/* Input-gradient GEMM whose output is the gradient of a LayerNorm OUTPUT, with that LayerNorm's backward as the
+ * epilogue (src/model/layers.py:187-192 backward: the dgrad of the next Linear feeds ln4 / ln6):
+ *   v  = a[R,K] . B + residual                      (K = N = 128; residual nullable)
+ *   dz = rstd (v gamma - mean(v gamma) - xhat mean(v gamma xhat)),  xhat = (ln_pre - ln_mean) ln_rstd
+ *   dgamma = sum_r v xhat,  dbeta = sum_r v          (either may be NULL)
+ * v itself is never written: one launch replaces the GEMM and the dg_ln_residual_bwd that would read it back
+ * (2 of its 3 [R,128] passes).  float32 only.  workspace >= dg_row_gemm_ln_bwd_workspace_bytes(dtype).            */
+size_t dg_row_gemm_ln_bwd_workspace_bytes(int dtype);
+int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, int64_t R, int K, const void* residual,
+                       const void* ln_pre, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int dtype,
+                       dg_stream_t stream);
 /* dtype = DG_DTYPE_BF16 (csrc/gemm_bf16.hip): a, y, residual, pre_ln are bf16; the packed weight is the
  * bf16 fragment-order copy made by dg_row_gemm_pack(..., DG_DTYPE_BF16, ...); one MFMA per product,
  * fp32 accumulate and epilogue arithmetic.  Bit masks are available for every shape in this mode (the
@@ -202,7 +214,8 @@ int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, in
  * epilogues).  Weights are passed in fragment order: forward packs (dg_row_gemm_pack mode 0) for
  * _fwd, input-gradient packs (mode 1) for _bwd.  The forward saves h [R,H], the packed ReLU
  * bits (dg_row_gemm_mask_words(R,C,H) words), the pre-LayerNorm sum [R,C] and mean/rstd [R].
- * _bwd: dz_add (nullable, [R,C]) is added to the LayerNorm input-gradient; outputs: dz [R,C] and
+ * _bwd: dz_add (nullable, [R,C]) is added to the LayerNorm input-gradient (dy == NULL with dz_add == dz: dz already
+ * holds that gradient -- made by dg_row_gemm_ln_bwd -- and dgamma / dbeta are left alone); outputs: dz [R,C] and
  * dh [R,H] (scratch the caller owns), dx (nullable), dgamma, dbeta,
  * dw1 [H,C], db1, dw2 [C,H], db2 (dw1/dw2 nullable = skip the weight gradients).             */
 size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H);

@@ -249,6 +249,91 @@ def test_row_gemm_forward_and_dgrad_modes(R, K, N):
     assert _rel(y, a @ w2) < TOL
 
 
+@pytest.mark.parametrize("need_edge", [True, False])
+def test_encoder_runs_ln6_backward_inside_the_next_blocks_dy_gemm(need_edge):
+    """TransformerEncoder in float32: block l + 1 receives the handle of block l's ln6 and, in a plain first-order
+    backward, runs that LayerNorm's backward as the epilogue of its own dy GEMM (dg_row_gemm_ln_bwd): one edge-level
+    LayerNorm-backward launch less per block boundary, same gradients as with the separate launches
+    (DG_LN_BWD_EPILOGUE=off) to fp32 round-off.  Under create_graph (the gradient penalty's first pass,
+    loss.py:32-39) the separate, twice-differentiable launches stay."""
+    import os
+    from druggen_amd import functional as dgf
+    from druggen_amd.model.layers import TransformerEncoder
+    L = _lib()
+    torch.manual_seed(11)
+    B, N, C, depth = 2, 9, 128, 3
+    enc = TransformerEncoder(C, depth, 8, torch.nn.ReLU, mlp_ratio=3, drop_rate=0.0).cuda()
+    x = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    y = (0.5 * torch.randn(B, N, N, C, device="cuda")).requires_grad_(True)
+    gx = torch.randn(B, N, C, device="cuda")
+    gy = torch.randn(B, N, N, C, device="cuda")
+    params = [p for p in enc.parameters()]
+
+    def grads():
+        xo, yo = enc(x, y, need_edge)
+        outs, gos = ([xo, yo], [gx, gy]) if need_edge else ([xo], [gx])
+        return torch.autograd.grad(outs, [x, y] + params, gos, allow_unused=True)
+
+    def count(fn):
+        L.prof_enable(True, kernels=["ln_bwd"])
+        L.prof_reset()
+        out = fn()
+        n = L.prof_read("ln_bwd")[0]
+        L.prof_enable(False)
+        return out, n
+
+    fused, n_fused = count(grads)
+    os.environ["DG_LN_BWD_EPILOGUE"] = "off"
+    try:
+        plain, n_plain = count(grads)
+    finally:
+        del os.environ["DG_LN_BWD_EPILOGUE"]
+    assert n_plain - n_fused == depth - 1, (n_plain, n_fused)      # one ln6 backward per block boundary
+    for a_, b_ in zip(fused, plain):
+        assert (a_ is None) == (b_ is None)
+        if a_ is not None:
+            assert _rel(a_, b_.double().cpu()) < 2e-5
+    # twice-differentiable pass: no epilogue fusion, and the result can be differentiated again
+    xo, yo = enc(x, y, need_edge)
+    with dgf.inputs_only_backward():
+        (g1,), n_cg = count(lambda: torch.autograd.grad([xo], [y], [gx], create_graph=True))
+    assert n_cg > 0 and g1.requires_grad
+
+
+@pytest.mark.parametrize("with_residual", [True, False])
+@pytest.mark.parametrize("R", [1, 63, 64, 200, 4097, 20000])
+@pytest.mark.parametrize("K", [128])
+def test_row_gemm_with_layernorm_backward_epilogue(R, K, with_residual):
+    """dg_row_gemm_ln_bwd: the input-gradient GEMM that produces the gradient of a LayerNorm output, with that
+    LayerNorm's backward (layers.py:187-192) as its epilogue, against float64 autograd of
+    LayerNorm(pre) . (a W + residual) and against the two launches it replaces (row GEMM, then dg_ln_residual_bwd)."""
+    from druggen_amd import functional as dgf
+    a = _gen((R, K), 1)
+    w = _gen((K, 128), 2) * 0.1          # a Linear(128 -> K) weight, used transposed: dx = dy @ w
+    res = _gen((R, 128), 3) if with_residual else None
+    pre = (_gen((R, 128), 4) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * _gen((128,), 5)).requires_grad_(True)
+    beta = _gen((128,), 6).requires_grad_(True)
+    v = a @ w + (res if with_residual else 0)
+    out = torch.nn.functional.layer_norm(pre, (128,), gamma, beta, 1e-5)
+    dz_ref, dg_ref, db_ref = torch.autograd.grad(out, [pre, gamma, beta], v)
+    pre_d = pre.detach().float().cuda()
+    mean = pre_d.mean(-1)
+    rstd = (pre_d.var(-1, unbiased=False) + 1e-5).rsqrt()
+    packed = dgf.packed_weight(w.float().cuda(), 1)
+    ad = a.float().cuda()
+    resd = res.float().cuda() if with_residual else None
+    gd = gamma.detach().float().cuda()
+    dz, dg, db = dgf.row_gemm_ln_bwd(ad, packed, K, resd, pre_d, gd, mean, rstd)
+    assert _rel(dz, dz_ref) < TOL and _rel(dg, dg_ref) < TOL and _rel(db, db_ref) < TOL
+    # the two launches it replaces
+    dy = dgf.row_gemm(ad, packed, K, 128, residual=resd)
+    dz2, dg2, db2 = dgf._ln_bwd_rows(pre_d, gd, mean, rstd, dy)
+    assert _rel(dz, dz2.double().cpu()) < 1e-5 and _rel(dg, dg2.double().cpu()) < 1e-5 and _rel(db, db2.double().cpu()) < 1e-5
+    again = dgf.row_gemm_ln_bwd(ad, packed, K, resd, pre_d, gd, mean, rstd)
+    assert all(torch.equal(x, y) for x, y in zip((dz, dg, db), again))      # fixed-order partial sums
+
+
 @pytest.mark.parametrize("N,K", [(128, 128), (384, 128), (128, 384)])
 def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
     """Same claim for the weight-gradient kernel (dW = dy^T x on the fp16 hi + lo split with running column scales):
