@@ -15,7 +15,7 @@ from typing import Iterable, List, Optional
 import torch
 
 from . import _lib
-from .functional import _dev, bump_weights_epoch
+from .functional import _dev
 
 __all__ = ["FlatAdamW"]
 
@@ -98,5 +98,6 @@ class FlatAdamW:
                                                  _lib.stream_of(self.flat_param)), "dg_adamw_flat_devstep")
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that
         # version-keyed caches (packed GEMM weights) notice, exactly as an in-place torch op would
+        # (only THESE parameters go stale: a global epoch bump here made every step re-pack the other network's
+        # unchanged weights too -- half of the ~230 pack launches per step)
         torch.autograd.graph.increment_version([self.params[i] for i in self._live])
-        bump_weights_epoch()
