@@ -25,6 +25,7 @@ SIGNATURES = {
     "dg_last_error_string": (c_char_p, []),
     "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_int, _P]),
+    "dg_attn_core_bwd_add": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd2": (c_int, [_P] * 16 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_half_packed_bytes": (c_size_t, [c_int]),
     "dg_attn_half_pack": (c_int, [_P, _P, _P, c_int, _P]),

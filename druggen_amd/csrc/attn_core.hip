@@ -126,10 +126,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
 }
 
 // --------------------------------------------------------------- backward ----
-template <typename T, int LQS, int JPL, int RW>
+// ADDE: `add_e` [B,N,N,C] is added to de on its way out (the adjoint that the second order of the gradient penalty
+// hands to the first-order pass, loss.py:32-47): one more read stream instead of a 3-pass elementwise add afterwards.
+template <typename T, int LQS, int JPL, int RW, bool ADDE = false>
 __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-    const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
+    const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo, const T* __restrict__ add_e,
     T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, T* __restrict__ de, int N, int C,
     float alpha, int SL, int B) {
     constexpr int QS = 1 << LQS;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     // fp32 rows cost 4 registers per slot: no room for the second set, and that variant sits at the HBM roof already.
     constexpr bool PF = !std::is_same<T, float>::value;
     typedef typename raw4<T>::type Raw;
-    Raw re[JPL], rws[JPL], rq, rwo;
+    Raw re[JPL], rws[JPL], rae[ADDE ? JPL : 1], rq, rwo;
     auto request = [&](int i) {
         const size_t row = static_cast<size_t>(b) * N + i;
         rq = ld_raw(q + row * C + L.c0);
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
         for (int t = 0; t < JPL; ++t) {
             re[t] = ld_raw_stream(e + row * NC + L.off[t]);
             if (ws) rws[t] = ld_raw_stream(ws + row * NC + L.off[t]);
+            if (ADDE) rae[ADDE ? t : 0] = ld_raw_stream(add_e + row * NC + L.off[t]);
         }
     };
     if (PF && rw < N) request(rw);
@@ -185,10 +188,12 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
         const float4 woi = cvt_raw(rwo);
         T* der = de + row * NC;
         float4 ee[JPL], wss[JPL], pe[JPL];
+        Raw hae[ADDE ? JPL : 1];      // still packed: converted at the store
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             ee[t] = cvt_raw(re[t]);
             wss[t] = ws ? cvt_raw(rws[t]) : f4(0.f);
+            if (ADDE) hae[ADDE ? t : 0] = rae[ADDE ? t : 0];
         }
         if (PF && i + RW < N) request(i + RW);
         float4 m = f4(kNegBig);
@@ -222,7 +227,9 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
             dqa = fma4(dsg, kk, dqa);
             dkk[t] = fma4(dsg, aq, dkk[t]);
             const float4 g1 = fma4(f4(2.f), ee[t], f4(1.f));
-            if (L.jok[t] && L.cok) st4_stream(der + L.off[t], ds * aq * kk * g1);
+            float4 dev = ds * aq * kk * g1;
+            if (ADDE) dev += cvt_raw(hae[ADDE ? t : 0]);
+            if (L.jok[t] && L.cok) st4_stream(der + L.off[t], dev);
             __builtin_amdgcn_sched_barrier(0);   // one slot at a time: bounds the live temporaries
         }
         dqa = xor_sum4<QS>(dqa);
@@ -514,6 +521,12 @@ extern "C" int dg_attn_core_fwd(const void* q_, const void* k_, const void* v_, 
 extern "C" int dg_attn_core_bwd(const void* q_, const void* k_, const void* v_, const void* e_, const void* ws_,
                                 const void* wo_, void* dq_, void* dk_, void* dv_, void* de_, int B, int N, int C,
                                 float alpha, int dtype, dg_stream_t stream_) {
+    return dg_attn_core_bwd_add(q_, k_, v_, e_, ws_, wo_, nullptr, dq_, dk_, dv_, de_, B, N, C, alpha, dtype, stream_);
+}
+
+extern "C" int dg_attn_core_bwd_add(const void* q_, const void* k_, const void* v_, const void* e_, const void* ws_,
+                                    const void* wo_, const void* add_e_, void* dq_, void* dk_, void* dv_, void* de_, int B,
+                                    int N, int C, float alpha, int dtype, dg_stream_t stream_) {
     if (!q_ || !k_ || !v_ || !e_ || !wo_ || !dq_ || !dk_ || !dv_ || !de_)
         return fail(DG_E_ARG, "dg_attn_core_bwd: null pointer");  // ws may be NULL (= zeros)
     if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_attn_core_bwd: unknown dtype %d", dtype);
@@ -529,12 +542,21 @@ extern "C" int dg_attn_core_bwd(const void* q_, const void* k_, const void* v_, 
 #define LAUNCH_T(T, LQS, JPL, RW_)                                                                              \
     {                                                                                                           \
         constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL) * 64 * 16;                                          \
-        DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_>), lds);                                                \
-        hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_>), grid, block, lds, stream,                        \
-                           static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_),     \
-                           static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_),   \
-                           static_cast<T*>(dq_), static_cast<T*>(dk_), static_cast<T*>(dv_), static_cast<T*>(de_), \
-                           N, C, alpha, g.slices, B);                                                           \
+        if (add_e_) {                                                                                           \
+            DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_, true>), lds);                                      \
+            hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_, true>), grid, block, lds, stream,              \
+                               static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_), \
+                               static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_), \
+                               static_cast<const T*>(add_e_), static_cast<T*>(dq_), static_cast<T*>(dk_),       \
+                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B);           \
+        } else {                                                                                                \
+            DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_>), lds);                                            \
+            hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_>), grid, block, lds, stream,                    \
+                               static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_), \
+                               static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_), \
+                               static_cast<const T*>(nullptr), static_cast<T*>(dq_), static_cast<T*>(dk_),      \
+                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B);           \
+        }                                                                                                       \
     }
 #define LAUNCH_RW(LQS, JPL, RW_)                                        \
     {                                                                   \

@@ -1023,16 +1023,17 @@ class _AttnBlock(Function):
                 None, None, None, None, dzp, None, None, dgp, dbp)
 
 
-def _attn_bwd_launch(q, k, v, e, ws, wo, alpha):
+def _attn_bwd_launch(q, k, v, e, ws, wo, alpha, add_e=None):
     B, N, C = q.shape[0], q.shape[1], q.shape[2]
     lib = _lib.load()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     de = torch.empty_like(e)
     with _dev(q):
-        _lib.check(lib.dg_attn_core_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws), _lib.ptr(wo),
-                                        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(de), B, N, C, alpha,
-                                        _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_bwd")
-    _account("attn_bwd", q.element_size() * B * ((3 if ws is not None else 2) * N * N * C + 7 * N * C))
+        _lib.check(lib.dg_attn_core_bwd_add(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(ws),
+                                            _lib.ptr(wo), _lib.ptr(add_e), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv),
+                                            _lib.ptr(de), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)),
+                   "dg_attn_core_bwd")
+    _account("attn_bwd", q.element_size() * B * ((2 + (ws is not None) + (add_e is not None)) * N * N * C + 7 * N * C))
     return dq, dk, dv, de
 
 
@@ -1079,8 +1080,13 @@ class _AttnBlockBwd(Function):
             dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4))
             ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
-        dq, dk, dv, de = _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha)
-        for got, extra in ((dq, aq), (dk, ak), (dv, av), (de, ae)):
+        # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
+        # variant of that kernel is latency-bound at 2 waves / SIMD and the extra operand set costs more than the add
+        # it saves (configs[2], A/B on one box: 217.2 vs 213.7 ms per step): bf16 adds afterwards.
+        fold = ae is not None and adt == torch.float32 and os.environ.get("DG_ATTN_ADD", "kernel") != "post"
+        aef = _c(cast(ae)).view(B, N, N, C) if fold else None      # joins de inside the kernel
+        dq, dk, dv, de = _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha, add_e=aef)
+        for got, extra in ((dq, aq), (dk, ak), (dv, av), (de, None if fold else ae)):
             if extra is not None:
                 got.add_(extra.view(got.shape))
         ctx.third = any(t is not None for t in (add3, add4, aq, ak, av, ae))

@@ -67,6 +67,11 @@ int dg_attn_core_bwd(const void* q, const void* k, const void* v, const void* e,
                      const void* ws, const void* wo,
                      void* dq, void* dk, void* dv, void* de,
                      int B, int N, int C, float alpha, int dtype, dg_stream_t stream);
+/* The same with `add_e` (NULL or [B,N,N,C]) added to de on its way out: the double backward of the gradient penalty
+ * (loss.py:32-47) hands the second-order adjoint of e to the first-order pass this way.                          */
+int dg_attn_core_bwd_add(const void* q, const void* k, const void* v, const void* e, const void* ws, const void* wo,
+                         const void* add_e, void* dq, void* dk, void* dv, void* de, int B, int N, int C, float alpha,
+                         int dtype, dg_stream_t stream);
 
 /* Second-order: backward of dg_attn_core_bwd, needed by the WGAN-GP gradient
  * penalty (src/model/loss.py:32-39 create_graph=True, train.py:367).

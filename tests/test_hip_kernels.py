@@ -82,6 +82,28 @@ def test_attn_core_without_score_output_and_null_ws():
         assert _rel(got, want) < 5 * TOL
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,C", [(2, 9, 128), (3, 45, 128), (1, 90, 128), (2, 7, 32)])
+def test_attn_core_backward_adds_an_outside_adjoint_of_e(B, N, C, dtype):
+    """dg_attn_core_bwd_add: the adjoint that the gradient penalty's second order hands to the first-order pass
+    (loss.py:32-47) joins de inside the kernel; dq / dk / dv are untouched, de = de(plain launch) + add_e."""
+    from druggen_amd import functional as dgf
+    f = lambda shape, s, sc=1.0: (_gen(shape, s) * sc).to(dtype).cuda()
+    q, k, v, wo = f((B, N, C), 1), f((B, N, C), 2), f((B, N, C), 3), f((B, N, C), 6)
+    e, ws, ae = f((B, N, N, C), 4, 0.8), f((B, N, N, C), 5), f((B, N, N, C), 11, 0.5)
+    plain = dgf._attn_bwd_launch(q, k, v, e, ws, wo, 0.25)
+    fused = dgf._attn_bwd_launch(q, k, v, e, ws, wo, 0.25, add_e=ae)
+    for a, b in zip(plain[:3], fused[:3]):
+        assert torch.equal(a, b)
+    want = plain[3].double() + ae.double()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3      # bf16: the plain launch rounded de once more before the add
+    assert _rel(fused[3], want.cpu()) < tol
+    # without the score gradient (Discriminator's last block)
+    p2 = dgf._attn_bwd_launch(q, k, v, e, None, wo, 0.25)
+    f2 = dgf._attn_bwd_launch(q, k, v, e, None, wo, 0.25, add_e=ae)
+    assert _rel(f2[3], (p2[3].double() + ae.double()).cpu()) < tol
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
