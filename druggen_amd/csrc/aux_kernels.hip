@@ -3,7 +3,7 @@
 //   * AdamW update   -- reference train.py:213-214,368,384 (torch.optim.AdamW defaults)
 //   * argmax decode  -- reference inference.py:197-198 (torch.max(.., -1)[1])
 // All HBM/latency-bound byte and elementwise work: one coalesced pass each.
-#include "common.h"
+#include "bf16.h"
 
 namespace dg {
 namespace {
@@ -113,10 +113,106 @@ __global__ void argmax_kernel(const float* __restrict__ logits, int64_t rows, in
     out[r] = static_cast<unsigned char>(arg);
 }
 
+// ---- skinny readout: nn.Linear(128 -> N <= 16) over edge / node rows (reference models.py:67-68,100-101) ----
+// y[r][n] = sum_k x[r][k] w[n][k] + b[n]: a coalesced stream over x (32 lanes x 4 columns = one 128-wide row, two rows
+// per wave instruction), N x 4 multiply-adds per lane against weights held in registers, a 32-lane DPP sum per output.
+// x may be float32 or bfloat16 (the activation dtype); the logits are float32 in every mode (no `.float()` copy).
+__device__ __forceinline__ float half_wave_sum32(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float lo2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float hi2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return (threadIdx.x & 32) ? lo2 + hi2 : lo + hi;
+}
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void skinny_linear_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ y,
+                                                              int64_t R, int N) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, c4 = lane & 31;
+    float4 wr[NMAX];
+    float br[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+        wr[n] = n < N ? ld4(w + n * 128 + 4 * c4) : f4(0.f);
+        br[n] = (n < N && b) ? b[n] : 0.f;
+    }
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t r0 = wave * 2; r0 < R; r0 += nwaves * 2) {
+        const int64_t row = r0 + half;
+        const bool ok = row < R;
+        const float4 xv = ok ? ld4_stream(x + row * 128 + 4 * c4) : f4(0.f);
+        float out = 0.f;      // lane n of each half keeps output n
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+            const float s = half_wave_sum32((xv.x * wr[n].x + xv.y * wr[n].y) + (xv.z * wr[n].z + xv.w * wr[n].w));
+            if (c4 == n) out = s + br[n];
+        }
+        if (ok && c4 < N) y[row * N + c4] = out;
+    }
+}
+// dx[r][k] = sum_n dy[r][n] w[n][k]  (the readout's input gradient; dy float32, dx in the activation dtype)
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void skinny_linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                T* __restrict__ dx, int64_t R, int N) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, c4 = lane & 31;
+    float4 wr[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) wr[n] = n < N ? ld4(w + n * 128 + 4 * c4) : f4(0.f);
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t r0 = wave * 2; r0 < R; r0 += nwaves * 2) {
+        const int64_t row = r0 + half;
+        if (row >= R) continue;
+        float4 acc = f4(0.f);
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+            if (n < N) acc = fma4(f4(dy[row * N + n]), wr[n], acc);      // one address per half-wave: broadcast load
+        st4_stream(dx + row * 128 + 4 * c4, acc);
+    }
+}
+
 }  // namespace
 }  // namespace dg
 
 using namespace dg;
+
+extern "C" int dg_skinny_linear_fwd(const void* x, const float* w, const float* b, float* y, int64_t R, int N, int K,
+                                    int dtype, dg_stream_t stream_) {
+    if (!x || !w || !y) return fail(DG_E_ARG, "dg_skinny_linear_fwd: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_skinny_linear_fwd: unknown dtype %d", dtype);
+    if (R < 0 || K != 128 || N < 1 || N > 16) return fail(DG_E_SHAPE, "dg_skinny_linear_fwd: unsupported N=%d K=%d (N <= 16, K == 128)", N, K);
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t blocks = (R / 2 + 3) / 4 + 1;
+    const int grid = static_cast<int>(blocks < 2048 ? blocks : 2048);
+#define LAUNCH(T, NM) hipLaunchKernelGGL((skinny_linear_fwd_kernel<T, NM>), dim3(grid), dim3(256), 0, stream, static_cast<const T*>(x), w, b, y, R, N)
+    if (dtype == DG_DTYPE_BF16) { if (N <= 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
+    else { if (N <= 8) LAUNCH(float, 8); else LAUNCH(float, 16); }
+#undef LAUNCH
+    return check_launch("dg_skinny_linear_fwd");
+}
+
+extern "C" int dg_skinny_linear_dgrad(const float* dy, const float* w, void* dx, int64_t R, int N, int K, int dtype,
+                                      dg_stream_t stream_) {
+    if (!dy || !w || !dx) return fail(DG_E_ARG, "dg_skinny_linear_dgrad: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_skinny_linear_dgrad: unknown dtype %d", dtype);
+    if (R < 0 || K != 128 || N < 1 || N > 16) return fail(DG_E_SHAPE, "dg_skinny_linear_dgrad: unsupported N=%d K=%d (N <= 16, K == 128)", N, K);
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t blocks = (R / 2 + 3) / 4 + 1;
+    const int grid = static_cast<int>(blocks < 2048 ? blocks : 2048);
+#define LAUNCH(T, NM) hipLaunchKernelGGL((skinny_linear_dgrad_kernel<T, NM>), dim3(grid), dim3(256), 0, stream, dy, w, static_cast<T*>(dx), R, N)
+    if (dtype == DG_DTYPE_BF16) { if (N <= 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16); }
+    else { if (N <= 8) LAUNCH(float, 8); else LAUNCH(float, 16); }
+#undef LAUNCH
+    return check_launch("dg_skinny_linear_dgrad");
+}
+
 
 extern "C" int dg_densify(const int64_t* edge_src, const int64_t* edge_dst, const int64_t* edge_attr, int64_t n_edges,
                           int B, int N, int E, int* labels, float* a, int* bad_count, dg_stream_t stream_) {

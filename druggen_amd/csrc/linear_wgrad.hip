@@ -514,8 +514,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // dW[n][k] = sum_r dy[r][n] x[r][k] with N = 5 / 13: no MFMA tile to fill, the kernel is a coalesced
 // stream over x (512 B rows) with N float4 accumulators per lane; dy[r][.] is a broadcast load.
 // Thread = (row phase, k quad); row phases are combined through LDS in a fixed order.
-template <typename T, int NMAX>
-__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename TY, typename T, int NMAX>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const TY* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ part_w, float* __restrict__ part_b,
                                                          int64_t R, int N, int K, int64_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const T* __restrict__
     if (rp < phases) {
         for (int64_t r = r_lo + rp; r < r_hi; r += phases) {
             const float4 xv = ld4(x + r * K + kq * 4);
-            const T* dr = dy + r * N;
+            const TY* dr = dy + r * N;
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 const float d = n < N ? ld1(dr + n) : 0.f;
@@ -656,6 +656,46 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
+// N <= 16 output rows: dy (float32 or bf16) and x (float32 or bf16) may differ -- the readout's logits are float32 in
+// the bf16 configuration too
+static int skinny_wgrad(const void* dy_, bool dy_f32, const void* x_, bool x_bf, float* dw, float* db, void* workspace,
+                        size_t workspace_bytes, int64_t R, int N, int K, dg_stream_t stream_) {
+    if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
+        return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int S = kSkinnyBlocks;
+    int64_t rpb = (R + S - 1) / S;
+    if (rpb < 64) rpb = 64;
+    S = static_cast<int>((R + rpb - 1) / rpb);
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
+    const int KQ = K / 4, phases = 256 / KQ;
+    ProfScope prof(DG_K_LINEAR_WGRAD, stream);
+#define SKINNY(TY, T, NM)                                                                                         \
+    hipLaunchKernelGGL((skinny_wgrad_kernel<TY, T, NM>), dim3(S), dim3(256), phases * NM * KQ * 16, stream,       \
+                       static_cast<const TY*>(dy_), static_cast<const T*>(x_), part_w, part_b, R, N, K, rpb);
+#define SKINNY_N(TY, T) { if (N <= 8) { SKINNY(TY, T, 8) } else { SKINNY(TY, T, 16) } }
+    if (dy_f32 && x_bf) SKINNY_N(float, bf16_t)
+    else if (x_bf) SKINNY_N(bf16_t, bf16_t)
+    else SKINNY_N(float, float)
+#undef SKINNY_N
+#undef SKINNY
+    const int64_t nw = static_cast<int64_t>(N) * K;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + 255) / 256)), dim3(256), 0, stream,
+                       part_w, S, nw, dw);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part_b, S, static_cast<int64_t>(N), db);
+    return check_launch("dg_linear_wgrad(skinny)");
+}
+
+/* The readout's weight gradient with float32 logit gradients and activations of `dtype` (models.py:67-68 backward). */
+extern "C" int dg_skinny_linear_wgrad(const float* dy, const void* x, float* dw, float* db, void* workspace,
+                                      size_t workspace_bytes, int64_t R, int N, int K, int dtype, dg_stream_t stream_) {
+    if (!dy || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_skinny_linear_wgrad: null pointer");
+    if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_skinny_linear_wgrad: unknown dtype %d", dtype);
+    if (R < 1 || !skinny_ok(N, K)) return fail(DG_E_SHAPE, "dg_skinny_linear_wgrad: unsupported shape R=%lld N=%d K=%d", (long long)R, N, K);
+    return skinny_wgrad(dy, true, x, dtype == DG_DTYPE_BF16, dw, db, workspace, workspace_bytes, R, N, K, stream_);
+}
+
 extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void* x_, float* dw, float* db,
                                void* workspace, size_t workspace_bytes, int64_t R, int N, int K, int dtype,
                                dg_stream_t stream_) {
@@ -664,31 +704,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     const bool bf = dtype == DG_DTYPE_BF16;
     if (R >= 1 && skinny_ok(N, K)) {
         if (dy_mask_) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask is not supported for N <= 16");
-        if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
-            return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
-        hipStream_t stream = static_cast<hipStream_t>(stream_);
-        int S = kSkinnyBlocks;
-        int64_t rpb = (R + S - 1) / S;
-        if (rpb < 64) rpb = 64;
-        S = static_cast<int>((R + rpb - 1) / rpb);
-        float* part_w = static_cast<float*>(workspace);
-        float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
-        const int KQ = K / 4, phases = 256 / KQ;
-        ProfScope prof(DG_K_LINEAR_WGRAD, stream);
-#define SKINNY(T, NM)                                                                                             \
-    hipLaunchKernelGGL((skinny_wgrad_kernel<T, NM>), dim3(S), dim3(256), phases * NM * KQ * 16, stream,           \
-                       static_cast<const T*>(dy_), static_cast<const T*>(x_), part_w, part_b, R, N, K, rpb);
-        if (N <= 8) {
-            if (bf) { SKINNY(bf16_t, 8) } else { SKINNY(float, 8) }
-        } else {
-            if (bf) { SKINNY(bf16_t, 16) } else { SKINNY(float, 16) }
-        }
-#undef SKINNY
-        const int64_t nw = static_cast<int64_t>(N) * K;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + 255) / 256)), dim3(256), 0, stream,
-                           part_w, S, nw, dw);
-        if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part_b, S, static_cast<int64_t>(N), db);
-        return check_launch("dg_linear_wgrad(skinny)");
+        return skinny_wgrad(dy_, !bf, x_, bf, dw, db, workspace, workspace_bytes, R, N, K, stream_);
     }
     WgradPlan p;
     if (R < 1 || !wgrad_plan(N, K, &p))

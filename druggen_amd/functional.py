@@ -22,7 +22,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
-           "second_order_forward", "in_second_order_forward", "traffic_reset", "traffic_bytes", "traffic_flops",
+           "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops",
            "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
@@ -429,6 +429,65 @@ def linear(x, weight, bias=None):
     """``F.linear`` whose weight/bias gradients (first and second order) run on
     ``dg_linear_wgrad``."""
     return _Linear.apply(x, weight, bias)
+
+
+class _Readout(Function):
+    """nn.Linear(128 -> N <= 16) over edge / node rows with float32 logits whatever the activation dtype (reference
+    models.py:67-68,100-101: readout_e / readout_n): one streaming kernel per direction (dg_skinny_linear_fwd / _dgrad,
+    dg_skinny_linear_wgrad) instead of `x.float()` + a library GEMM.  First order; a graph that is differentiated again
+    goes through the composite."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        N, K = w.shape
+        x2 = _c(x).reshape(-1, K)
+        R = x2.shape[0]
+        y = torch.empty(R, N, dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with _dev(x2):
+            _lib.check(lib.dg_skinny_linear_fwd(_lib.ptr(x2), _lib.fptr(_c(w)), _lib.fptr(None if b is None else _c(b)),
+                                                _lib.ptr(y), R, N, K, _lib.dt(x2), _lib.stream_of(x2)),
+                       "dg_skinny_linear_fwd")
+        _account("readout", x2.element_size() * R * K + 4 * R * N)
+        ctx.save_for_backward(x, w, b)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return _double_backward_fallback(lambda x_, w_, b_: torch.nn.functional.linear(x_.float(), w_, b_),
+                                             (x, w, b), dy)
+        N, K = w.shape
+        lib = _lib.load()
+        dy2 = _c(dy.float()).reshape(-1, N)
+        x2 = _c(x).reshape(-1, K)
+        R = x2.shape[0]
+        dx = dw = db = None
+        with _dev(x2):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x2)
+                _lib.check(lib.dg_skinny_linear_dgrad(_lib.ptr(dy2), _lib.fptr(_c(w)), _lib.ptr(dx), R, N, K, _lib.dt(x2),
+                                                      _lib.stream_of(x2)), "dg_skinny_linear_dgrad")
+                _account("readout", x2.element_size() * R * K + 4 * R * N)
+            if ctx.needs_input_grad[1] and not _inputs_only():
+                dw = torch.empty_like(w)
+                db = torch.empty(N, dtype=torch.float32, device=x.device) if b is not None else None
+                ws = _scratch(x2, int(lib.dg_linear_wgrad_workspace_bytes(R, N, K)), "wgrad")
+                _lib.check(lib.dg_skinny_linear_wgrad(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
+                                                      ws.numel(), R, N, K, _lib.dt(x2), _lib.stream_of(x2)),
+                           "dg_skinny_linear_wgrad")
+                _account("linear_wgrad", x2.element_size() * R * K + 4 * R * N)
+        return (None if dx is None else dx.view(x.shape)), dw, db
+
+
+def readout(x, weight, bias=None):
+    """float32 ``F.linear(x.float(), weight, bias)`` for the Generator's readouts (dim 128 -> edge / node classes)."""
+    ok = (x.is_cuda and x.dtype in _lib.DTYPES and weight.dim() == 2 and weight.shape[1] == 128 and 1 <= weight.shape[0] <= 16
+          and weight.dtype == torch.float32 and os.environ.get("DG_READOUT", "skinny") != "library")
+    if not ok:
+        return linear(x.float(), weight, bias)
+    return _Readout.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------

@@ -100,8 +100,8 @@ class Generator(_Trunk):
     def forward(self, z_e, z_n):
         node, edge = self._encode(z_e, z_n, True)
         # logits are float32 in every activation mode (they are the model's outputs and D's inputs)
-        node_sample = dgf.linear(node.float(), self.readout_n.weight, self.readout_n.bias)
-        edge_sample = dgf.linear(edge.float(), self.readout_e.weight, self.readout_e.bias)
+        node_sample = dgf.readout(node, self.readout_n.weight, self.readout_n.bias)
+        edge_sample = dgf.readout(edge, self.readout_e.weight, self.readout_e.bias)
         return node, edge, node_sample, edge_sample
 
 

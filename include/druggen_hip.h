@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 211            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 212            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -337,6 +337,18 @@ int dg_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_av
 int dg_adamw_flat_devstep(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                           float lr, float beta1, float beta2, float eps, float weight_decay,
                           int* step_counter, dg_stream_t stream);
+
+/* Skinny readout: nn.Linear(128 -> N), N <= 16, over edge / node rows (reference models.py:67-68,100-101: readout_e,
+ * readout_n).  x [R,128] in the activation dtype (`dtype`), w [N,128], b [N] or NULL, y [R,N] float32 (the logits are
+ * float32 in every activation mode); _dgrad: dx [R,128] (activation dtype) = dy [R,N] (float32) . w.  The weight
+ * gradient is dg_linear_wgrad's N <= 16 variant.                                                                     */
+int dg_skinny_linear_fwd(const void* x, const float* w, const float* b, float* y, int64_t R, int N, int K, int dtype,
+                         dg_stream_t stream);
+int dg_skinny_linear_dgrad(const float* dy, const float* w, void* dx, int64_t R, int N, int K, int dtype,
+                           dg_stream_t stream);
+/* dw [N,K], db [N] (nullable) from float32 dy [R,N] and x [R,K] of `dtype`; workspace as for dg_linear_wgrad. */
+int dg_skinny_linear_wgrad(const float* dy, const void* x, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                           int64_t R, int N, int K, int dtype, dg_stream_t stream);
 
 /* dg_argmax_decode: reference inference.py:197-198 `torch.max(x, -1)[1]` on logits
  * [rows, E] -> uint8 labels [rows] (first maximum), so only bytes cross PCIe.      */

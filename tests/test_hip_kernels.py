@@ -104,6 +104,36 @@ def test_attn_core_backward_adds_an_outside_adjoint_of_e(B, N, C, dtype):
     assert _rel(f2[3], (p2[3].double() + ae.double()).cpu()) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,N", [((3, 9, 9, 128), 5), ((2, 45, 128), 13), ((1, 7, 7, 128), 1), ((2, 20, 20, 128), 16), ((1, 1, 128), 10)])
+def test_skinny_readout_matches_linear_on_float32_logits(shape, N, dtype):
+    """dgf.readout (Generator.readout_e / readout_n, reference models.py:67-68,100-101): float32 logits from float32 or
+    bf16 activations in one streaming kernel; input / weight / bias gradients against autograd of
+    F.linear(x.float(), w, b) on the same (already rounded) activations."""
+    from druggen_amd import functional as dgf
+    x0 = _gen(shape, 1).to(dtype)
+    w0, b0 = _gen((N, 128), 2) * 0.2, _gen((N,), 3)
+    dy = _gen(shape[:-1] + (N,), 4)
+    xr, wr, br = x0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    y_ref = torch.nn.functional.linear(xr, wr, br)
+    g_ref = torch.autograd.grad(y_ref, [xr, wr, br], dy)
+    xd = x0.cuda().requires_grad_(True)
+    wd, bd = w0.float().cuda().requires_grad_(True), b0.float().cuda().requires_grad_(True)
+    y = dgf.readout(xd, wd, bd)
+    assert y.dtype == torch.float32 and type(y.grad_fn).__name__.startswith("_Readout")
+    assert _rel(y, y_ref) < TOL
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], dy.float().cuda())
+    assert gx.dtype == dtype
+    assert _rel(gx, g_ref[0]) < (TOL if dtype == torch.float32 else 4e-3)      # dx is stored in the activation dtype
+    assert _rel(gw, g_ref[1]) < TOL and _rel(gb, g_ref[2]) < TOL
+    # no bias, and a graph that is differentiated again (composite fallback)
+    y2 = dgf.readout(xd, wd)
+    assert _rel(y2, torch.nn.functional.linear(xr, wr)) < TOL
+    (g1,) = torch.autograd.grad(y2, [xd], dy.float().cuda(), create_graph=True)
+    (g2,) = torch.autograd.grad((g1.float() ** 2).sum(), [wd])
+    assert torch.isfinite(g2).all()
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
