@@ -1,43 +1,29 @@
 #!/usr/bin/env python
-"""Time the bf16 feed-forward kernels (fused vs unfused) at a given number of rows; also the target of PMC passes.
-    python scripts/ffn_probe.py [B=2048] [reps=5]"""
-import os
-import sys
-import time
-
-import torch
-
+"""Fused bf16 feed-forward (dg_ffn_ln_fwd_bf16 / _bwd_bf16) at configs[2] size: time per launch."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from druggen_amd import _lib, functional as dgf   # noqa: E402
+import torch
+from druggen_amd import functional as dgf
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-R = B * 45 * 45
-g = torch.Generator(device="cuda").manual_seed(0)
-x = (torch.randn(R, 128, device="cuda", generator=g)).to(torch.bfloat16).requires_grad_(True)
-dy = (torch.randn(R, 128, device="cuda", generator=g)).to(torch.bfloat16)
-ps = [(torch.randn(384, 128, device="cuda", generator=g) * 0.1).requires_grad_(True), torch.zeros(384, device="cuda").requires_grad_(True),
-      (torch.randn(128, 384, device="cuda", generator=g) * 0.06).requires_grad_(True), torch.zeros(128, device="cuda").requires_grad_(True),
-      torch.ones(128, device="cuda").requires_grad_(True), torch.zeros(128, device="cuda").requires_grad_(True)]
-
-
-def timed(fn, what, nbytes):
-    fn()
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048 * 45 * 45
+torch.manual_seed(0)
+dev = "cuda"
+x = torch.randn(R, 128, device=dev).bfloat16().requires_grad_(True)
+w1 = (torch.randn(384, 128, device=dev) * 0.1).requires_grad_(True); b1 = (torch.randn(384, device=dev) * 0.1).requires_grad_(True)
+w2 = (torch.randn(128, 384, device=dev) * 0.06).requires_grad_(True); b2 = (torch.randn(128, device=dev) * 0.1).requires_grad_(True)
+g = (torch.rand(128, device=dev) + 0.5).requires_grad_(True); be = (torch.randn(128, device=dev) * 0.1).requires_grad_(True)
+dy = torch.randn(R, 128, device=dev).bfloat16()
+def timeit(fn, n=10):
+    for _ in range(2): fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    us = (time.perf_counter() - t0) / reps * 1e6
-    print(f"{what:44s} {us:9.1f} us   {nbytes / us / 1e6:6.2f} TB/s algorithmic")
-
-
-for mode in ("fused", "unfused"):
-    os.environ["DG_FFN_BF16"] = mode
-    y = dgf.ffn_ln(x, *ps, 1e-5)
-    timed(lambda: dgf.ffn_ln(x, *ps, 1e-5), f"{mode} forward (saves for backward)", 2 * R * 128 * 3)
-    with torch.no_grad():
-        timed(lambda: dgf.ffn_ln(x, *ps, 1e-5), f"{mode} forward (no_grad)", 2 * R * 128 * 2)
-    timed(lambda: torch.autograd.grad(y, [x], dy, retain_graph=True), f"{mode} backward, dx only", 2 * R * 128 * 4)
-    timed(lambda: torch.autograd.grad(y, [x] + ps, dy, retain_graph=True), f"{mode} backward, dx + weights", 2 * R * 128 * 8)
-_lib.prof_reset()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    for _ in range(n): fn()
+    e[1].record(); torch.cuda.synchronize()
+    return e[0].elapsed_time(e[1]) / n * 1e3
+with torch.no_grad():
+    t_f = timeit(lambda: dgf.ffn_ln(x, w1, b1, w2, b2, g, be, 1e-5))
+y = dgf.ffn_ln(x, w1, b1, w2, b2, g, be, 1e-5)
+t_dx = timeit(lambda: torch.autograd.grad(y, [x], dy, retain_graph=True))
+t_all = timeit(lambda: torch.autograd.grad(y, [x, w1, b1, w2, b2, g, be], dy, retain_graph=True))
+print(f"ffn bf16 R={R}: forward (no save) {t_f:7.1f} us   backward dx only {t_dx:7.1f} us   backward all {t_all:7.1f} us")
