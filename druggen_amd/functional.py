@@ -693,20 +693,27 @@ class _FFNLN(Function):
         lib = _lib.load()
         dev = x2.device
         adt, code, es = x2.dtype, _lib.dt(x2), x2.element_size()
+        # no input needs a gradient (e.g. the Generator's forward inside the D step): nothing is kept for a backward --
+        # no pre-LayerNorm sum (one [R,C] write pass) and no ReLU bit mask
+        keep = any(ctx.needs_input_grad)
         y = torch.empty(R, C, dtype=adt, device=dev)
         h = torch.empty(R, H, dtype=adt, device=dev)
-        pre = torch.empty(R, C, dtype=adt, device=dev)
+        pre = torch.empty(R, C, dtype=adt, device=dev) if keep else None
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
-        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev)
+        bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev) if keep else None
         with _dev(x2):
             _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), packed_weight(w1, 0, adt).data_ptr(), _lib.fptr(_c(b1)),
                                               packed_weight(w2, 0, adt).data_ptr(), _lib.fptr(_c(b2)), _lib.fptr(_c(gamma)),
-                                              _lib.fptr(_c(beta)), _lib.ptr(y), _lib.ptr(h), bits.data_ptr(),
+                                              _lib.fptr(_c(beta)), _lib.ptr(y), _lib.ptr(h),
+                                              None if bits is None else bits.data_ptr(),
                                               _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
                                               _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
         _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
-        _account(_gemm_key(R, H, C), es * R * (H + 3 * C), 2 * R * C * H)
+        _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H)
+        if not keep:
+            ctx.mark_non_differentiable(mean, rstd)
+            return y.view(x.shape), None, mean, rstd
         ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits)
         ctx.eps = eps
         ctx.set_materialize_grads(False)
@@ -931,7 +938,7 @@ def ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5, want_handle: bool 
         y = _FFNLNFusedBF16.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
     else:
         y, pre, mean, rstd = _FFNLN.apply(x, w1, b1, w2, b2, gamma, beta, float(eps))
-        if want_handle and x.dtype == torch.float32 and pre.requires_grad:
+        if want_handle and x.dtype == torch.float32 and pre is not None and pre.requires_grad:
             handle = LNHandle(pre, mean, rstd, gamma, beta)
     return (y, handle) if want_handle else y
 
@@ -1024,13 +1031,16 @@ class _AttnBlock(Function):
             _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
                                             _lib.ptr(o), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_fwd")
         _account("attn_fwd", q.element_size() * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
-        x2, mean3, rstd3, pre3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3),
-                                          want_pre=True)
+        # no input needs a gradient (the Generator's forward inside the D step): the pre-LayerNorm sums are not written
+        keep = any(ctx.needs_input_grad)
+        r3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3), want_pre=keep)
+        x2, mean3, rstd3, pre3 = r3 if keep else (*r3, None)
         outs = [x2.view(B, N, C)]
         saved = [x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3]
+        pre4 = None
         if need_edge:
-            y2, mean4, rstd4, pre4 = row_gemm(s, pw(woe, 0), C, C, bias=boe, residual=yf,
-                                              ln=(_c(g4), _c(b4), eps4), want_pre=True)
+            r4 = row_gemm(s, pw(woe, 0), C, C, bias=boe, residual=yf, ln=(_c(g4), _c(b4), eps4), want_pre=keep)
+            y2, mean4, rstd4, pre4 = r4 if keep else (*r4, None)
             outs.append(y2.view(B, N, N, C))
             saved += [mean4, rstd4, pre4]
         ctx.has_prev = ppre is not None
