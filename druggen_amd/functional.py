@@ -612,12 +612,13 @@ def _fusable(x, w):
     return x.is_cuda and x.dtype in _lib.DTYPES and row_gemm_supported(K, N)
 
 
-def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None):
-    """LayerNorm backward over rows of the saved pre-LN sum -> (dz [+ dz_add], dgamma, dbeta)."""
+def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None, want_affine=True):
+    """LayerNorm backward over rows of the saved pre-LN sum -> (dz [+ dz_add], dgamma, dbeta).  ``want_affine`` False
+    (input-gradient-only passes: loss.py:32-39, the D pass of the G step): no reduction launch for dgamma / dbeta."""
     R, N = pre.shape
     lib = _lib.load()
     dz = torch.empty_like(pre)
-    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+    dgamma, dbeta = (torch.empty_like(gamma), torch.empty_like(gamma)) if want_affine else (None, None)
     with _dev(pre):
         ws, _ = _workspace(pre, R, N)
         _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(pre), None, _lib.fptr(_c(gamma)), _lib.ptr(mean),
@@ -760,7 +761,7 @@ class _FFNLNBwd(Function):
         else:
             dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
             dz = torch.empty(R, C, dtype=adt, device=dev)
-            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+            dgamma, dbeta = (torch.empty_like(gamma), torch.empty_like(gamma)) if want_w else (None, None)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
             dw1 = torch.empty_like(w1)
@@ -1141,12 +1142,12 @@ class _AttnBlockBwd(Function):
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         dx2f = _c(cast(dx2)).reshape(-1, C)
         cadd = lambda t: None if t is None else _c(cast(t)).reshape(-1, C)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3))
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3), want_affine=wants_w)
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
             dy2f = _c(cast(dy2)).reshape(-1, C)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4))
+            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w)
             ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
@@ -1343,13 +1344,13 @@ class _AttnBlockFused(Function):
         x1f = _c(x1).reshape(-1, C)
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C))
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C), want_affine=wants_w)
         do = row_gemm(dz3, pw(won, 1), C, C)
         dz4 = dg4 = db4 = None
         if need_edge:
             if dy2 is None:
                 dy2 = torch.zeros_like(pre4)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C))
+            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C), want_affine=wants_w)
         lib = _lib.load()
         dy = torch.empty_like(y)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
