@@ -26,6 +26,7 @@ namespace dg {
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract);
 int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
 size_t row_gemm_f32_mask_words(int64_t R, int K, int N);
+int row_gemm_f32_pack_batch(const void* table, int n, int max_rows_cols, dg_stream_t stream);
 size_t row_gemm_f32_ln_bwd_workspace_bytes();
 int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t R, int K, const float* residual,
                         const float* pre, const float* mean, const float* rstd, const float* gamma, float* dgamma,
@@ -306,4 +307,10 @@ extern "C" int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, i
     return row_gemm_f32_ln_bwd(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(dz), R, K,
                                static_cast<const float*>(residual), static_cast<const float*>(ln_pre), ln_mean, ln_rstd,
                                ln_gamma, dgamma, dbeta, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream_) {
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: float32 packs only");
+    if (max_dim < 1 || max_dim > 4096) return fail(DG_E_SHAPE, "dg_row_gemm_pack_batch: max_dim %d", max_dim);
+    return row_gemm_f32_pack_batch(table, n, max_dim, stream_);
 }

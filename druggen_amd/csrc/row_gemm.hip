@@ -548,10 +548,10 @@ __device__ __forceinline__ void split_write_h3(const float4 (&set)[PFN], char* p
 // packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs] (one scale
 // per output column over the whole contraction).  One 512-thread workgroup per (32-column slab, 128-wide k
 // chunk): thread = (k-step, lane) keeps its 8 values in registers while the column maxima are reduced through LDS.
-__global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows,
-                                                             int cols, int mode, int n_tiles) {
+__device__ __forceinline__ void pack_weight_h3_block(const float* __restrict__ w, f16x8* __restrict__ p, int rows, int cols,
+                                                     int mode, int n_tiles, int t, int kcb, int kchunks) {
     __shared__ unsigned part[16][32];
-    const int t = blockIdx.x, kcb = blockIdx.y, kchunks = gridDim.y, k_steps = 8 * kchunks;
+    const int k_steps = 8 * kchunks;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int c = lane & 31, n = 32 * t + c;
     const int n_out = mode == 0 ? rows : cols, kdim = mode == 0 ? cols : rows;
@@ -586,6 +586,22 @@ __global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __rest
     p[(slot * 2 + 1) * 64 + lane] = lo;
     if (kcb == 0 && ks == 0 && lane < 32)
         reinterpret_cast<float*>(p + static_cast<size_t>(n_tiles) * k_steps * 2 * 64)[n] = inv_scale_of(e);
+}
+__global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows,
+                                                             int cols, int mode, int n_tiles) {
+    pack_weight_h3_block(w, p, rows, cols, mode, n_tiles, blockIdx.x, blockIdx.y, gridDim.y);
+}
+// Every weight of a network in ONE launch (after an optimizer step): blockIdx.z walks a device table of
+// { w, packed, rows, cols, mode } (int64 x 5); blocks outside an entry's (slab, k-chunk) grid leave at once.
+__global__ __launch_bounds__(512) void pack_weight_h3_batch_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 5 * static_cast<size_t>(blockIdx.z);
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    f16x8* p = reinterpret_cast<f16x8*>(e[1]);
+    const int rows = static_cast<int>(e[2]), cols = static_cast<int>(e[3]), mode = static_cast<int>(e[4]);
+    const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
+    const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
+    if (static_cast<int>(blockIdx.x) >= nt || static_cast<int>(blockIdx.y) >= kc) return;      // block-uniform
+    pack_weight_h3_block(w, p, rows, cols, mode, nt, blockIdx.x, blockIdx.y, kc);
 }
 
 // exact three-way split of a float4 into bf16 planes by truncation: h = top 16 bits of x,
@@ -1428,6 +1444,16 @@ int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mod
     hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), w,
                        packed, rows, cols, mode, nt, kc);
     return check_launch("dg_row_gemm_pack");
+}
+
+int row_gemm_f32_pack_batch(const void* table, int n, int max_rows_cols, dg_stream_t stream_) {
+    if (!table) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: null pointer");
+    if (n < 1) return 0;
+    if (!use_x6()) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: needs the fp16 hi+lo row GEMM (DG_ROW_GEMM=mfma32 is set)");
+    const int nt = (max_rows_cols + 31) / 32, kc = (max_rows_cols + 127) / 128;
+    hipLaunchKernelGGL(pack_weight_h3_batch_kernel, dim3(nt, kc, n), dim3(512), 0, static_cast<hipStream_t>(stream_),
+                       static_cast<const long long*>(table));
+    return check_launch("dg_row_gemm_pack_batch");
 }
 
 size_t row_gemm_f32_mask_words(int64_t R, int K, int N) {

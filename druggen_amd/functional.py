@@ -536,6 +536,47 @@ def packed_weight(w, mode: int, dtype=torch.float32):
     return packed
 
 
+_repack_tables = {}
+
+
+def repack_params(params) -> int:
+    """Re-pack every cached float32 pack of ``params`` in ONE launch (dg_row_gemm_pack_batch) -- called by the
+    optimizer right after it changed them, instead of ~110 single pack launches at their next uses.  Entries that are not
+    refreshed here (other dtypes, stream capture, first use) take the lazy path in ``packed_weight``.  Returns the number
+    of packs refreshed."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return 0      # the device table is built with a host -> device copy
+    if os.environ.get("DG_PACK", "batch") != "batch":
+        return 0
+    ids = {id(p) for p in params}
+    entries = []
+    for key, hit in _pack_cache.items():
+        if key[0] in ids and key[2] == torch.float32:
+            w = hit[0]()
+            if w is not None and w.is_cuda and w.is_contiguous() and hit[3] == w.data_ptr():
+                entries.append((key, w, hit[2]))
+    if len(entries) < 2:
+        return 0
+    dev = entries[0][1].device
+    entries = [e for e in entries if e[1].device == dev]
+    sig = (dev, tuple(k for k, _, _ in entries), tuple(p.data_ptr() for _, _, p in entries))
+    tab = _repack_tables.get(sig)
+    if tab is None:
+        if len(_repack_tables) > 16:
+            _repack_tables.clear()
+        rows = [[w.data_ptr(), packed.data_ptr(), w.shape[0], w.shape[1], key[1]] for key, w, packed in entries]
+        tab = torch.tensor(rows, dtype=torch.int64, device=dev)
+        _repack_tables[sig] = tab
+    lib = _lib.load()
+    w0 = entries[0][1]
+    with _dev(w0):
+        _lib.check(lib.dg_row_gemm_pack_batch(tab.data_ptr(), len(entries), max(max(w.shape) for _, w, _ in entries),
+                                              _lib.DTYPES[torch.float32], _lib.stream_of(w0)), "dg_row_gemm_pack_batch")
+    for key, w, packed in entries:
+        _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr(), _weights_epoch)
+    return len(entries)
+
+
 def row_gemm_supported(K: int, N: int) -> bool:
     return (K == 128 and N in (128, 384)) or (K == 384 and N == 128)
 

@@ -15,7 +15,7 @@ from typing import Iterable, List, Optional
 import torch
 
 from . import _lib
-from .functional import _dev
+from .functional import _dev, repack_params
 
 __all__ = ["FlatAdamW"]
 
@@ -101,3 +101,4 @@ class FlatAdamW:
         # (only THESE parameters go stale: a global epoch bump here made every step re-pack the other network's
         # unchanged weights too -- half of the ~230 pack launches per step)
         torch.autograd.graph.increment_version([self.params[i] for i in self._live])
+        repack_params(self.params)      # their cached GEMM packs, in one launch

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 212            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 213            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -189,6 +189,10 @@ int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* d
  * N == 128, writes mean/rstd [R] and, if pre_ln != NULL, the pre-LayerNorm sum.   */
 size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype);
 int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols, int mode, int dtype, dg_stream_t stream);
+/* Many packs in one launch (after an optimizer step every weight of the network is stale at once): `table` is a DEVICE
+ * array of n entries { const float* w; void* packed; int64 rows; int64 cols; int64 mode } (5 x int64 each), max_dim >=
+ * every rows / cols.  float32 packs only.                                                                            */
+int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream);
 size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype);
 int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N,
                 const float* bias, int relu, unsigned* relu_bits_out, const unsigned* mask_bits,

@@ -134,6 +134,30 @@ def test_skinny_readout_matches_linear_on_float32_logits(shape, N, dtype):
     assert torch.isfinite(g2).all()
 
 
+def test_batched_repack_equals_single_packs():
+    """dg_row_gemm_pack_batch (one launch for all stale packs of an optimizer's parameters) writes byte-for-byte what
+    the single pack launches write, for every shape / mode of the step, and leaves other parameters' packs alone."""
+    from druggen_amd import functional as dgf
+    torch.manual_seed(0)
+    ws = [torch.randn(128, 128, device="cuda"), torch.randn(384, 128, device="cuda"), torch.randn(128, 384, device="cuda"),
+          torch.randn(128, 128, device="cuda")]
+    other = torch.randn(128, 128, device="cuda")
+    packs = [(w, m, dgf.packed_weight(w, m)) for w in ws for m in (0, 1)]
+    keep = dgf.packed_weight(other, 0)
+    keep0 = keep.clone()
+    for w in ws:
+        w.mul_(1.5).add_(0.01)                      # an "optimizer step": versions move
+    n = dgf.repack_params(ws)
+    assert n == len(packs)
+    for w, m, p in packs:
+        again = dgf.packed_weight(w, m)
+        assert again.data_ptr() == p.data_ptr()       # cache hit: refreshed in place by the batched launch
+        dgf._pack_cache.pop((id(w), m, torch.float32))
+        single = dgf.packed_weight(w, m)              # a fresh single pack of the same weight
+        assert torch.equal(single, p)
+    assert torch.equal(keep, keep0)
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
