@@ -41,8 +41,9 @@ def _accepts_edge_parts(discriminator) -> bool:
 
 
 def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, mol_annot, batch_size, device,
-                       lambda_gp, *, eps=None, generator_outputs=None):
-    """Reference loss.py:52-72 -> (node, edge, d_loss).
+                       lambda_gp, *, eps=None, generator_outputs=None, return_terms=False):
+    """Reference loss.py:52-72 -> (node, edge, d_loss); with ``return_terms`` additionally the two summands
+    (prediction_fake + prediction_real, lambda_gp * gp) whose graphs share nothing but the parameters.
 
     The generator output only enters detached, so its forward runs without
     recording a graph (the reference records one it never uses).  ``generator_outputs``
@@ -70,7 +71,10 @@ def discriminator_loss(generator, discriminator, drug_adj, drug_annot, mol_adj, 
         prediction_real = -torch.mean(discriminator(drug_adj, drug_annot))
         prediction_fake = torch.mean(discriminator(edge_sample, node_sample))
     gp = gradient_penalty(discriminator, drug_annot, drug_adj, node_sample, edge_sample, batch_size, device, eps=eps)
-    return node, edge, prediction_fake + prediction_real + lambda_gp * gp
+    main, pen = prediction_fake + prediction_real, lambda_gp * gp
+    if return_terms:
+        return node, edge, main + pen, main, pen
+    return node, edge, main + pen
 
 
 def generator_loss(generator, discriminator, mol_adj, mol_annot, batch_size, *, generator_outputs=None):

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -203,7 +205,27 @@ class GANStep:
                 and not (self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0)):
             shared = self.G(gen_edge, gen_node)
             kw["generator_outputs"] = shared
-        if not low:
+        if not low and self._d_loss_fn is discriminator_loss and os.environ.get("DG_D_BACKWARD", "split") == "split":
+            # The critic terms and the penalty share nothing but D's parameters.  One backward over their sum makes the
+            # autograd engine add the two contributions of every parameter with a kernel of its own (~140 tiny adds per
+            # step); two backward passes and ONE multi-tensor add give the same sums in the same order.
+            _, _, d_loss, main, pen = discriminator_loss(self.G, self.D, disc_edge, disc_node, gen_edge, gen_node, B, dev,
+                                                         self.lambda_gp, return_terms=True, **kw)
+            main.backward()
+            params = [p for p in self.D.parameters() if p.requires_grad]
+            g2 = torch.autograd.grad(pen, params, allow_unused=True)
+            have, add = [], []
+            for p, g in zip(params, g2):
+                if g is None:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    have.append(p.grad)
+                    add.append(g)
+            if have:
+                torch._foreach_add_(have, add)
+        elif not low:
             _, _, d_loss = self._d_loss_fn(self.G, self.D, disc_edge, disc_node, gen_edge, gen_node, B, dev,
                                            self.lambda_gp, **kw)
             d_loss.backward()
