@@ -19,7 +19,7 @@ extern "C" size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H) {
     const size_t ln = dg_ln_workspace_bytes(R, C);
     const size_t w1 = dg_linear_wgrad_workspace_bytes(R, H, C), w2 = dg_linear_wgrad_workspace_bytes(R, C, H);
     if (!ln || !w1 || !w2) return 0;
-    const size_t m = w1 > w2 ? w1 : w2;
+    const size_t m = ((w1 + 255) / 256 + (w2 + 255) / 256) * 256;      // both weight gradients' partial sums at once
     return ln > m ? ln : m;
 }
 
@@ -66,6 +66,16 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
         st = dg_row_gemm(dh, w1_dgrad_packed, dx, R, H, C, nullptr, 0, nullptr, nullptr, dz, nullptr, nullptr,
                          nullptr, nullptr, nullptr, 0.f, dtype, stream);
         if (st) return st;
+    }
+    if (dw2 && dw1) {      // two split-K kernels into separate halves of the workspace, ONE reduce launch
+        const size_t w2b = (dg_linear_wgrad_workspace_bytes(R, C, H) + 255) / 256 * 256;
+        dg_linear_wgrad_batch_begin();
+        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, w2b, R, C, H, dtype, stream);
+        if (!st)
+            st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, static_cast<char*>(workspace) + w2b, workspace_bytes - w2b, R, H, C,
+                                 dtype, stream);
+        const int st2 = dg_linear_wgrad_batch_end(stream);
+        return st ? st : st2;
     }
     if (dw2) {
         st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, workspace_bytes, R, C, H, dtype, stream);

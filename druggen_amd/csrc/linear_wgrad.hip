@@ -510,6 +510,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The fixed-order reduce of up to 8 weight gradients in ONE launch (the projections of an attention block, fc1 + fc2 of
+// a feed-forward block: their split-K kernels run back to back into separate workspaces): blockIdx.y = entry.
+struct RedEntry {
+    const float* part;
+    const float* part_b;
+    float* out;
+    float* out_b;
+    long long n4, n4_b;
+    int S, blocks_a, blocks;
+};
+struct RedBatch {
+    RedEntry e[8];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const RedBatch b) {
+    __shared__ float4 red[16][17];
+    const RedEntry& en = b.e[blockIdx.y];
+    if (static_cast<int>(blockIdx.x) >= en.blocks) return;      // block-uniform
+    const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+    int64_t blk = blockIdx.x;
+    const float* part = en.part;
+    float* out = en.out;
+    long long n4 = en.n4;
+    if (blk >= en.blocks_a) {
+        blk -= en.blocks_a;
+        part = en.part_b;
+        n4 = en.n4_b;
+        out = en.out_b;
+    }
+    const int64_t i = blk * 16 + c;
+    float4 s = f4(0.f);
+    if (i < n4) {
+#pragma unroll 8
+        for (int p = g; p < en.S; p += 16) s += ld4(part + (static_cast<size_t>(p) * n4 + i) * 4);
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+        float4 t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][c];
+        st4(out + i * 4, t);
+    }
+}
+
 // ---- skinny outputs: N <= 16 rows of dW (readout_e / readout_n, reference models.py:67-68) -----
 // dW[n][k] = sum_r dy[r][n] x[r][k] with N = 5 / 13: no MFMA tile to fill, the kernel is a coalesced
 // stream over x (512 B rows) with N float4 accumulators per lane; dy[r][.] is a broadcast load.
@@ -656,6 +700,29 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
+// ---- deferred reduces: between dg_linear_wgrad_batch_begin() and _end() a (non-skinny) dg_linear_wgrad only runs its
+// split-K kernel and records its reduce; _end() runs them all in one launch.  Every call of a batch needs its OWN
+// workspace.  Thread-local: one batch per host thread.
+static thread_local bool g_batch_on = false;
+static thread_local int g_batch_n = 0;
+static thread_local RedBatch g_batch;
+
+extern "C" int dg_linear_wgrad_batch_begin(void) {
+    g_batch_on = true;
+    g_batch_n = 0;
+    return 0;
+}
+extern "C" int dg_linear_wgrad_batch_end(dg_stream_t stream_) {
+    const int n = g_batch_n;
+    g_batch_on = false;
+    g_batch_n = 0;
+    if (n == 0) return 0;
+    int maxb = 0;
+    for (int i = 0; i < n; ++i) maxb = g_batch.e[i].blocks > maxb ? g_batch.e[i].blocks : maxb;
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(maxb, n), dim3(256), 0, static_cast<hipStream_t>(stream_), g_batch);
+    return check_launch("dg_linear_wgrad_batch_end");
+}
+
 // N <= 16 output rows: dy (float32 or bf16) and x (float32 or bf16) may differ -- the readout's logits are float32 in
 // the bf16 configuration too
 static int skinny_wgrad(const void* dy_, bool dy_f32, const void* x_, bool x_bf, float* dw, float* db, void* workspace,
@@ -768,6 +835,12 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
 #undef LAUNCH
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;
     const int blocks_w = static_cast<int>((n4 + 15) / 16), blocks_b = db ? (N / 4 + 15) / 16 : 0;
+    if (g_batch_on && g_batch_n < 8) {      // the reduce joins the batch (dg_linear_wgrad_batch_end)
+        RedEntry& en = g_batch.e[g_batch_n++];
+        en.part = part_w; en.part_b = part_b; en.out = dw; en.out_b = db;
+        en.n4 = n4; en.n4_b = N / 4; en.S = S; en.blocks_a = blocks_w; en.blocks = blocks_w + blocks_b;
+        return check_launch("dg_linear_wgrad");
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks_w + blocks_b), dim3(256), 0, stream, part_w, S, n4, dw, blocks_w,
                        part_b, static_cast<int64_t>(N / 4), db);
     return check_launch("dg_linear_wgrad");

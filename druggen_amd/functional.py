@@ -331,9 +331,36 @@ def inputs_only_backward():
         _flags.inputs_only -= 1
 
 
-def _wgrad(dy2, x2, want_bias, dy_mask=None):
+def _wgrad_many(items):
+    """[(dy2, x2, want_bias), ...] -> [(dW, db), ...]: the split-K kernels of up to 8 weight gradients run back to back
+    into separate workspaces and ONE launch reduces them all (dg_linear_wgrad_batch_begin / _end) -- the six projections
+    of an attention block used to cost six reduce launches.  Shapes outside the MFMA kernel take their usual path."""
+    lib = _lib.load()
+    ref = items[0][0]
+    ok = (ref.is_cuda and len(items) <= 8 and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
+          and all(dy.dtype == x.dtype and dy.shape[1] > 16 and x.shape[1] > 16 for dy, x, _ in items))
+    needs = [int(lib.dg_linear_wgrad_workspace_bytes(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _ in items] if ok else []
+    if not ok or any(n == 0 for n in needs):
+        return [_wgrad(dy, x, b) for dy, x, b in items]
+    offs, total = [], 0
+    for n in needs:
+        offs.append(total)
+        total += (n + 255) // 256 * 256
+    out = []
+    with _dev(ref):
+        ws = _scratch(ref, total, "wgrad_batch")
+        _lib.check(lib.dg_linear_wgrad_batch_begin(), "dg_linear_wgrad_batch_begin")
+        try:
+            for (dy, x, b), off, n in zip(items, offs, needs):
+                out.append(_wgrad(dy, x, b, ws=ws[off:off + n]))
+        finally:
+            _lib.check(lib.dg_linear_wgrad_batch_end(_lib.stream_of(ref)), "dg_linear_wgrad_batch_end")
+    return out
+
+
+def _wgrad(dy2, x2, want_bias, dy_mask=None, ws=None):
     """dW [N,K] = dy2^T x2, db [N] = column sums of dy2 (or None); float32 results for float32 or
-    bfloat16 operands."""
+    bfloat16 operands.  ``ws``: a private workspace (calls inside ``_wgrad_many``)."""
     if dy2.dtype != x2.dtype:      # e.g. fp32 logit gradients against bf16 activations (readout layers)
         dy2 = dy2.to(x2.dtype)
     R, N = dy2.shape
@@ -353,7 +380,8 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None):
     dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
     db = torch.empty(N, dtype=torch.float32, device=dy2.device) if want_bias else None
     with _dev(dy2):
-        ws = _scratch(dy2, need, "wgrad")
+        if ws is None:
+            ws = _scratch(dy2, need, "wgrad")
         _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
                                        ws.numel(), R, N, K, _lib.dt(dy2), _lib.stream_of(dy2)), "dg_linear_wgrad")
     _account("linear_wgrad", dy2.element_size() * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
@@ -1213,13 +1241,13 @@ class _AttnBlockBwd(Function):
             dx1 = row_gemm(dvf, pw(wv, 1), C, C, residual=t).view(x1.shape)
         gw = [None] * 12
         if wants_w:
-            gw[0], gw[1] = _wgrad(dqf, x1f, True)
-            gw[2], gw[3] = _wgrad(dkf, x1f, True)
-            gw[4], gw[5] = _wgrad(dvf, x1f, True)
-            gw[6], gw[7] = _wgrad(def_, yf, True)
+            items = [(dqf, x1f, True), (dkf, x1f, True), (dvf, x1f, True), (def_, yf, True), (dz3, o, True)]
             if need_edge:
-                gw[8], gw[9] = _wgrad(dz4, s, True)
-            gw[10], gw[11] = _wgrad(dz3, o, True)
+                items.append((dz4, s, True))
+            res = _wgrad_many(items)
+            (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]), (gw[6], gw[7]), (gw[10], gw[11]) = res[:5]
+            if need_edge:
+                gw[8], gw[9] = res[5]
         ctx.save_for_backward(x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3,
                               mean4, rstd4, pre4, dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de)
         ctx.cfg = (alpha, need_edge, (B, N, C), dx2.shape, None if dy2 is None else dy2.shape)
@@ -1420,12 +1448,10 @@ class _AttnBlockFused(Function):
             dx1 = row_gemm(dv, pw(wv, 1), C, C, residual=t).view(x1.shape)
         gw = [None] * 12
         if wants_w:
-            gw[0], gw[1] = _wgrad(dq, x1f, True)
-            gw[2], gw[3] = _wgrad(dk, x1f, True)
-            gw[4], gw[5] = _wgrad(dv, x1f, True)
+            (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]), (gw[10], gw[11]) = _wgrad_many(
+                [(dq, x1f, True), (dk, x1f, True), (dv, x1f, True), (dz3, o, True)])
             gw[6], gw[7] = dwe, dbe
             gw[8], gw[9] = dwoe, dboe
-            gw[10], gw[11] = _wgrad(dz3, o, True)
         else:
             dg3 = db3 = dg4 = db4 = None
         return (dx1, (dy if ctx.needs_input_grad[1] else None), *gw, dg3, db3, dg4, db4, None, None, None, None)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 213            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 214            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -166,6 +166,13 @@ size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K);
 int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* dw, float* db,
                     void* workspace, size_t workspace_bytes,
                     int64_t R, int N, int K, int dtype, dg_stream_t stream);
+
+/* Deferred reduces: between _batch_begin() and _batch_end() every dg_linear_wgrad call with N > 16 only runs its
+ * split-K kernel and records its fixed-order reduce; _batch_end() runs up to 8 recorded reduces in ONE launch (a 9th
+ * call reduces at once).  Each call of a batch needs its OWN workspace; dw / db are complete after _batch_end().  The
+ * state is per host thread.  (The six projections of an attention block, fc1 + fc2 of a feed-forward block.)      */
+int dg_linear_wgrad_batch_begin(void);
+int dg_linear_wgrad_batch_end(dg_stream_t stream);
 
 /* ---- fp32-MFMA row GEMM with fused epilogues ------------------------------------
  * The dense layers applied to every edge / node row: MHA projections
