@@ -880,8 +880,8 @@ class _FFNLNBwd(Function):
         zbar, dybar, gbar = _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, ubar)
         gw1 = gw2 = None
         if not _inputs_only():
-            gw1, _ = _wgrad(dh, t, False)                                  # ((u W2)*m)^T t
-            gw2, _ = _wgrad(dz, vbar, False)                               # u^T ((t W1^T)*m)
+            (gw1, _), (gw2, _) = _wgrad_many([(dh, t, False),              # ((u W2)*m)^T t
+                                              (dz, vbar, False)])          # u^T ((t W1^T)*m)
         # dx depends on x only through the saved pre-LN sum z: its adjoint goes back to the forward
         # node (second output of _FFNLN), which runs ONE backward pass for both gradient sources.
         # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w
@@ -1291,13 +1291,13 @@ class _AttnBlockBwd(Function):
             z4bar, dy2bar, g4bar = _ln_bwd2_rows(pre4, g4, mean4, rstd4, dy2f, adz4)
         gW = [None] * 12
         if with_w:
-            gW[0], _ = _wgrad(dqf, t1f, False)
-            gW[2], _ = _wgrad(dkf, t1f, False)
-            gW[4], _ = _wgrad(dvf, t1f, False)
-            gW[6], _ = _wgrad(def_, tyf, False)
+            items = [(dqf, t1f, False), (dkf, t1f, False), (dvf, t1f, False), (def_, tyf, False), (dz3, gwo.view(-1, C), False)]
             if need_edge:
-                gW[8], _ = _wgrad(dz4, gws.view(-1, C), False)
-            gW[10], _ = _wgrad(dz3, gwo.view(-1, C), False)
+                items.append((dz4, gws.view(-1, C), False))
+            res = _wgrad_many(items)
+            gW[0], gW[2], gW[4], gW[6], gW[10] = (r[0] for r in res[:5])
+            if need_edge:
+                gW[8] = res[5][0]
         # The outputs depend on x1 / y only through the forward intermediates: their adjoints
         # (z3bar, z4bar at the pre-LayerNorm sums; gq, gk, gv, ge) go to the forward node.
         # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, q,k,v,e, s,o,
