@@ -59,6 +59,30 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict
     p[idx] = out;
 }
 
+// every stale bf16 pack of a network in one launch: blockIdx.y walks a device table of { w, packed, rows, cols, mode }
+__global__ void pack_bf16_batch_kernel(const long long* __restrict__ table, int mb_size) {
+    const long long* e = table + 5 * static_cast<size_t>(blockIdx.y);
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    bf16x8* p = reinterpret_cast<bf16x8*>(e[1]);
+    const int rows = static_cast<int>(e[2]), cols = static_cast<int>(e[3]), mode = static_cast<int>(e[4]);
+    const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+    const int kstep = 512 / mb_size;
+    const int MB = M / mb_size, KS = K / kstep;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= MB * KS * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % KS, mb = (idx >> 6) / KS;
+    const int m = mb * mb_size + (lane & (mb_size - 1));
+    const int k0 = ks * kstep + 8 * (mb_size == 32 ? lane >> 5 : lane >> 4);
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const float v = mode == 0 ? w[static_cast<size_t>(m) * cols + k] : w[static_cast<size_t>(k) * cols + m];
+        out[j] = static_cast<__bf16>(v);
+    }
+    p[idx] = out;
+}
+
 struct EpiB {
     const float* bias;          // [N] or null
     const unsigned* mask_bits;  // ReLU mask written by a relu launch of the same (K, N) geometry
@@ -310,7 +334,15 @@ extern "C" int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, i
 }
 
 extern "C" int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream_) {
-    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: float32 packs only");
+    if (!table) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: null pointer");
     if (max_dim < 1 || max_dim > 4096) return fail(DG_E_SHAPE, "dg_row_gemm_pack_batch: max_dim %d", max_dim);
+    if (dtype == DG_DTYPE_BF16) {      // entries must be multiples of the MFMA tile (as dg_row_gemm_pack checks one by one)
+        if (n < 1) return 0;
+        const int total = (max_dim / 32) * (max_dim / 16) * 64;
+        hipLaunchKernelGGL(pack_bf16_batch_kernel, dim3((total + 255) / 256, n), dim3(256), 0,
+                           static_cast<hipStream_t>(stream_), static_cast<const long long*>(table), 32);
+        return check_launch("dg_row_gemm_pack_batch(bf16)");
+    }
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack_batch: unknown dtype %d", dtype);
     return row_gemm_f32_pack_batch(table, n, max_dim, stream_);
 }

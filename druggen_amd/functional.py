@@ -577,17 +577,24 @@ def repack_params(params) -> int:
     if os.environ.get("DG_PACK", "batch") != "batch":
         return 0
     ids = {id(p) for p in params}
-    entries = []
-    for key, hit in _pack_cache.items():
-        if key[0] in ids and key[2] == torch.float32:
-            w = hit[0]()
-            if w is not None and w.is_cuda and w.is_contiguous() and hit[3] == w.data_ptr():
-                entries.append((key, w, hit[2]))
-    if len(entries) < 2:
-        return 0
+    total = 0
+    for dtype in (torch.float32, torch.bfloat16):
+        entries = []
+        for key, hit in _pack_cache.items():
+            if key[0] in ids and key[2] == dtype:
+                w = hit[0]()
+                if (w is not None and w.is_cuda and w.is_contiguous() and hit[3] == w.data_ptr()
+                        and (dtype == torch.float32 or (w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0))):
+                    entries.append((key, w, hit[2]))
+        if len(entries) >= 2:
+            total += _repack_entries(entries, dtype)
+    return total
+
+
+def _repack_entries(entries, dtype) -> int:
     dev = entries[0][1].device
     entries = [e for e in entries if e[1].device == dev]
-    sig = (dev, tuple(k for k, _, _ in entries), tuple(p.data_ptr() for _, _, p in entries))
+    sig = (dev, dtype, tuple(k for k, _, _ in entries), tuple(p.data_ptr() for _, _, p in entries))
     tab = _repack_tables.get(sig)
     if tab is None:
         if len(_repack_tables) > 16:
@@ -599,7 +606,7 @@ def repack_params(params) -> int:
     w0 = entries[0][1]
     with _dev(w0):
         _lib.check(lib.dg_row_gemm_pack_batch(tab.data_ptr(), len(entries), max(max(w.shape) for _, w, _ in entries),
-                                              _lib.DTYPES[torch.float32], _lib.stream_of(w0)), "dg_row_gemm_pack_batch")
+                                              _lib.DTYPES[dtype], _lib.stream_of(w0)), "dg_row_gemm_pack_batch")
     for key, w, packed in entries:
         _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr(), _weights_epoch)
     return len(entries)

@@ -198,7 +198,7 @@ size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype);
 int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols, int mode, int dtype, dg_stream_t stream);
 /* Many packs in one launch (after an optimizer step every weight of the network is stale at once): `table` is a DEVICE
  * array of n entries { const float* w; void* packed; int64 rows; int64 cols; int64 mode } (5 x int64 each), max_dim >=
- * every rows / cols.  float32 packs only.                                                                            */
+ * every rows / cols; for DG_DTYPE_BF16 every rows / cols must be a multiple of 32.                                    */
 int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream);
 size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype);
 int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N,

@@ -134,7 +134,8 @@ def test_skinny_readout_matches_linear_on_float32_logits(shape, N, dtype):
     assert torch.isfinite(g2).all()
 
 
-def test_batched_repack_equals_single_packs():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_repack_equals_single_packs(dtype):
     """dg_row_gemm_pack_batch (one launch for all stale packs of an optimizer's parameters) writes byte-for-byte what
     the single pack launches write, for every shape / mode of the step, and leaves other parameters' packs alone."""
     from druggen_amd import functional as dgf
@@ -142,18 +143,18 @@ def test_batched_repack_equals_single_packs():
     ws = [torch.randn(128, 128, device="cuda"), torch.randn(384, 128, device="cuda"), torch.randn(128, 384, device="cuda"),
           torch.randn(128, 128, device="cuda")]
     other = torch.randn(128, 128, device="cuda")
-    packs = [(w, m, dgf.packed_weight(w, m)) for w in ws for m in (0, 1)]
-    keep = dgf.packed_weight(other, 0)
+    packs = [(w, m, dgf.packed_weight(w, m, dtype)) for w in ws for m in (0, 1)]
+    keep = dgf.packed_weight(other, 0, dtype)
     keep0 = keep.clone()
     for w in ws:
         w.mul_(1.5).add_(0.01)                      # an "optimizer step": versions move
     n = dgf.repack_params(ws)
     assert n == len(packs)
     for w, m, p in packs:
-        again = dgf.packed_weight(w, m)
+        again = dgf.packed_weight(w, m, dtype)
         assert again.data_ptr() == p.data_ptr()       # cache hit: refreshed in place by the batched launch
-        dgf._pack_cache.pop((id(w), m, torch.float32))
-        single = dgf.packed_weight(w, m)              # a fresh single pack of the same weight
+        dgf._pack_cache.pop((id(w), m, dtype))
+        single = dgf.packed_weight(w, m, dtype)       # a fresh single pack of the same weight
         assert torch.equal(single, p)
     assert torch.equal(keep, keep0)
 
