@@ -19,8 +19,8 @@ extern "C" size_t dg_edge_ffn_ln_workspace_bytes(int64_t R, int C, int H) {
     const size_t ln = dg_ln_workspace_bytes(R, C);
     const size_t w1 = dg_linear_wgrad_workspace_bytes(R, H, C), w2 = dg_linear_wgrad_workspace_bytes(R, C, H);
     if (!ln || !w1 || !w2) return 0;
-    const size_t m = ((w1 + 255) / 256 + (w2 + 255) / 256) * 256;      // both weight gradients' partial sums at once
-    return ln > m ? ln : m;
+    // LayerNorm partials and both weight gradients' partial sums live side by side (one reduce launch for all three)
+    return ((ln + 255) / 256 + (w1 + 255) / 256 + (w2 + 255) / 256) * 256;
 }
 
 extern "C" int dg_edge_ffn_ln_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed,
@@ -52,24 +52,32 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
     if (workspace_bytes < dg_edge_ffn_ln_workspace_bytes(R, C, H))
         return fail(DG_E_WORKSPACE, "dg_edge_ffn_ln_bwd: workspace too small");
     int st = 0;
+    const size_t lnb = (dg_ln_workspace_bytes(R, C) + 255) / 256 * 256;
+    const bool batch = dw2 && dw1;      // LayerNorm's dgamma / dbeta and both weight gradients: one reduce launch
+    if (batch) dg_linear_wgrad_batch_begin();
     // dy == NULL: the LayerNorm backward ran in the epilogue of the GEMM that produced its output gradient
     // (dg_row_gemm_ln_bwd) and dz holds the result; dgamma / dbeta are not touched
     if (dy)
         st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
-                                    workspace_bytes, R, C, dtype, stream);
-    if (st) return st;
+                                    lnb, R, C, dtype, stream);
+    if (st) {
+        if (batch) dg_linear_wgrad_batch_end(stream);
+        return st;
+    }
+    workspace = static_cast<char*>(workspace) + lnb;
+    workspace_bytes -= lnb;
     // dh = (dz @ W2) masked by the forward's ReLU bits
     st = dg_row_gemm(dz, w2_dgrad_packed, dh, R, C, H, nullptr, 0, nullptr, relu_bits, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, 0.f, dtype, stream);
-    if (st) return st;
-    if (dx) {   // dx = dz + dh @ W1 (residual path folded into the epilogue)
+    if (!st && dx)   // dx = dz + dh @ W1 (residual path folded into the epilogue)
         st = dg_row_gemm(dh, w1_dgrad_packed, dx, R, H, C, nullptr, 0, nullptr, nullptr, dz, nullptr, nullptr,
                          nullptr, nullptr, nullptr, 0.f, dtype, stream);
-        if (st) return st;
+    if (st) {
+        if (batch) dg_linear_wgrad_batch_end(stream);
+        return st;
     }
-    if (dw2 && dw1) {      // two split-K kernels into separate halves of the workspace, ONE reduce launch
+    if (batch) {      // two split-K kernels into separate parts of the workspace
         const size_t w2b = (dg_linear_wgrad_workspace_bytes(R, C, H) + 255) / 256 * 256;
-        dg_linear_wgrad_batch_begin();
         st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, w2b, R, C, H, dtype, stream);
         if (!st)
             st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, static_cast<char*>(workspace) + w2b, workspace_bytes - w2b, R, H, C,

@@ -301,6 +301,8 @@ int ln_grid(int64_t R, int G) {
 
 }  // namespace
 
+bool reduce_batch_try_add(const float* part, int S, long long n_floats, float* out);      // linear_wgrad.hip
+
 // out_k[c] = sum_b part[b][k][c] in a fixed order (shared with the LayerNorm-backward epilogue of row_gemm.hip)
 void launch_ln_finish(const float* part, int nblocks, int K, int C, float* out0, float* out1, hipStream_t stream) {
     hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, K), dim3(1024), 0, stream, part, nblocks, K, C, out0, out1);
@@ -378,7 +380,9 @@ extern "C" int dg_ln_residual_bwd_add(const void* a, const void* r, const float*
     DG_FOR_LN(LAUNCH)
 #undef LAUNCH
 #undef LAUNCH_T
-    if (dgamma || dbeta)
+    // inside dg_linear_wgrad_batch_begin / _end the reduction joins that batch's single reduce launch (dgamma and dbeta
+    // adjacent in memory: out[2][C]); the partials must then stay untouched until _end
+    if ((dgamma || dbeta) && !(dgamma && dbeta == dgamma + C && reduce_batch_try_add(part, grid, 2 * static_cast<long long>(C), dgamma)))
         hipLaunchKernelGGL(ln_finish_kernel, dim3((C + 31) / 32, 2), dim3(1024), 0, stream, part, grid, 2, C, dgamma, dbeta);
     return check_launch("dg_ln_residual_bwd");
 }

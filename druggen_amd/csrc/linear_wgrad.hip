@@ -723,6 +723,19 @@ extern "C" int dg_linear_wgrad_batch_end(dg_stream_t stream_) {
     return check_launch("dg_linear_wgrad_batch_end");
 }
 
+// Other fixed-order partial-sum reductions (LayerNorm's dgamma / dbeta: part[S][n] -> out[n]) can ride in the same launch.
+namespace dg {
+bool reduce_batch_try_add(const float* part, int S, long long n_floats, float* out) {
+    if (!g_batch_on || g_batch_n >= 8 || (n_floats & 3)) return false;
+    RedEntry& en = g_batch.e[g_batch_n++];
+    en.part = part; en.part_b = nullptr; en.out = out; en.out_b = nullptr;
+    en.n4 = n_floats / 4; en.n4_b = 0; en.S = S;
+    en.blocks_a = static_cast<int>((en.n4 + 15) / 16);
+    en.blocks = en.blocks_a;
+    return true;
+}
+}  // namespace dg
+
 // N <= 16 output rows: dy (float32 or bf16) and x (float32 or bf16) may differ -- the readout's logits are float32 in
 // the bf16 configuration too
 static int skinny_wgrad(const void* dy_, bool dy_f32, const void* x_, bool x_bf, float* dw, float* db, void* workspace,

@@ -331,7 +331,24 @@ def inputs_only_backward():
         _flags.inputs_only -= 1
 
 
-def _wgrad_many(items):
+@contextlib.contextmanager
+def _reduce_batch(ref, on=True):
+    """dg_linear_wgrad_batch_begin / _end around a block's backward: the fixed-order reductions of its weight gradients
+    (``_wgrad_many(..., open_batch=False)``) and of its LayerNorms' dgamma / dbeta (``_ln_bwd_rows(batch_slot=i)``) run
+    as ONE launch at the end (at most 8 of them; further ones reduce at once)."""
+    if not (on and ref.is_cuda and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"):
+        yield False
+        return
+    lib = _lib.load()
+    with _dev(ref):
+        _lib.check(lib.dg_linear_wgrad_batch_begin(), "dg_linear_wgrad_batch_begin")
+        try:
+            yield True
+        finally:
+            _lib.check(lib.dg_linear_wgrad_batch_end(_lib.stream_of(ref)), "dg_linear_wgrad_batch_end")
+
+
+def _wgrad_many(items, open_batch=True):
     """[(dy2, x2, want_bias), ...] -> [(dW, db), ...]: the split-K kernels of up to 8 weight gradients run back to back
     into separate workspaces and ONE launch reduces them all (dg_linear_wgrad_batch_begin / _end) -- the six projections
     of an attention block used to cost six reduce launches.  Shapes outside the MFMA kernel take their usual path."""
@@ -349,12 +366,9 @@ def _wgrad_many(items):
     out = []
     with _dev(ref):
         ws = _scratch(ref, total, "wgrad_batch")
-        _lib.check(lib.dg_linear_wgrad_batch_begin(), "dg_linear_wgrad_batch_begin")
-        try:
+        with _reduce_batch(ref, on=open_batch):
             for (dy, x, b), off, n in zip(items, offs, needs):
                 out.append(_wgrad(dy, x, b, ws=ws[off:off + n]))
-        finally:
-            _lib.check(lib.dg_linear_wgrad_batch_end(_lib.stream_of(ref)), "dg_linear_wgrad_batch_end")
     return out
 
 
@@ -688,15 +702,21 @@ def _fusable(x, w):
     return x.is_cuda and x.dtype in _lib.DTYPES and row_gemm_supported(K, N)
 
 
-def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None, want_affine=True):
+def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None, want_affine=True, batch_slot=None):
     """LayerNorm backward over rows of the saved pre-LN sum -> (dz [+ dz_add], dgamma, dbeta).  ``want_affine`` False
-    (input-gradient-only passes: loss.py:32-39, the D pass of the G step): no reduction launch for dgamma / dbeta."""
+    (input-gradient-only passes: loss.py:32-39, the D pass of the G step): no reduction launch for dgamma / dbeta.
+    ``batch_slot`` (inside ``_reduce_batch``): the reduction joins the batch's single launch; the partial sums get a
+    workspace of their own (slot index) because they must survive until the batch ends."""
     R, N = pre.shape
     lib = _lib.load()
     dz = torch.empty_like(pre)
-    dgamma, dbeta = (torch.empty_like(gamma), torch.empty_like(gamma)) if want_affine else (None, None)
+    dgamma, dbeta = (torch.empty(2, gamma.numel(), dtype=gamma.dtype, device=pre.device).unbind(0) if want_affine
+                     else (None, None))
     with _dev(pre):
-        ws, _ = _workspace(pre, R, N)
+        if batch_slot is None:
+            ws, _ = _workspace(pre, R, N)
+        else:
+            ws = _scratch(pre, int(lib.dg_ln_workspace_bytes(R, N)), f"ln_batch{batch_slot}")
         _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(pre), None, _lib.fptr(_c(gamma)), _lib.ptr(mean),
                                               _lib.ptr(rstd), _lib.ptr(dy2), _lib.ptr(dz_add), _lib.ptr(dz),
                                               _lib.ptr(dgamma), _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, N,
@@ -837,7 +857,8 @@ class _FFNLNBwd(Function):
         else:
             dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
             dz = torch.empty(R, C, dtype=adt, device=dev)
-            dgamma, dbeta = (torch.empty_like(gamma), torch.empty_like(gamma)) if want_w else (None, None)
+            # adjacent in memory: their reduction then rides in the block's single reduce launch
+            dgamma, dbeta = torch.empty(2, gamma.numel(), dtype=gamma.dtype, device=dev).unbind(0) if want_w else (None, None)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
             dw1 = torch.empty_like(w1)
@@ -1208,9 +1229,16 @@ class _AttnBlockBwd(Function):
     pass of that node."""
 
     @staticmethod
-    def forward(ctx, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
-                mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
-                alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None):
+    def forward(ctx, *args):
+        # one reduce launch for the block: six weight gradients + two LayerNorms' dgamma / dbeta
+        wants_w = args[40]
+        with _reduce_batch(args[0], on=bool(wants_w)) as inb:
+            return _AttnBlockBwd._forward(ctx, inb, *args)
+
+    @staticmethod
+    def _forward(ctx, inb, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
+                 mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
+                 alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None):
         B, N, C = x1.shape
         adt = q.dtype
         pw = lambda w_, m_: packed_weight(w_, m_, adt)
@@ -1218,12 +1246,14 @@ class _AttnBlockBwd(Function):
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         dx2f = _c(cast(dx2)).reshape(-1, C)
         cadd = lambda t: None if t is None else _c(cast(t)).reshape(-1, C)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3), want_affine=wants_w)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3), want_affine=wants_w,
+                                     batch_slot=0 if inb else None)
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
             dy2f = _c(cast(dy2)).reshape(-1, C)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w)
+            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w,
+                                         batch_slot=1 if inb else None)
             ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
@@ -1251,7 +1281,7 @@ class _AttnBlockBwd(Function):
             items = [(dqf, x1f, True), (dkf, x1f, True), (dvf, x1f, True), (def_, yf, True), (dz3, o, True)]
             if need_edge:
                 items.append((dz4, s, True))
-            res = _wgrad_many(items)
+            res = _wgrad_many(items, open_batch=not inb)
             (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]), (gw[6], gw[7]), (gw[10], gw[11]) = res[:5]
             if need_edge:
                 gw[8], gw[9] = res[5]
@@ -1402,6 +1432,12 @@ class _AttnBlockFused(Function):
 
     @staticmethod
     def backward(ctx, dx2, dy2=None):
+        wants_w = bool(ctx.needs_input_grad[2] and not _inputs_only() and not torch.is_grad_enabled())
+        with _reduce_batch(ctx.saved_tensors[0], on=wants_w) as inb:      # one reduce launch for the block
+            return _AttnBlockFused._backward(ctx, inb, dx2, dy2)
+
+    @staticmethod
+    def _backward(ctx, inb, dx2, dy2=None):
         alpha, need_edge, (B, N, C) = ctx.cfg
         (x1, y, wq, wk, wv, we, woe, won, g3, g4, be, q, k, v, o, mean3, rstd3, pre3, mean4, rstd4,
          pre4) = ctx.saved_tensors
@@ -1420,13 +1456,15 @@ class _AttnBlockFused(Function):
         x1f = _c(x1).reshape(-1, C)
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C), want_affine=wants_w)
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C), want_affine=wants_w,
+                                     batch_slot=0 if inb else None)
         do = row_gemm(dz3, pw(won, 1), C, C)
         dz4 = dg4 = db4 = None
         if need_edge:
             if dy2 is None:
                 dy2 = torch.zeros_like(pre4)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C), want_affine=wants_w)
+            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C), want_affine=wants_w,
+                                         batch_slot=1 if inb else None)
         lib = _lib.load()
         dy = torch.empty_like(y)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
@@ -1456,7 +1494,7 @@ class _AttnBlockFused(Function):
         gw = [None] * 12
         if wants_w:
             (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]), (gw[10], gw[11]) = _wgrad_many(
-                [(dq, x1f, True), (dk, x1f, True), (dv, x1f, True), (dz3, o, True)])
+                [(dq, x1f, True), (dk, x1f, True), (dv, x1f, True), (dz3, o, True)], open_batch=not inb)
             gw[6], gw[7] = dwe, dbe
             gw[8], gw[9] = dwoe, dboe
         else:

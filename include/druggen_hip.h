@@ -170,7 +170,9 @@ int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* d
 /* Deferred reduces: between _batch_begin() and _batch_end() every dg_linear_wgrad call with N > 16 only runs its
  * split-K kernel and records its fixed-order reduce; _batch_end() runs up to 8 recorded reduces in ONE launch (a 9th
  * call reduces at once).  Each call of a batch needs its OWN workspace; dw / db are complete after _batch_end().  The
- * state is per host thread.  (The six projections of an attention block, fc1 + fc2 of a feed-forward block.)      */
+ * state is per host thread.  (The six projections of an attention block, fc1 + fc2 of a feed-forward block.)
+ * dg_ln_residual_bwd(_add) calls inside a batch whose dgamma and dbeta are adjacent (dbeta == dgamma + C) join it too:
+ * their partial sums (the workspace) must then stay untouched until _batch_end().                                  */
 int dg_linear_wgrad_batch_begin(void);
 int dg_linear_wgrad_batch_end(dg_stream_t stream);
 
