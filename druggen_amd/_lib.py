@@ -51,6 +51,7 @@ SIGNATURES = {
     "dg_row_gemm_pack_batch": (c_int, [_P, c_int, c_int, c_int, _P]),
     "dg_row_gemm_ln_bwd_workspace_bytes": (c_size_t, [c_int]),
     "dg_row_gemm_ln_bwd": (c_int, [_P] * 3 + [c_int64, c_int] + [_P] * 7 + [_P, c_size_t, c_int, _P]),
+    "dg_row_gemm_ln_bwd_in": (c_int, [_P] * 10 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
     "dg_edge_ffn_ln_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, c_int, _P]),
     "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),

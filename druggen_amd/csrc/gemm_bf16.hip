@@ -31,6 +31,9 @@ size_t row_gemm_f32_ln_bwd_workspace_bytes();
 int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t R, int K, const float* residual,
                         const float* pre, const float* mean, const float* rstd, const float* gamma, float* dgamma,
                         float* dbeta, void* workspace, size_t workspace_bytes, dg_stream_t stream);
+int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma,
+                       const float* packed, float* dz, float* y, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, int64_t R, dg_stream_t stream);
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
                  unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
                  const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream);
@@ -331,6 +334,17 @@ extern "C" int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, i
     return row_gemm_f32_ln_bwd(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(dz), R, K,
                                static_cast<const float*>(residual), static_cast<const float*>(ln_pre), ln_mean, ln_rstd,
                                ln_gamma, dgamma, dbeta, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_row_gemm_ln_bwd_in(const void* dy, const void* ln_pre, const float* ln_mean, const float* ln_rstd,
+                                     const float* ln_gamma, const void* packed, void* dz, void* y, float* dgamma,
+                                     float* dbeta, void* workspace, size_t workspace_bytes, int64_t R, int K, int N,
+                                     int dtype, dg_stream_t stream_) {
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_ln_bwd_in: float32 only");
+    if (K != 128 || N != 128) return fail(DG_E_SHAPE, "dg_row_gemm_ln_bwd_in: unsupported K=%d N=%d (K = N = 128)", K, N);
+    return row_gemm_f32_ln_in(static_cast<const float*>(dy), static_cast<const float*>(ln_pre), ln_mean, ln_rstd, ln_gamma,
+                              static_cast<const float*>(packed), static_cast<float*>(dz), static_cast<float*>(y), dgamma,
+                              dbeta, workspace, workspace_bytes, R, stream_);
 }
 
 extern "C" int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream_) {

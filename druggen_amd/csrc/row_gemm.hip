@@ -85,6 +85,12 @@ struct Epilogue {
     // of dgamma = sum_rows v xhat and dbeta = sum_rows v go to lnb_part[(block * 8 + half-wave)][2][128].
     const float* lnb_pre = nullptr;
     float* lnb_part = nullptr;
+    // LayerNorm-backward PROLOGUE (LNA kernel): the A operand is dz = LayerNormBackward(a; lna_pre, mean, rstd, gamma),
+    // computed by the producer waves on the rows they stream (a is that LayerNorm's OUTPUT gradient); dz is also
+    // written to lna_dz [R,128] (the residual path and the weight gradient read it later), dgamma / dbeta partials go
+    // to lnb_part in the layout above (half-waves of the four producer waves).
+    const float* lna_pre = nullptr;
+    float* lna_dz = nullptr;
 };
 
 // Sum over the 32 lanes of a half-wave, result in every lane.  DPP adds inside each 16-lane row
@@ -481,7 +487,9 @@ __device__ __forceinline__ unsigned dpp_umax_step(unsigned x) {
 template <int PFN, int STRIDE>
 __device__ __forceinline__ void split_write_h3(const float4 (&set)[PFN], char* pl, int pt) {
     constexpr int G = PFN > 8 ? 2 : 4;   // the 16-float4 producers (two waves) are short of registers
-    static_assert(PFN % G == 0, "whole groups");
+    static_assert(PFN % G == 0 && STRIDE % 32 == 0, "whole groups, whole rows");
+    char* const prow = pl + (pt >> 5) * kX6Pitch + (pt & 31) * 8;
+    char* const prs = pl + kH3Rs + (pt >> 5) * 4;
 #pragma unroll
     for (int g0 = 0; g0 < PFN; g0 += G) {
         unsigned m[G];
@@ -530,17 +538,17 @@ __device__ __forceinline__ void split_write_h3(const float4 (&set)[PFN], char* p
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            const int L = pt + STRIDE * (g0 + j), r = L >> 5, c4 = L & 31;
+            // row (pt >> 5) + (STRIDE / 32) (g0 + j): one base address per call, the rest are store-offset immediates
             const f16x2 la = __builtin_convertvector(xa[j], f16x2), lb = __builtin_convertvector(xb[j], f16x2);
             const u32x2 h = {__builtin_bit_cast(unsigned, ha[j]), __builtin_bit_cast(unsigned, hb[j])};
             const u32x2 l = {__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
-            *reinterpret_cast<u32x2*>(pl + 0 * kH3Plane + r * kX6Pitch + c4 * 8) = h;
-            *reinterpret_cast<u32x2*>(pl + 1 * kH3Plane + r * kX6Pitch + c4 * 8) = l;
+            *reinterpret_cast<u32x2*>(prow + 0 * kH3Plane + (STRIDE / 32) * (g0 + j) * kX6Pitch) = h;
+            *reinterpret_cast<u32x2*>(prow + 1 * kH3Plane + (STRIDE / 32) * (g0 + j) * kX6Pitch) = l;
         }
         if ((pt & 31) == 0) {   // one divergent block per group (branches between the stages would serialise the chains)
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                *reinterpret_cast<float*>(pl + kH3Rs + ((pt + STRIDE * (g0 + j)) >> 5) * 4) = inv_scale_of(m[j]);
+                *reinterpret_cast<float*>(prs + (STRIDE / 32) * (g0 + j) * 4) = inv_scale_of(m[j]);
         }
     }
 }
@@ -632,7 +640,7 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 // tile accumulate into the same registers; N = 384: the three column groups of a tile run back to back on
 // the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
 // per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
-template <int KC, int NG, bool EXCH, int NC = 4, bool LNB = false>
+template <int KC, int NG, bool EXCH, int NC = 4, bool LNB = false, bool LNA = false>
 __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
     // NC = 6 (N = 384 only): six consumer waves, each with two resident 32-column slabs (w and w + 6: 128 VGPRs
@@ -645,6 +653,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     static_assert(NC == 4 || (NC == 6 && KC == 1 && NG == 1 && !EXCH), "6 consumers: resident-B 128 -> 384 only");
     static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
     static_assert(!LNB || (EXCH && NC == 4 && NG == 1), "LayerNorm-backward epilogue: 128 -> 128 exchange kernel");
+    static_assert(!LNA || (!EXCH && !LNB && NC == 4 && NG == 1), "LayerNorm-backward prologue: plain 128 -> 128 kernel");
+    constexpr int DEPTH = LNA ? 2 : 3;      // register sets of A chunks the producers keep in flight
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* lds = smem_raw;                              // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
     float* xb = reinterpret_cast<float*>(smem_raw + kH3Lds);   // direct epilogue: one 32 x 32 fp32 tile per consumer wave
@@ -658,12 +668,126 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     // Workgroups walk the three k-chunks / column groups of a tile in rotated orders (blockIdx % 3): at any
     // moment a third of the CUs streams each group's B fragments from L2 instead of all CUs the same 96 KiB.
     const int rot = static_cast<int>(blockIdx.x % 3);
-    const int64_t padded = (nchunks + 2) / 3 * 3;      // the producers run whole groups of three iterations
+    const int64_t padded = (nchunks + DEPTH - 1) / DEPTH * DEPTH;      // the producers run whole groups of DEPTH iterations
     auto tile_of = [&](int64_t chunk) { return blockIdx.x + (chunk / KC) * gridDim.x; };
 
     if (w >= NC) {
         // ------------------------------------------------------------------ producers
         const int pt = threadIdx.x - 64 * NC;
+        if constexpr (LNA) {
+            // ---- LayerNorm backward on the way in.  Thread pt holds float4 column (pt & 31) of tile rows
+            // (pt >> 5) + 8 i: the 32 lanes of a half-wave own whole rows, so both row means are DPP sums.  Two register
+            // sets of dy rows; ONE set of pre-LayerNorm rows and row statistics, requested as soon as the previous
+            // chunk's rows are finished (a chunk period ahead of their use: with four [R,128] streams per tile that
+            // period is ~2x the plain kernel's).  Addresses past the end (last tile, padded iterations) are CLAMPED,
+            // never branched around: a clamped row recomputes the dz of the row it was clamped to and stores the same
+            // values again; only the dgamma / dbeta sums are masked.
+            constexpr int K_ = 128;
+            float4 dyr[2][PFN], prr[PFN];
+            float st;      // lane c < 8: mean of this half-wave's row c ; 8 <= c < 16: rstd of row c - 8
+            const float4 gam = ld4(ep.gamma + (pt & 31) * 4);
+            float4 dgam = f4(0.f), dbet = f4(0.f);
+            const unsigned voff0 = static_cast<unsigned>(pt >> 5) * (K_ * 4) + static_cast<unsigned>(pt & 31) * 16;
+            auto offsets = [&](int64_t chunk, int64_t& r0, unsigned& lim) {
+                r0 = tile_of(chunk) * kTR;
+                const int64_t last = R - 1 - r0;   // >= 0
+                lim = last >= kTR - 1 ? 0xFFFFFFFFu
+                                      : static_cast<unsigned>(last) * (K_ * 4) + static_cast<unsigned>(pt & 31) * 16;
+            };
+            auto fetch_dy = [&](auto s_tag, int64_t chunk) {
+                constexpr int s = decltype(s_tag)::value;
+                if (chunk > nchunks - 1) chunk = nchunks - 1;
+                int64_t r0;
+                unsigned lim;
+                offsets(chunk, r0, lim);
+                const char* ba = reinterpret_cast<const char*>(a) + r0 * (K_ * 4);
+#pragma unroll
+                for (int i = 0; i < PFN; ++i) {
+                    unsigned off = voff0 + i * (2 * NM * K_ * 4);
+                    off = off < lim ? off : lim;
+                    dyr[s][i] = ld4(reinterpret_cast<const float*>(ba + off));
+                }
+            };
+            auto fetch_pre = [&](int64_t chunk) {
+                if (chunk > nchunks - 1) chunk = nchunks - 1;
+                int64_t r0;
+                unsigned lim;
+                offsets(chunk, r0, lim);
+                const char* bp = reinterpret_cast<const char*>(ep.lna_pre) + r0 * (K_ * 4);
+#pragma unroll
+                for (int i = 0; i < PFN; ++i) {
+                    unsigned off = voff0 + i * (2 * NM * K_ * 4);
+                    off = off < lim ? off : lim;
+                    prr[i] = ld4(reinterpret_cast<const float*>(bp + off));
+                }
+                int64_t row = r0 + (pt >> 5) + 8 * (pt & 7);
+                if (row > R - 1) row = R - 1;
+                st = (pt & 8) ? ep.rstd[row] : ep.mean[row];
+            };
+            auto write2 = [&](auto s_tag, int64_t chunk) {
+                constexpr int s = decltype(s_tag)::value;
+                const float live = chunk < nchunks ? 1.f : 0.f;
+                const int buf = static_cast<int>(chunk & 1);
+                if (chunk > nchunks - 1) chunk = nchunks - 1;
+                int64_t r0;
+                unsigned lim;
+                offsets(chunk, r0, lim);
+                char* bz = reinterpret_cast<char*>(ep.lna_dz) + r0 * (K_ * 4);
+                const int64_t last = R - 1 - r0;
+                const int sti = __float_as_int(st);
+                // four rows at a time -- LayerNorm backward, dz store, split into the LDS planes -- fenced: left alone,
+                // the scheduler interleaves all eight rows' chains and spills
+#pragma unroll
+                for (int i0 = 0; i0 < PFN; i0 += 4) {
+                    float4 dzs[4];
+#pragma unroll
+                    for (int i = i0; i < i0 + 4; ++i) {
+                        // statistics of row i of this half-wave: scalar reads of both half-waves' lanes, then a select
+                        const int mu0 = __builtin_amdgcn_readlane(sti, i), mu1 = __builtin_amdgcn_readlane(sti, 32 + i);
+                        const int rs0 = __builtin_amdgcn_readlane(sti, 8 + i), rs1 = __builtin_amdgcn_readlane(sti, 40 + i);
+                        const float mu = __int_as_float(half ? mu1 : mu0), rs = __int_as_float(half ? rs1 : rs0);
+                        const float4 v = dyr[s][i];
+                        const float4 xh = rs * (prr[i] - f4(mu));
+                        const float4 u = v * gam;
+                        const float c1 = half_sum((u.x + u.y) + (u.z + u.w)) * (1.0f / 128.0f);
+                        const float c2 = half_sum((u.x * xh.x + u.y * xh.y) + (u.z * xh.z + u.w * xh.w)) * (1.0f / 128.0f);
+                        const float4 dz = rs * (u - f4(c1) - c2 * xh);
+                        const float ok = (pt >> 5) + 8 * i <= last ? live : 0.f;
+                        const float4 vm = ok * v;
+                        dgam = fma4(vm, xh, dgam);
+                        dbet += vm;
+                        dzs[i - i0] = dz;
+                        unsigned off = voff0 + i * (2 * NM * K_ * 4);
+                        off = off < lim ? off : lim;
+                        st4(reinterpret_cast<float*>(bz + off), dz);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_write_h3<4, 64 * NM>(dzs, lds + buf * kH3Buf, pt + i0 * (64 * NM));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fetch_pre(chunk + 1);      // the pre rows / statistics of the next chunk
+            };
+            constexpr std::integral_constant<int, 0> S0{};
+            constexpr std::integral_constant<int, 1> S1{};
+            fetch_dy(S0, 0);
+            fetch_pre(0);
+            fetch_dy(S1, 1);
+            write2(S0, 0);
+            fetch_dy(S0, 2);
+            __syncthreads();
+            for (int64_t c = 0; c < padded; c += 2) {
+                write2(S1, c + 1);
+                fetch_dy(S1, c + 3);
+                __syncthreads();
+                write2(S0, c + 2);
+                fetch_dy(S0, c + 4);
+                __syncthreads();
+            }
+            float* pp = ep.lnb_part + (static_cast<size_t>(blockIdx.x) * 8 + 2 * (w - NC) + half) * 256 + (pt & 31) * 4;
+            st4(pp, dgam);
+            st4(pp + 128, dbet);
+            return;
+        }
         float4 pf[3][PFN];
         // Straight-line on purpose (chunk indices are clamped instead of guarded): with branches around
         // the loads hipcc can no longer count how many younger loads may stay in flight and drains
@@ -1579,6 +1703,39 @@ int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t 
     }
     if (dgamma || dbeta) launch_ln_finish(ep.lnb_part, seqs * 8, 2, 128, dgamma, dbeta, stream);
     return check_launch("dg_row_gemm_ln_bwd");
+}
+
+bool reduce_batch_try_add(const float* part, int S, long long n_floats, float* out);      // linear_wgrad.hip
+
+// y = dz B with dz = LayerNormBackward(dy; pre, mean, rstd, gamma) computed (and written) on the way in: see
+// Epilogue::lna_pre.  K = N = 128.
+int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma,
+                       const float* packed, float* dz, float* y, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, int64_t R, dg_stream_t stream_) {
+    if (!dy || !pre || !mean || !rstd || !gamma || !packed || !dz || !y || !workspace)
+        return fail(DG_E_ARG, "dg_row_gemm_ln_bwd_in: null pointer");
+    if (R < 0) return fail(DG_E_SHAPE, "dg_row_gemm_ln_bwd_in: R = %lld", static_cast<long long>(R));
+    if (!use_x6()) return fail(DG_E_ARG, "dg_row_gemm_ln_bwd_in: needs the fp16 hi+lo row GEMM (DG_ROW_GEMM=mfma32 is set)");
+    if (workspace_bytes < row_gemm_f32_ln_bwd_workspace_bytes()) return fail(DG_E_WORKSPACE, "dg_row_gemm_ln_bwd_in: workspace too small");
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Epilogue ep{nullptr, nullptr, nullptr, nullptr, gamma, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, 0.f, 0};
+    ep.lna_pre = pre;
+    ep.lna_dz = dz;
+    ep.lnb_part = static_cast<float*>(workspace);
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
+    {
+        ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        constexpr int lds = kH3Lds + 4 * 32 * 32 * 4;
+        DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 4, false, true>), lds);
+        hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 4, false, true>), dim3(seqs), dim3(512), lds, stream, dy,
+                           reinterpret_cast<const f16x8*>(packed), y, R, ep);
+    }
+    // inside dg_linear_wgrad_batch_begin / _end the reduction joins that batch's launch (dgamma, dbeta adjacent)
+    if ((dgamma || dbeta) && !(dgamma && dbeta == dgamma + 128 && reduce_batch_try_add(ep.lnb_part, seqs * 8, 256, dgamma)))
+        launch_ln_finish(ep.lnb_part, seqs * 8, 2, 128, dgamma, dbeta, stream);
+    return check_launch("dg_row_gemm_ln_bwd_in");
 }
 
 }  // namespace dg

@@ -749,6 +749,34 @@ def row_gemm_ln_bwd(a2, packed, K, residual, pre, gamma, mean, rstd):
     return dz, dgamma, dbeta
 
 
+def ln_bwd_row_gemm_supported(a2, K: int, N: int) -> bool:
+    """dg_row_gemm_ln_bwd_in serves float32 rows, K = N = 128 (DG_LN_BWD_PROLOGUE=off: A/B measurements)."""
+    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and N == 128
+            and os.environ.get("DG_LN_BWD_PROLOGUE", "on") != "off")
+
+
+def ln_bwd_row_gemm(pre, gamma, mean, rstd, dy2, packed, want_affine=True, batch_slot=None):
+    """(dz, y, dgamma, dbeta) with dz = LayerNormBackward(dy2) and y = dz @ B in ONE launch (dg_row_gemm_ln_bwd_in):
+    the producer waves of the GEMM run the LayerNorm backward on the rows they stream, dz is written once and never
+    read back by this GEMM.  ``batch_slot``: as in ``_ln_bwd_rows``."""
+    R = pre.shape[0]
+    lib = _lib.load()
+    dz = torch.empty_like(pre)
+    y = torch.empty(R, 128, dtype=pre.dtype, device=pre.device)
+    dgamma, dbeta = (torch.empty(2, gamma.numel(), dtype=gamma.dtype, device=pre.device).unbind(0) if want_affine
+                     else (None, None))
+    code = _lib.dt(pre)
+    with _dev(pre):
+        ws = _scratch(pre, int(lib.dg_row_gemm_ln_bwd_workspace_bytes(code)),
+                      "lna" if batch_slot is None else f"lna_batch{batch_slot}")
+        _lib.check(lib.dg_row_gemm_ln_bwd_in(_lib.ptr(dy2), _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd),
+                                             _lib.fptr(_c(gamma)), packed.data_ptr(), _lib.ptr(dz), _lib.ptr(y),
+                                             _lib.ptr(dgamma), _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, 128, 128,
+                                             code, _lib.stream_of(pre)), "dg_row_gemm_ln_bwd_in")
+    _account(_gemm_key(R, 128, 128), pre.element_size() * R * 128 * 4, 2 * R * 128 * 128)
+    return dz, y, dgamma, dbeta
+
+
 def _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, tz):
     """Backward of ``_ln_bwd_rows`` w.r.t. the adjoint ``tz`` of dz -> (gz, gdy, ggamma)."""
     R, N = pre.shape
@@ -1252,9 +1280,16 @@ class _AttnBlockBwd(Function):
         ds = dz4 = dg4 = db4 = dy2f = None
         if need_edge:
             dy2f = _c(cast(dy2)).reshape(-1, C)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w,
-                                         batch_slot=1 if inb else None)
-            ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
+            if add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):
+                # ln4's backward runs in the producer waves of the out_e input-gradient GEMM (edge-level launches only:
+                # at node level the three small launches it replaces are faster)
+                dz4, ds, dg4, db4 = ln_bwd_row_gemm(pre4, g4, mean4, rstd4, dy2f, pw(woe, 1), want_affine=wants_w,
+                                                    batch_slot=1 if inb else None)
+                ds = ds.view(B, N, N, C)
+            else:
+                dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w,
+                                             batch_slot=1 if inb else None)
+                ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
         # variant of that kernel is latency-bound at 2 waves / SIMD and the extra operand set costs more than the add

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 214            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 215            /* 0.2.1: + fused attention half (dg_attn_half_*) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -220,6 +220,19 @@ int dg_row_gemm_ln_bwd(const void* a, const void* packed, void* dz, int64_t R, i
                        const void* ln_pre, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int dtype,
                        dg_stream_t stream);
+/* The mirror image: the GEMM whose A operand is the INPUT gradient of a LayerNorm (src/model/layers.py:187-190
+ * backward: ln4 / ln3 feed the input-gradient GEMM of out_e / out_n), with that LayerNorm's backward on the way in:
+ *   dz = rstd (dy gamma - mean(dy gamma) - xhat mean(dy gamma xhat)),  xhat = (ln_pre - ln_mean) ln_rstd
+ *   y  = dz[R,K] . B                                   (K = N = 128, plain epilogue)
+ *   dgamma = sum_r dy xhat,  dbeta = sum_r dy          (either may be NULL)
+ * dz [R,128] is written too (the residual path and the weight gradient need it); one launch replaces
+ * dg_ln_residual_bwd + dg_row_gemm and one of their five [R,128] passes.  float32 only.
+ * workspace >= dg_row_gemm_ln_bwd_workspace_bytes(dtype); inside dg_linear_wgrad_batch_begin / _end the dgamma / dbeta
+ * reduction joins the batch when dbeta == dgamma + 128 (the workspace must then stay untouched until _end).      */
+int dg_row_gemm_ln_bwd_in(const void* dy, const void* ln_pre, const float* ln_mean, const float* ln_rstd,
+                          const float* ln_gamma, const void* packed, void* dz, void* y, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, int64_t R, int K, int N, int dtype,
+                          dg_stream_t stream);
 /* dtype = DG_DTYPE_BF16 (csrc/gemm_bf16.hip): a, y, residual, pre_ln are bf16; the packed weight is the
  * bf16 fragment-order copy made by dg_row_gemm_pack(..., DG_DTYPE_BF16, ...); one MFMA per product,
  * fp32 accumulate and epilogue arithmetic.  Bit masks are available for every shape in this mode (the

@@ -411,6 +411,67 @@ def test_row_gemm_with_layernorm_backward_epilogue(R, K, with_residual):
     assert all(torch.equal(x, y) for x, y in zip((dz, dg, db), again))      # fixed-order partial sums
 
 
+@pytest.mark.parametrize("R", [1, 63, 64, 65, 200, 4097, 16384 + 17, 70000])
+def test_row_gemm_with_layernorm_backward_prologue(R):
+    """dg_row_gemm_ln_bwd_in: the input-gradient GEMM whose A operand is the INPUT gradient of a LayerNorm
+    (layers.py:187-190 backward: ln4 feeds the out_e input gradient), with that LayerNorm's backward run by the GEMM's
+    producer waves -- against float64 autograd of LayerNorm(pre) and dz @ W, and against the two launches it replaces
+    (dg_ln_residual_bwd, then the row GEMM).  Ragged row counts: the last tile clamps its addresses."""
+    from druggen_amd import functional as dgf
+    dy = _gen((R, 128), 1)
+    w = _gen((128, 128), 2) * 0.1          # a Linear(128 -> 128) weight, used transposed: ds = dz @ w
+    pre = (_gen((R, 128), 4) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * _gen((128,), 5)).requires_grad_(True)
+    beta = _gen((128,), 6).requires_grad_(True)
+    out = torch.nn.functional.layer_norm(pre, (128,), gamma, beta, 1e-5)
+    dz_ref, dg_ref, db_ref = torch.autograd.grad(out, [pre, gamma, beta], dy)
+    y_ref = dz_ref @ w
+    pre_d = pre.detach().float().cuda()
+    mean = pre_d.mean(-1)
+    rstd = (pre_d.var(-1, unbiased=False) + 1e-5).rsqrt()
+    packed = dgf.packed_weight(w.float().cuda(), 1)
+    dyd = dy.float().cuda()
+    gd = gamma.detach().float().cuda()
+    dz, y, dg, db = dgf.ln_bwd_row_gemm(pre_d, gd, mean, rstd, dyd, packed)
+    assert _rel(dz, dz_ref) < TOL and _rel(y, y_ref) < TOL and _rel(dg, dg_ref) < TOL and _rel(db, db_ref) < TOL
+    dz2, dg2, db2 = dgf._ln_bwd_rows(pre_d, gd, mean, rstd, dyd)
+    y2 = dgf.row_gemm(dz2, packed, 128, 128)
+    for got, want in ((dz, dz2), (y, y2), (dg, dg2), (db, db2)):
+        assert _rel(got, want.double().cpu()) < 1e-5
+    again = dgf.ln_bwd_row_gemm(pre_d, gd, mean, rstd, dyd, packed)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip((dz, y, dg, db), again))      # fixed-order partial sums
+    # input-gradient-only passes: no dgamma / dbeta
+    dz3, y3, none_g, none_b = dgf.ln_bwd_row_gemm(pre_d, gd, mean, rstd, dyd, packed, want_affine=False)
+    assert none_g is None and none_b is None and torch.equal(dz3, dz) and torch.equal(y3, y)
+
+
+def test_attn_block_backward_with_and_without_the_layernorm_prologue(monkeypatch):
+    """The edge-level ln4 backward inside the out_e input-gradient GEMM (DG_LN_BWD_PROLOGUE, default on) gives the
+    gradients of the separate launches: one attention block at an edge-level row count, all parameter and input grads."""
+    import os
+    from druggen_amd.model.layers import Encoder_Block
+    torch.manual_seed(3)
+    B, N, C = 40, 45, 128                      # 40 * 45 * 45 = 81 000 rows >= DG_EDGE_ROWS
+    blk = Encoder_Block(C, 8, torch.nn.ReLU(), 3, 0.0).cuda()
+    x = torch.randn(B, N, C, device="cuda").requires_grad_(True)
+    y = torch.randn(B, N, N, C, device="cuda").requires_grad_(True)
+    px, py = torch.randn(B, N, C, device="cuda"), torch.randn(B, N, N, C, device="cuda")
+
+    def run(flag):
+        monkeypatch.setenv("DG_LN_BWD_PROLOGUE", flag)
+        for p in blk.parameters():
+            p.grad = None
+        xo, yo = blk(x, y)
+        gx, gy = torch.autograd.grad((xo * px).sum() + (yo * py).sum(), [x, y], retain_graph=True)
+        ((xo * px).sum() + (yo * py).sum()).backward()
+        return [gx, gy] + [p.grad.clone() for p in blk.parameters() if p.grad is not None]
+
+    on, off = run("on"), run("off")
+    assert len(on) == len(off)
+    for a_, b_ in zip(on, off):
+        assert _rel(a_, b_.double().cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("N,K", [(128, 128), (384, 128), (128, 384)])
 def test_wgrad_split_bf16_is_fp32_class_accurate(N, K):
     """Same claim for the weight-gradient kernel (dW = dy^T x on the fp16 hi + lo split with running column scales):
