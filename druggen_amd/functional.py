@@ -1203,7 +1203,11 @@ class _AttnBlock(Function):
             ppre, pmean, prstd, pgamma = sv[-4:]
         # y is the output of a LayerNorm whose handle came with it, and no graph is being recorded: that LayerNorm's
         # backward runs as the epilogue of the dy GEMM (its result is the gradient of `ppre`, y itself gets none)
-        fuse_prev = bool(ctx.has_prev and not torch.is_grad_enabled() and ctx.needs_input_grad[1]
+        # (not in the last pass of a double backward -- recognisable by the adjoints of this node's extra outputs: there
+        # the producing feed-forward node's `pre` ALSO receives the second-order adjoint, and autograd would join the
+        # two with an edge-level add that costs more than the fused LayerNorm backward saves)
+        second_pass = any(t is not None for t in (add3, add4, aq, ak, av, ae))
+        fuse_prev = bool(ctx.has_prev and not torch.is_grad_enabled() and not second_pass and ctx.needs_input_grad[1]
                          and ctx.needs_input_grad[22] and row_gemm_ln_bwd_supported(q, C)
                          and tuple(ppre.shape) == (B * N * N, C))
         outs = _AttnBlockBwd.apply(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4,
