@@ -35,6 +35,19 @@ def main():
             groups["ATen elementwise/reduce"] += dur
         else:
             groups["other"] += dur
+    # the persistent kernels run one workgroup per CU at edge level (grid = 256 workgroups) and fewer at node level:
+    # the per-kernel averages above mix the two; bench.py's roofline blocks time the edge-level launches only
+    try:
+        lv = list(cur.execute(
+            "select name, (grid_x >= 256 * workgroup_x) as full, count(*), sum(duration), avg(duration) from kernels "
+            "where name like '%row_gemm%' or name like '%wgrad_kernel%' or name like '%ffn_%bf16%' or name like '%attn_half%' "
+            "group by name, full order by sum(duration) desc"))
+        print("\n# persistent kernels by launch size (full = at least 256 workgroups: the edge-level launches)")
+        print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10}  {'grid':>5}  kernel")
+        for name, full, calls, dur, avg in lv[:24]:
+            print(f"{calls:7d} {dur / 1e6:10.3f} {avg / 1e3:10.2f}  {'full' if full else 'small':>5}  {demangle(name)[:130]}")
+    except sqlite3.Error as e:      # older rocpd schemas
+        print(f"\n# (no per-dispatch view in this trace: {e})")
     print("\n# by group")
     for k, v in groups.items():
         print(f"{v / 1e3:10.3f} ms {100 * v / total:6.2f} %  {k}")
