@@ -37,15 +37,33 @@ def main():
             groups["other"] += dur
     # the persistent kernels run one workgroup per CU at edge level (grid = 256 workgroups) and fewer at node level:
     # the per-kernel averages above mix the two; bench.py's roofline blocks time the edge-level launches only
+    # (R >= DG_EDGE_ROWS).  A node-level launch over 2B molecules (23 040 rows = 360 tiles) also fills the grid, with one
+    # or two tiles per workgroup against >= 31: full-grid launches of a kernel are therefore split once more at the
+    # largest gap of their sorted durations (when it is at least 3x).
     try:
-        lv = list(cur.execute(
-            "select name, (grid_x >= 256 * workgroup_x) as full, count(*), sum(duration), avg(duration) from kernels "
-            "where name like '%row_gemm%' or name like '%wgrad_kernel%' or name like '%ffn_%bf16%' or name like '%attn_half%' "
-            "group by name, full order by sum(duration) desc"))
-        print("\n# persistent kernels by launch size (full = at least 256 workgroups: the edge-level launches)")
-        print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10}  {'grid':>5}  kernel")
-        for name, full, calls, dur, avg in lv[:24]:
-            print(f"{calls:7d} {dur / 1e6:10.3f} {avg / 1e3:10.2f}  {'full' if full else 'small':>5}  {demangle(name)[:130]}")
+        disp = {}
+        for name, full, dur in cur.execute(
+                "select name, (grid_x >= 256 * workgroup_x), duration from kernels where name like '%row_gemm%' "
+                "or name like '%wgrad_kernel%' or name like '%ffn_%bf16%' or name like '%attn_half%'"):
+            disp.setdefault(name, {0: [], 1: []})[1 if full else 0].append(dur)
+        table = []
+        for name, d in disp.items():
+            if d[0]:
+                table.append((sum(d[0]), len(d[0]), "small", name))
+            fl = sorted(d[1])
+            cut = 0
+            if len(fl) > 1:
+                ratio, at = max((fl[i + 1] / max(fl[i], 1), i + 1) for i in range(len(fl) - 1))
+                cut = at if ratio >= 3 else 0
+            if cut:
+                table.append((sum(fl[:cut]), cut, "full/short", name))
+            if fl:
+                table.append((sum(fl[cut:]), len(fl) - cut, "full/edge" if cut else "full", name))
+        table.sort(reverse=True)
+        print("\n# persistent kernels by launch size (full = at least 256 workgroups; full/edge = the edge-level launches)")
+        print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10}  {'launches':>10}  kernel")
+        for dur, calls, cls, name in table[:30]:
+            print(f"{calls:7d} {dur / 1e6:10.3f} {dur / calls / 1e3:10.2f}  {cls:>10}  {demangle(name)[:120]}")
     except sqlite3.Error as e:      # older rocpd schemas
         print(f"\n# (no per-dispatch view in this trace: {e})")
     print("\n# by group")
