@@ -734,6 +734,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                 offsets(chunk, r0, lim);
                 char* bz = reinterpret_cast<char*>(ep.lna_dz) + r0 * (K_ * 4);
                 const int64_t last = R - 1 - r0;
+                // 32-bit row test from a lane term that is opaque per chunk (as loop invariants the eight 64-bit row
+                // numbers of a thread are hoisted and spilled)
+                const unsigned lastu = static_cast<unsigned>(last < kTR - 1 ? last : kTR - 1);
+                unsigned rowt = static_cast<unsigned>(pt) >> 5;
+                asm volatile("" : "+v"(rowt));
                 const int sti = __float_as_int(st);
                 // four rows at a time -- LayerNorm backward, dz store, split into the LDS planes -- fenced: left alone,
                 // the scheduler interleaves all eight rows' chains and spills
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                         const float c1 = half_sum((u.x + u.y) + (u.z + u.w)) * (1.0f / 128.0f);
                         const float c2 = half_sum((u.x * xh.x + u.y * xh.y) + (u.z * xh.z + u.w * xh.w)) * (1.0f / 128.0f);
                         const float4 dz = rs * (u - f4(c1) - c2 * xh);
-                        const float ok = (pt >> 5) + 8 * i <= last ? live : 0.f;
+                        const float ok = rowt + 8u * i <= lastu ? live : 0.f;
                         const float4 vm = ok * v;
                         dgam = fma4(vm, xh, dgam);
                         dbet += vm;
@@ -916,13 +921,21 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[s][m][i] = 0.f;
         }
+        // rows of this wave in the exchange epilogue: w * 16 + it * 2 + half, clamped to the last row of a partial tile
+        // in 32 bits: uniform 64-bit tile base + a per-lane byte offset derived HERE from lane terms that are opaque per
+        // tile (as loop invariants the per-row pointers are hoisted out of the tile loop and spilled)
+        unsigned colv = static_cast<unsigned>(col), halfv = static_cast<unsigned>(half);
+        if (EXCH) asm volatile("" : "+v"(colv), "+v"(halfv));
+        const unsigned lastr = static_cast<unsigned>(R - 1 - r0 < kTR - 1 ? R - 1 - r0 : kTR - 1);
+        auto row_off = [&](int it) {
+            unsigned rr = static_cast<unsigned>(w * 16 + it * 2) + halfv;
+            rr = rr < lastr ? rr : lastr;
+            return rr * 512u + colv * 16u;
+        };
         if (EXCH && kc == KC - 1 && ep.residual) {
+            const char* rbase = reinterpret_cast<const char*>(ep.residual) + r0 * 512;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                int64_t rrow = r0 + w * 16 + it * 2 + half;
-                if (rrow > R - 1) rrow = R - 1;
-                res[it] = ld4(ep.residual + rrow * 128 + col * 4);
-            }
+            for (int it = 0; it < 8; ++it) res[it] = ld4(reinterpret_cast<const float*>(rbase + row_off(it)));
         }
         const char* pl = lds + (chunk & 1) * kH3Buf;
         // fragments of step ks + 1 are requested before the MFMAs of step ks; consecutive MFMAs alternate
@@ -1029,12 +1042,9 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             row_scales(rs[1], 1, cs_g[0]);
             if (LNB) {      // rows of the saved pre-LayerNorm sum: requested here (the fragment registers are free now),
                             // they arrive during the exchange
+                const char* pbase = reinterpret_cast<const char*>(ep.lnb_pre) + r0 * 512;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    int64_t rrow = r0 + w * 16 + it * 2 + half;
-                    if (rrow > R - 1) rrow = R - 1;
-                    lpre[LNB ? it : 0] = ld4(ep.lnb_pre + rrow * 128 + col * 4);
-                }
+                for (int it = 0; it < 4; ++it) lpre[LNB ? it : 0] = ld4(reinterpret_cast<const float*>(pbase + row_off(it)));
             }
             __syncthreads();   // every consumer has finished its fragment reads
 #pragma unroll
@@ -1050,36 +1060,33 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             // rows of this wave: w * 16 + it * 2 + half.  `CHECK` only for the tail tile (uniform branch)
             auto finish_rows_lnb = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
-                float* yrow = y + (r0 + w * 16 + half) * 128 + col * 4;
-                const float4 gam = ld4(ep.gamma + col * 4);
+                float* yrow = reinterpret_cast<float*>(reinterpret_cast<char*>(y + r0 * 128) + ((w * 16 + halfv) * 512u + colv * 16u));
+                const float4 gam = ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ep.gamma) + colv * 16u));
                 // two groups of four rows (register budget): the second group's rows of the saved pre-LayerNorm sum are
                 // requested before the first group is finished
 #pragma unroll
                 for (int hg = 0; hg < 2; ++hg) {
                     float4 pn[4];
                     if (hg == 0) {
+                        const char* pbase = reinterpret_cast<const char*>(ep.lnb_pre) + r0 * 512;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int64_t rrow = r0 + w * 16 + (4 + j) * 2 + half;
-                            if (rrow > R - 1) rrow = R - 1;
-                            pn[j] = ld4(ep.lnb_pre + rrow * 128 + col * 4);
-                        }
+                        for (int j = 0; j < 4; ++j) pn[j] = ld4(reinterpret_cast<const float*>(pbase + row_off(4 + j)));
                     }
                     float mu4[4], rs4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {      // one address per half-wave: broadcast loads
-                        int64_t rrow = r0 + w * 16 + (4 * hg + j) * 2 + half;
-                        if (CHECK && rrow > R - 1) rrow = R - 1;
-                        mu4[j] = ep.mean[rrow];
-                        rs4[j] = ep.rstd[rrow];
+                        unsigned rr = static_cast<unsigned>(w * 16 + (4 * hg + j) * 2) + halfv;
+                        rr = rr < lastr ? rr : lastr;
+                        mu4[j] = ep.mean[r0 + rr];
+                        rs4[j] = ep.rstd[r0 + rr];
                     }
                     float4 yv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int it = 4 * hg + j, rr = w * 16 + it * 2 + half;
-                        float4 v = ld4(ex + rr * 128 + col * 4);
+                        float4 v = ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ex) + ((w * 16 + it * 2 + halfv) * 512u + colv * 16u)));
                         if (ep.residual) v += res[it];
-                        if (CHECK && r0 + rr >= R) v = f4(0.f);
+                        if (CHECK && static_cast<unsigned>(w * 16 + it * 2) + halfv > lastr) v = f4(0.f);
                         const float4 xh = rs4[j] * (lpre[LNB ? j : 0] - f4(mu4[j]));
                         const float4 u = v * gam;
                         const float c1 = half_sum((u.x + u.y) + (u.z + u.w)) * (1.0f / 128.0f);
@@ -1091,7 +1098,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int it = 4 * hg + j, rr = w * 16 + it * 2 + half;
-                        if (!CHECK || r0 + rr < R) st4(yrow + it * 256, yv[j]);
+                        if (!CHECK || static_cast<unsigned>(w * 16 + it * 2) + halfv <= lastr) st4(yrow + it * 256, yv[j]);
                         if (hg == 0) lpre[LNB ? j : 0] = pn[j];
                     }
                 }
