@@ -584,19 +584,23 @@ __global__ __launch_bounds__(512, 1) void attn_half_bwd_bf16_kernel(const HalfBw
     const unsigned qdst = lds_byte_address(qbuf);
     auto dma_tile = [&](size_t tile, int bufi) {
         const unsigned ydst = lds_byte_address(smem + bufi * (2 * YB)), zdst = ydst + YB;
+        // lane term opaque per call: as loop invariants the per-lane source offsets (64-bit) are hoisted out of the
+        // tile loop and spilled, and a scratch reload waits (vmcnt(0)) for the LDS-DMA this very call has just issued
+        int ol = lane;
+        asm volatile("" : "+v"(ol));
 #pragma unroll
         for (int ii0 = 0; ii0 < 4 * MB; ii0 += 8) {
             const int ii = ii0 + w;
-            const int L = ii * 64 + lane;
+            const int L = ii * 64 + ol;
             const int row = L >> 4, cpos = L & 15;
             if (ii < 4 * MB && row < N) {
-                const size_t src = tile * N * kC + row * kC + ((cpos ^ bswz(row)) << 3);
+                const size_t src = tile * N * kC + static_cast<unsigned>(row * kC + ((cpos ^ bswz(row)) << 3));
                 dma16_async(reinterpret_cast<const float*>(a.y + src), ydst + ii * 1024);
                 if (EDGE) dma16_async(reinterpret_cast<const float*>(a.dz + src), zdst + ii * 1024);
             }
         }
-        if (w == 7 && lane < 32) {
-            const bf16_t* src = (lane < 16 ? a.q : a.dO) + tile * kC + (lane & 15) * 8;
+        if (w == 7 && ol < 32) {
+            const bf16_t* src = (ol < 16 ? a.q : a.dO) + tile * kC + (ol & 15) * 8;
             dma16_async(reinterpret_cast<const float*>(src), qdst + bufi * 512);
         }
     };
