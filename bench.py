@@ -14,9 +14,11 @@ fp32.  Multi-GPU: one process per GPU, the batch is sharded (weak scaling: 256
 molecules per rank), gradients averaged with one RCCL all-reduce per backward.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      attention-core forward kernel (the HBM-bound kernel north_star
-                names): algorithmic bytes / HIP-event time measured during the
-                timed steps, against the 8 TB/s HBM3E peak;
+  roofline      the time-dominant edge-level kernel of the step (chosen by
+                measurement: one instrumented step before the timed region ranks
+                them): algorithmic bytes / HIP-event time measured during the timed
+                steps, against the 8 TB/s HBM3E peak (+ its MFMA-side fraction);
+  roofline_attention  the same for the attention kernel north_star names;
   kernels       the same figure for every profiled HIP kernel;
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on the
                 host cores on a bounded sample of the same workload.
@@ -225,16 +227,27 @@ def main():
     if args.graph and world == 1:
         graphed = GraphedGANStep(stepper, disc_edge, disc_node, gen_edge, gen_node, warmup=1)
         run = graphed.step
+    # Which edge-level kernel (and shape) is the time-dominant one is MEASURED, not assumed: one fully instrumented,
+    # untimed step after the warm-up ranks every edge-level key by its total HIP-event time ...
+    edge_keys = ("attn_fwd", "attn_bwd", "attn_bwd2", "attn_half_fwd", "attn_half_bwd", "row_gemm_e128",
+                 "row_gemm_e_n384", "row_gemm_e_k384", "linear_wgrad_e128", "linear_wgrad_e_n384", "linear_wgrad_e_k384",
+                 "ffn", "ffn_wgrad")
+    attn_key = "attn_half_fwd" if (act_dtype == "bf16" and dgf.attn_half_supported(torch.bfloat16, w["vertexes"], w["dim"])
+                                   and os.environ.get("DG_ATTN_HALF", "fused") != "unfused") else "attn_fwd"
+    top_key = None
+    if not args.graph:
+        _lib.prof_reset()
+        _lib.prof_enable(kernels=edge_keys)
+        stepper.step(disc_edge, disc_node, gen_edge, gen_node)
+        torch.cuda.synchronize(dev)
+        _lib.prof_enable(False)
+        ranked = sorted(((_lib.prof_read(k)[1], k) for k in edge_keys), reverse=True)
+        top_key = ranked[0][1] if ranked and ranked[0][0] > 0 else None
     _lib.prof_reset()
     dgf.traffic_reset()
-    # timed region: HIP events only around the EDGE-level launches that can be the roofline kernel (attention core,
-    # fused attention half, the three row-GEMM shapes, fused feed-forward: ~300 of the ~1.7 k launches of a step), so
-    # that the timing of the small launches is not perturbed
-    all_edge_kernels = ("attn_fwd", "attn_bwd", "attn_bwd2", "attn_half_fwd", "attn_half_bwd", "row_gemm_e128",
-                        "row_gemm_e_n384", "row_gemm_e_k384", "ffn", "ffn_wgrad")
-    # ... and of those only the time-dominant kernel of this dtype plus the attention kernel north_star names (~50
-    # launches per step: every pair of events costs a few microseconds of stream time)
-    attn_kernels = ("ffn", "attn_half_fwd") if act_dtype == "bf16" else ("row_gemm_e_k384", "attn_fwd")
+    # ... and the timed region carries HIP events only around that kernel plus the attention kernel north_star names
+    # (~50 of the ~1.1 k launches of a step: every pair of events costs a few microseconds of stream time)
+    attn_kernels = tuple(dict.fromkeys(k for k in (top_key, attn_key) if k))
     if not args.graph:
         _lib.prof_enable(kernels=attn_kernels)
     sync()
@@ -277,8 +290,9 @@ def main():
     if rank == 0:
         bf16 = act_dtype == "bf16"
         # MFMA ceiling of the GEMM-shaped kernels by arithmetic: fp32 activations run a power-of-two scaled fp16
-        # two-plane split (3 fp16 MFMAs per product: ceiling = 16-bit peak / 3; the weight-gradient kernel still
-        # uses the 3-way bf16 split, 6 MFMAs per product); bf16 activations one MFMA per product
+        # two-plane split in the row GEMMs AND the weight gradients (3 fp16 MFMAs per product: ceiling = 16-bit peak / 3;
+        # DG_WGRAD=x6 / mfma32 select the older arithmetics of the weight-gradient kernel); bf16 activations one MFMA
+        # per product
         split = os.environ.get("DG_ROW_GEMM") != "mfma32"
         gemm_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS)
         gemm_how = ("1x v_mfma_f32_*_bf16 per product (bf16 operands, fp32 accumulate)" if bf16 else
@@ -301,8 +315,16 @@ def main():
                 if fl:          # GEMM-shaped kernels: flop rate against the MFMA ceiling of their arithmetic
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                     peak, how = gemm_peak, gemm_how
-                    if name == "linear_wgrad" and not bf16 and split:     # still the 3-way bf16 split
-                        peak, how = MFMA_BF16_PEAK_TFLOPS / 6.0, "6x v_mfma_f32_32x32x16_bf16 per product (fp32 operands split 3-way into bf16)"
+                    if name.startswith("linear_wgrad") and not bf16:
+                        wg = os.environ.get("DG_WGRAD", "h3")
+                        if wg == "x6":
+                            peak, how = MFMA_BF16_PEAK_TFLOPS / 6.0, "6x v_mfma_f32_32x32x16_bf16 per product (fp32 operands split 3-way into bf16)"
+                        elif wg == "mfma32":
+                            peak, how = MFMA_F32_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32"
+                        else:
+                            peak = MFMA_BF16_PEAK_TFLOPS / 3.0
+                            how = ("3x v_mfma_f32_32x32x16_f16 per product (fp32 operands split hi + lo into fp16 under running "
+                                   "power-of-two column scales, fp32 accumulate)")
                     kernels[name].update({"achieved_TFLOPs": tf, "mfma_peak_TFLOPs": peak,
                                           "frac_of_mfma_peak": tf / peak, "mfma": how})
                     kernels[name]["bound"] = "hbm" if kernels[name]["frac_of_hbm_peak"] >= tf / peak else "mfma"
@@ -315,7 +337,11 @@ def main():
                   "attn_fwd": "attention core forward", "attn_bwd": "attention core backward",
                   "attn_bwd2": "attention core second order", "attn_half_fwd": "fused attention half forward "
                   "(e-proj + score/softmax/AV + out_e + residual + LN4)", "attn_half_bwd": "fused attention half backward",
-                  "ffn": "fused bf16 feed-forward (forward, dx)", "ffn_wgrad": "fused bf16 feed-forward weight gradients"}
+                  "linear_wgrad_e128": "weight gradient dW[128,128] = dy^T x over the edge rows",
+                  "linear_wgrad_e_n384": "weight gradient dW[384,128] (fc1) over the edge rows",
+                  "linear_wgrad_e_k384": "weight gradient dW[128,384] (fc2) over the edge rows",
+                  "ffn": "fused bf16 feed-forward (forward, dx), edge-level launches",
+                  "ffn_wgrad": "fused bf16 feed-forward weight gradients, edge-level launches"}
 
         def timed_block(name):
             (n, ms), nbytes = attn_stats[name]
@@ -341,12 +367,15 @@ def main():
                       for k, v in kernels.items() if k in SHAPES]
         if args.graph or not blocks:        # --graph: events cannot sit inside a replayed graph
             blocks = all_blocks
+        # the block of the kernel the pre-pass ranked first; the instrumented steps after the timed region rank again
         top_all = max(all_blocks, key=lambda b: b["share_of_step"])["kernel"] if all_blocks else None
-        dominant = max(blocks, key=lambda b: b["share_of_step"]) if blocks else {}
+        dominant = next((b for b in blocks if b["kernel"] == top_key), None) or (
+            max(blocks, key=lambda b: b["share_of_step"]) if blocks else {})
         if dominant:
             dominant["is_time_dominant_edge_kernel"] = bool(top_all == dominant["kernel"])
-        attn_name = "attn_half_fwd" if any(b["kernel"] == "attn_half_fwd" for b in blocks) else "attn_fwd"
-        attention = next((b for b in blocks if b["kernel"] == attn_name), None)
+            dominant["chosen_by"] = ("largest total HIP-event time among the edge-level kernels in one instrumented step "
+                                     "before the timed region")
+        attention = next((b for b in blocks if b["kernel"] == attn_key), None)
         # HBM bytes per launch from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
         # scripts/pmc_traffic.py): only reported when the pass was taken on THIS workload, dtype and batch; the record
         # names the commit it was measured at

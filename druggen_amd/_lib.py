@@ -86,7 +86,9 @@ SIGNATURES = {
 
 KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10,
               "attn_half_fwd": 11, "attn_half_bwd": 12,
-              "row_gemm_e128": 13, "row_gemm_e_n384": 14, "row_gemm_e_k384": 15}
+              "row_gemm_e128": 13, "row_gemm_e_n384": 14, "row_gemm_e_k384": 15,
+              "linear_wgrad_e128": 16, "linear_wgrad_e_n384": 17, "linear_wgrad_e_k384": 18,
+              "ffn_node": 19, "ffn_wgrad_node": 20}
 EDGE_ROWS = 65536        # DG_EDGE_ROWS of include/druggen_hip.h
 
 _lock = threading.Lock()

@@ -628,6 +628,15 @@ constexpr int kSkinnyBlocks = 512;
 
 bool skinny_ok(int N, int K) { return N >= 1 && N <= 16 && K >= 4 && K % 4 == 0 && K <= 1024 && 256 % (K / 4) == 0; }
 
+// profiler key: edge-level launches by shape, everything else together
+int wgrad_prof_key(int64_t R, int N, int K) {
+    if (R < DG_EDGE_ROWS) return DG_K_LINEAR_WGRAD;
+    if (N == 128 && K == 128) return DG_K_LINEAR_WGRAD_E_128;
+    if (N == 384 && K == 128) return DG_K_LINEAR_WGRAD_E_N384;
+    if (N == 128 && K == 384) return DG_K_LINEAR_WGRAD_E_K384;
+    return DG_K_LINEAR_WGRAD;
+}
+
 struct WgradPlan {
     int nt, kt, wn, wk, tr, threads, lds, lds_mask;
 };
@@ -803,7 +812,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
-    ProfScope prof(DG_K_LINEAR_WGRAD, stream);
+    ProfScope prof(wgrad_prof_key(R, N, K), stream);
 #define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \
     {                                                                                                            \
         constexpr int tile_bytes = TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * static_cast<int>(sizeof(T));           \

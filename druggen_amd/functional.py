@@ -51,6 +51,18 @@ def _gemm_key(R: int, K: int, N: int) -> str:
     return "row_gemm_e_k384" if K == 384 else ("row_gemm_e_n384" if N == 384 else "row_gemm_e128")
 
 
+def _wgrad_key(R: int, N: int, K: int) -> str:
+    """Profiler / traffic key of a weight-gradient launch (DG_K_LINEAR_WGRAD_E_*: edge-level launches by shape of dW)."""
+    if R >= _lib.EDGE_ROWS:
+        if (N, K) == (128, 128):
+            return "linear_wgrad_e128"
+        if (N, K) == (384, 128):
+            return "linear_wgrad_e_n384"
+        if (N, K) == (128, 384):
+            return "linear_wgrad_e_k384"
+    return "linear_wgrad"
+
+
 def traffic_flops(kernel: str) -> int:
     return _traffic.get(kernel + ":flops", 0)
 
@@ -170,6 +182,10 @@ def _scratch(ref, need, tag="ln"):
     key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream, threading.get_ident(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
+        if len(_ws_cache) > 256:      # nn.DataParallel starts fresh replica threads per forward: drop dead threads' buffers
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _ws_cache if k[2] not in alive]:
+                del _ws_cache[k]
         buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ref.device)
         _ws_cache[key] = buf
     return buf
@@ -358,7 +374,15 @@ def _wgrad_many(items, open_batch=True):
           and all(dy.dtype == x.dtype and dy.shape[1] > 16 and x.shape[1] > 16 for dy, x, _ in items))
     needs = [int(lib.dg_linear_wgrad_workspace_bytes(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _ in items] if ok else []
     if not ok or any(n == 0 for n in needs):
-        return [_wgrad(dy, x, b) for dy, x, b in items]
+        if open_batch:
+            return [_wgrad(dy, x, b) for dy, x, b in items]
+        # the caller's batch is open: every reduce is deferred to its end, so the calls must not share the one "wgrad"
+        # scratch buffer -- a private buffer per item
+        out = []
+        for i, (dy, x, b) in enumerate(items):
+            n = int(lib.dg_linear_wgrad_workspace_bytes(dy.shape[0], dy.shape[1], x.shape[1])) if dy.is_cuda else 0
+            out.append(_wgrad(dy, x, b, ws=_scratch(dy, n, f"wgrad_fb{i}") if n else None))
+        return out
     offs, total = [], 0
     for n in needs:
         offs.append(total)
@@ -398,7 +422,7 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None, ws=None):
             ws = _scratch(dy2, need, "wgrad")
         _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
                                        ws.numel(), R, N, K, _lib.dt(dy2), _lib.stream_of(dy2)), "dg_linear_wgrad")
-    _account("linear_wgrad", dy2.element_size() * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
+    _account(_wgrad_key(R, N, K), dy2.element_size() * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
     return dw, db
 
 
@@ -588,8 +612,8 @@ def repack_params(params) -> int:
     of packs refreshed."""
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return 0      # the device table is built with a host -> device copy
-    if os.environ.get("DG_PACK", "batch") != "batch":
-        return 0
+    if os.environ.get("DG_PACK", "batch") != "batch" or not _h3_row_gemm():
+        return 0      # (DG_ROW_GEMM=mfma32: dg_row_gemm_pack_batch packs the fp16 hi + lo layout only)
     ids = {id(p) for p in params}
     total = 0
     for dtype in (torch.float32, torch.bfloat16):
@@ -725,9 +749,15 @@ def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None, want_affine=True, bat
     return dz, dgamma, dbeta
 
 
+def _h3_row_gemm() -> bool:
+    """False under DG_ROW_GEMM=mfma32 (A/B switch: fp32-MFMA row GEMMs): the entry points that exist only for the fp16
+    hi + lo kernels (batched packs, LayerNorm-backward epilogue / prologue) are then not offered."""
+    return os.environ.get("DG_ROW_GEMM") != "mfma32"
+
+
 def row_gemm_ln_bwd_supported(a2, K: int) -> bool:
     """dg_row_gemm_ln_bwd serves float32 rows, K = N = 128 (DG_LN_BWD_EPILOGUE=off: A/B measurements)."""
-    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128
+    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and _h3_row_gemm()
             and os.environ.get("DG_LN_BWD_EPILOGUE", "on") != "off")
 
 
@@ -751,7 +781,7 @@ def row_gemm_ln_bwd(a2, packed, K, residual, pre, gamma, mean, rstd):
 
 def ln_bwd_row_gemm_supported(a2, K: int, N: int) -> bool:
     """dg_row_gemm_ln_bwd_in serves float32 rows, K = N = 128 (DG_LN_BWD_PROLOGUE=off: A/B measurements)."""
-    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and N == 128
+    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and N == 128 and _h3_row_gemm()
             and os.environ.get("DG_LN_BWD_PROLOGUE", "on") != "off")
 
 
@@ -853,11 +883,12 @@ class _FFNLN(Function):
     def backward(ctx, dy, dpre, _dmean=None, _drstd=None):
         x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = ctx.saved_tensors
         want_w = ctx.needs_input_grad[1] and not _inputs_only()
+        want_aff = (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]) and not _inputs_only()
         if dy is None and (dpre is None or torch.is_grad_enabled()):
             dy = torch.zeros_like(pre)
         # dy None, dpre given, no graph recorded: the LayerNorm backward already happened in the consumer's GEMM
         dx, dw1, db1, dw2, db2, dgamma, dbeta = _FFNLNBwd.apply(x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits,
-                                                                 dy, dpre, ctx.needs_input_grad[0], want_w)
+                                                                 dy, dpre, ctx.needs_input_grad[0], want_w, want_aff)
         return dx, dw1, db1, dw2, db2, dgamma, dbeta, None
 
 
@@ -870,7 +901,9 @@ class _FFNLNBwd(Function):
     and adj z then runs the first-order backward of z = x + fc2(relu(fc1 x)) (no LayerNorm)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff=None):
+        if want_aff is None:
+            want_aff = want_w
         H, C = w1.shape
         R = pre.shape[0]
         lib = _lib.load()
@@ -886,7 +919,7 @@ class _FFNLNBwd(Function):
             dy2 = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
             dz = torch.empty(R, C, dtype=adt, device=dev)
             # adjacent in memory: their reduction then rides in the block's single reduce launch
-            dgamma, dbeta = torch.empty(2, gamma.numel(), dtype=gamma.dtype, device=dev).unbind(0) if want_w else (None, None)
+            dgamma, dbeta = torch.empty(2, gamma.numel(), dtype=gamma.dtype, device=dev).unbind(0) if want_aff else (None, None)
         dw1 = db1 = dw2 = db2 = None
         if want_w:
             dw1 = torch.empty_like(w1)
@@ -910,7 +943,8 @@ class _FFNLNBwd(Function):
         if dx is not None:
             _account(_gemm_key(R, H, C), es * R * (H + 2 * C), 2 * R * C * H)
         if want_w:
-            _account("linear_wgrad", 2 * es * R * (C + H), 4 * R * C * H)
+            _account(_wgrad_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+            _account(_wgrad_key(R, H, C), es * R * (C + H), 2 * R * C * H)
         ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)
         ctx.had_add = dz_add is not None      # (includes the dy-None case: never differentiated again)
         ctx.set_materialize_grads(False)
@@ -923,7 +957,7 @@ class _FFNLNBwd(Function):
         if any(t is not None for t in (t_dw1, t_db1, t_dw2, t_db2, t_dg, t_db)):
             raise RuntimeError("ffn_ln: second-order terms through parameter gradients are not implemented")
         if t_dx is None:
-            return (None,) * 15
+            return (None,) * 16
         if ctx.had_add:
             raise RuntimeError("ffn_ln: third-order differentiation is not implemented")
         x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh = ctx.saved_tensors
@@ -940,8 +974,8 @@ class _FFNLNBwd(Function):
                                               (dz, vbar, False)])          # u^T ((t W1^T)*m)
         # dx depends on x only through the saved pre-LN sum z: its adjoint goes back to the forward
         # node (second output of _FFNLN), which runs ONE backward pass for both gradient sources.
-        # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w
-        return None, gw1, None, gw2, None, gbar, None, None, None, zbar, None, dybar.view_as(t_dx), None, None, None
+        # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff
+        return None, gw1, None, gw2, None, gbar, None, None, None, zbar, None, dybar.view_as(t_dx), None, None, None, None
 
 
 _ffn_pack_cache = {}
@@ -994,7 +1028,7 @@ class _FFNLNFusedBF16(Function):
                                               _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd),
                                               None if bits is None else bits.data_ptr(), R, eps, _lib.stream_of(x2)),
                        "dg_ffn_ln_fwd_bf16")
-        _account("ffn", 2 * R * C * (3 if record else 2) + (48 * R if record else 0), 4 * R * C * 3 * C)
+        _account("ffn" if R >= _lib.EDGE_ROWS else "ffn_node", 2 * R * C * (3 if record else 2) + (48 * R if record else 0), 4 * R * C * 3 * C)
         if record:
             ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, pre, mean, rstd, bits)
         ctx.eps = eps
@@ -1032,9 +1066,10 @@ class _FFNLNFusedBF16(Function):
                                               _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
                                               None if bits2 is None else bits2.data_ptr(), ws.data_ptr(), ws.numel(), R,
                                               _lib.stream_of(x2)), "dg_ffn_ln_bwd_bf16")
-        _account("ffn", 2 * R * C * (4 if want_x else 3) + 48 * R, 4 * R * C * H if want_x else 2 * R * C * H)
+        lvl = "" if R >= _lib.EDGE_ROWS else "_node"
+        _account("ffn" + lvl, 2 * R * C * (4 if want_x else 3) + 48 * R, 4 * R * C * H if want_x else 2 * R * C * H)
         if want_w:
-            _account("ffn_wgrad", 2 * (2 * R * C * 2 + 48 * R), 8 * R * C * H)
+            _account("ffn_wgrad" + lvl, 2 * (2 * R * C * 2 + 48 * R), 8 * R * C * H)
         if not ctx.needs_input_grad[5] or _inputs_only():
             dgamma = dbeta = None
         return (None if dx is None else dx.view(x.shape)), dw1, db1, dw2, db2, dgamma, dbeta, None
@@ -1198,6 +1233,7 @@ class _AttnBlock(Function):
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
         wants_w = ctx.needs_input_grad[2] and not _inputs_only()
+        want_aff = any(ctx.needs_input_grad[14:18]) and not _inputs_only()      # ln3 / ln4 affine parameters
         ppre = pmean = prstd = pgamma = None
         if ctx.has_prev:
             ppre, pmean, prstd, pgamma = sv[-4:]
@@ -1214,7 +1250,7 @@ class _AttnBlock(Function):
                                    q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
                                    add3, add4, aq, ak, av, ae,
                                    alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w,
-                                   ppre if fuse_prev else None, pmean, prstd, pgamma)
+                                   ppre if fuse_prev else None, pmean, prstd, pgamma, want_aff)
         (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4, dzp, dgp, dbp) = outs
         if not (ctx.needs_input_grad[25] and not _inputs_only()):
             dgp = dbp = None
@@ -1263,14 +1299,16 @@ class _AttnBlockBwd(Function):
     @staticmethod
     def forward(ctx, *args):
         # one reduce launch for the block: six weight gradients + two LayerNorms' dgamma / dbeta
-        wants_w = args[40]
+        wants_w = args[40] or (len(args) > 45 and args[45])      # weight gradients or LayerNorm affine gradients
         with _reduce_batch(args[0], on=bool(wants_w)) as inb:
             return _AttnBlockBwd._forward(ctx, inb, *args)
 
     @staticmethod
     def _forward(ctx, inb, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
                  mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
-                 alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None):
+                 alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None, want_aff=None):
+        if want_aff is None:
+            want_aff = wants_w
         B, N, C = x1.shape
         adt = q.dtype
         pw = lambda w_, m_: packed_weight(w_, m_, adt)
@@ -1278,7 +1316,7 @@ class _AttnBlockBwd(Function):
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         dx2f = _c(cast(dx2)).reshape(-1, C)
         cadd = lambda t: None if t is None else _c(cast(t)).reshape(-1, C)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3), want_affine=wants_w,
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, dx2f, cadd(add3), want_affine=want_aff,
                                      batch_slot=0 if inb else None)
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
@@ -1287,11 +1325,11 @@ class _AttnBlockBwd(Function):
             if add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):
                 # ln4's backward runs in the producer waves of the out_e input-gradient GEMM (edge-level launches only:
                 # at node level the three small launches it replaces are faster)
-                dz4, ds, dg4, db4 = ln_bwd_row_gemm(pre4, g4, mean4, rstd4, dy2f, pw(woe, 1), want_affine=wants_w,
+                dz4, ds, dg4, db4 = ln_bwd_row_gemm(pre4, g4, mean4, rstd4, dy2f, pw(woe, 1), want_affine=want_aff,
                                                     batch_slot=1 if inb else None)
                 ds = ds.view(B, N, N, C)
             else:
-                dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=wants_w,
+                dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=want_aff,
                                              batch_slot=1 if inb else None)
                 ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
@@ -1377,10 +1415,10 @@ class _AttnBlockBwd(Function):
         # The outputs depend on x1 / y only through the forward intermediates: their adjoints
         # (z3bar, z4bar at the pre-LayerNorm sums; gq, gk, gv, ge) go to the forward node.
         # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, q,k,v,e, s,o,
-        #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags, 4 LNHandle fields
+        #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags, 4 LNHandle fields, want_aff
         return (None, None, *gW, g3bar, g4bar, gq.view_as(q), gk.view_as(k), gv.view_as(v), ge.view_as(e), None, None,
                 None, None, z3bar, None, None, z4bar, dx2bar.view(dx2_shape),
-                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 15))
+                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 16))
 
 
 _half_pack_cache = {}
@@ -1471,7 +1509,8 @@ class _AttnBlockFused(Function):
 
     @staticmethod
     def backward(ctx, dx2, dy2=None):
-        wants_w = bool(ctx.needs_input_grad[2] and not _inputs_only() and not torch.is_grad_enabled())
+        wants_w = bool((ctx.needs_input_grad[2] or any(ctx.needs_input_grad[14:18])) and not _inputs_only()
+                       and not torch.is_grad_enabled())
         with _reduce_batch(ctx.saved_tensors[0], on=wants_w) as inb:      # one reduce launch for the block
             return _AttnBlockFused._backward(ctx, inb, dx2, dy2)
 
@@ -1492,17 +1531,18 @@ class _AttnBlockFused(Function):
         pw = lambda w_, m_: packed_weight(w_, m_, adt)
         cast = lambda t: t if t.dtype == adt else t.to(adt)
         wants_w = ctx.needs_input_grad[2] and not _inputs_only()
+        want_aff = any(ctx.needs_input_grad[14:18]) and not _inputs_only()
         x1f = _c(x1).reshape(-1, C)
         if dx2 is None:
             dx2 = torch.zeros_like(pre3)
-        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C), want_affine=wants_w,
+        dz3, dg3, db3 = _ln_bwd_rows(pre3, g3, mean3, rstd3, _c(cast(dx2)).reshape(-1, C), want_affine=want_aff,
                                      batch_slot=0 if inb else None)
         do = row_gemm(dz3, pw(won, 1), C, C)
         dz4 = dg4 = db4 = None
         if need_edge:
             if dy2 is None:
                 dy2 = torch.zeros_like(pre4)
-            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C), want_affine=wants_w,
+            dz4, dg4, db4 = _ln_bwd_rows(pre4.view(-1, C), g4, mean4, rstd4, _c(cast(dy2)).reshape(-1, C), want_affine=want_aff,
                                          batch_slot=1 if inb else None)
         lib = _lib.load()
         dy = torch.empty_like(y)
@@ -1536,8 +1576,6 @@ class _AttnBlockFused(Function):
                 [(dq, x1f, True), (dk, x1f, True), (dv, x1f, True), (dz3, o, True)], open_batch=not inb)
             gw[6], gw[7] = dwe, dbe
             gw[8], gw[9] = dwoe, dboe
-        else:
-            dg3 = db3 = dg4 = db4 = None
         return (dx1, (dy if ctx.needs_input_grad[1] else None), *gw, dg3, db3, dg4, db4, None, None, None, None)
 
 

@@ -2,8 +2,9 @@
 
 Module names, parameter names and call signatures follow the reference so its
 checkpoints load unchanged; the compute goes through the HIP kernels of
-``libdruggen_hip.so`` (``druggen_amd.functional``).  Dense ``nn.Linear``
-contractions use the ROCm BLAS behind ``F.linear``.  There is no CPU path.
+``libdruggen_hip.so`` (``druggen_amd.functional``): every dim-128 / 384 ``nn.Linear``
+runs on ``dg_row_gemm`` / ``dg_linear_wgrad`` (fp16 hi + lo split MFMA, fp32 class); only odd
+shapes (the Discriminator head, tiny test models) reach the ROCm BLAS.  There is no CPU path.
 """
 from __future__ import annotations
 

@@ -213,6 +213,8 @@ class GANStep:
                                                          self.lambda_gp, return_terms=True, **kw)
             main.backward()
             params = [p for p in self.D.parameters() if p.requires_grad]
+            # (torch.autograd.grad: tensor / post-accumulate-grad hooks on D's parameters fire for `main` only, not for
+            # the penalty term; DG_D_BACKWARD=joint runs the reference's single backward for hook users)
             g2 = torch.autograd.grad(pen, params, allow_unused=True)
             have, add = [], []
             for p, g in zip(params, g2):
@@ -293,10 +295,13 @@ class GraphedGANStep:
         """Replay on a new batch (``None`` keeps the previous tensor).  Edge batches captured as one-hot must be one-hot
         again: labels attached by ``data.load_molecules`` are trusted, other tensors are validated by ``as_one_hot``
         (one device->host read per new tensor object; ``check_one_hot=False`` skips it and trusts ``argmax``)."""
+        # validate every new batch BEFORE touching a static buffer: a batch that is rejected leaves the dense buffers and
+        # the label buffers of the previous batch intact (and consistent with each other)
+        todo = []
         for idx, (dst, src) in enumerate(zip(self.static, (disc_edge, disc_node, gen_edge, gen_node))):
             if src is None or src.data_ptr() == dst.data_ptr():
                 continue
-            dst.copy_(src)
+            lab = None
             if idx in self._labels:
                 lab = one_hot_labels(as_one_hot(src)) if check_one_hot else one_hot_labels(src)
                 if lab is None:
@@ -304,6 +309,10 @@ class GraphedGANStep:
                         raise RuntimeError("GraphedGANStep was captured with a one-hot edge batch (table-gather embedding); "
                                            "the new batch is not one-hot: capture a new graph for dense inputs")
                     lab = src.argmax(-1)
+            todo.append((idx, dst, src, lab))
+        for idx, dst, src, lab in todo:
+            dst.copy_(src)
+            if lab is not None:
                 self._labels[idx].copy_(lab)      # in place: the captured kernels read this buffer
                 attach_one_hot_labels(dst, self._labels[idx])
         self.graph.replay()

@@ -402,6 +402,13 @@ enum {
     DG_K_ROW_GEMM_E_128 = 13,      /* 128 -> 128 (q/k/v/e/out projections and their input gradients) */
     DG_K_ROW_GEMM_E_N384 = 14,     /* 128 -> 384 (fc1; dh = dz W2) */
     DG_K_ROW_GEMM_E_K384 = 15,     /* 384 -> 128 (fc2 [+ residual + LayerNorm]; dx = dh W1) */
+    /* weight gradients over EDGE-level row counts, by shape [N,K] of dW; smaller launches stay in DG_K_LINEAR_WGRAD */
+    DG_K_LINEAR_WGRAD_E_128 = 16,  /* dW [128,128] (the six projections of an attention block) */
+    DG_K_LINEAR_WGRAD_E_N384 = 17, /* dW [384,128] (fc1) */
+    DG_K_LINEAR_WGRAD_E_K384 = 18, /* dW [128,384] (fc2) */
+    /* fused bf16 feed-forward over NODE-level row counts (R < DG_EDGE_ROWS): DG_K_FFN / DG_K_FFN_WGRAD hold the edge-level launches */
+    DG_K_FFN_NODE = 19,
+    DG_K_FFN_WGRAD_NODE = 20,
     DG_K_COUNT = 24
 };
 int dg_prof_enable(int mask);

@@ -32,7 +32,9 @@ def main():
         for c in sorted(m):
             line.append(f"    {c:34s} {m[c]:16.0f}")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CU_CYCLES" in m and m["SQ_BUSY_CU_CYCLES"]:
-            line.append(f"    -> MFMA busy / CU busy cycles          {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_BUSY_CU_CYCLES']:.3f}")
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the four SIMDs' matrix pipes, SQ_BUSY_CU_CYCLES counts per CU: / 4
+            line.append(f"    -> MFMA pipe busy share (MFMA busy / (4 SIMDs x CU busy cycles))  "
+                        f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * m['SQ_BUSY_CU_CYCLES']):.3f}")
         if "SQ_LDS_BANK_CONFLICT" in m and "SQ_LDS_IDX_ACTIVE" in m and m["SQ_LDS_IDX_ACTIVE"]:
             line.append(f"    -> LDS bank-conflict cycles / LDS active  {m['SQ_LDS_BANK_CONFLICT'] / m['SQ_LDS_IDX_ACTIVE']:.3f}")
         print("\n".join(line))
