@@ -15,6 +15,7 @@
 // feeds MFMA operands with conflict-free ds_read_b32 (lane&31 walks a row).
 // Split-K partials are reduced by a second kernel in a fixed order.
 #include "bf16.h"
+#include "wgrad_stream.h"
 
 #include <cstring>
 #include <type_traits>
@@ -705,7 +706,8 @@ extern "C" size_t dg_linear_wgrad_workspace_bytes(int64_t R, int N, int K) {
     if (R >= 1 && skinny_ok(N, K)) return static_cast<size_t>(kSkinnyBlocks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
     if (R < 1 || !wgrad_plan(N, K, &p)) return 0;
     int tpb;
-    const int S = wgrad_blocks(R, p, &tpb);
+    int S = wgrad_blocks(R, p, &tpb);
+    if (wgrad_stream_supported(N, K) && wgrad_stream_blocks(R, N, K) > S) S = wgrad_stream_blocks(R, N, K);
     return static_cast<size_t>(S) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
@@ -807,12 +809,25 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
         const char* e = getenv("DG_WGRAD");
         return (e && strcmp(e, "mfma32") == 0) ? 0 : (e && strcmp(e, "x6") == 0) ? 1 : 2;
     }();
+    // fp32, fp16 hi + lo arithmetic, the three encoder shapes: producer / consumer kernel (wgrad_stream.hip), every
+    // element converted once per workgroup.  DG_WGRAD=sym keeps the symmetric kernel below (A/B measurements).
+    static const bool stream_kernel = [] {
+        const char* e = getenv("DG_WGRAD");
+        return !(e && strcmp(e, "sym") == 0);
+    }();
+    const bool use_stream = !bf && split == 2 && stream_kernel && !dy_mask_ && wgrad_stream_supported(N, K);
     int tpb;
-    const int S = wgrad_blocks(R, p, &tpb, !bf && split != 0 && p.nt + p.kt == 16 && p.tr % 16 == 0);
+    const int S = use_stream ? wgrad_stream_blocks(R, N, K)
+                             : wgrad_blocks(R, p, &tpb, !bf && split != 0 && p.nt + p.kt == 16 && p.tr % 16 == 0);
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(wgrad_prof_key(R, N, K), stream);
+    if (use_stream) {
+        if (int st = launch_wgrad_stream(static_cast<const float*>(dy_), static_cast<const float*>(x_), part_w, part_b, R, N,
+                                         K, S, stream))
+            return st;
+    } else {
 #define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \
     {                                                                                                            \
         constexpr int tile_bytes = TR_ * ((M_ ? 2 : 1) * NT_ + KT_) * 32 * static_cast<int>(sizeof(T));           \
@@ -855,6 +870,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
 #undef LAUNCH_M
 #undef LAUNCH_X
 #undef LAUNCH
+    }
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;
     const int blocks_w = static_cast<int>((n4 + 15) / 16), blocks_b = db ? (N / 4 + 15) / 16 : 0;
     if (g_batch_on && g_batch_n < 8) {      // the reduce joins the batch (dg_linear_wgrad_batch_end)

@@ -1,0 +1,15 @@
+// Producer / consumer weight-gradient kernel (wgrad_stream.hip), launched by dg_linear_wgrad (linear_wgrad.hip).
+#pragma once
+
+#include "common.h"
+
+namespace dg {
+
+bool wgrad_stream_supported(int N, int K);
+// workgroups (= split-K partials) the launch uses for R rows
+int wgrad_stream_blocks(int64_t R, int N, int K);
+// part_w [blocks][N][K], part_b [blocks][N] (nullable): partial sums, reduced by the caller in a fixed order
+int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
+                        hipStream_t stream);
+
+}  // namespace dg
