@@ -32,7 +32,10 @@ KEYS = [
     ("row_gemm_e128", r"row_gemm_h3_kernel(<1, 1, (false|true), 4>|ILi1ELi1ELb[01]ELi4E)|row_gemm_bf16_kernel(<1, 1>|ILi1ELi1E)"),
     ("ffn", r"ffn_fwd_bf16|ffn_bwd_dx_bf16"),
     ("ffn_wgrad", r"ffn_bwd_dw_bf16"),
-    ("linear_wgrad", r"wgrad_kernel"),
+    ("linear_wgrad_e_n384", r"wgrad_(stream_)?kernel(<(float, )?12, 4,|I(f)?Li12ELi4E)"),
+    ("linear_wgrad_e_k384", r"wgrad_(stream_)?kernel(<(float, )?4, 12,|I(f)?Li4ELi12E)"),
+    ("linear_wgrad_e128", r"wgrad_(stream_)?kernel(<(float, )?4, 4,|I(f)?Li4ELi4E)"),
+    ("linear_wgrad", r"wgrad_kernel|wgrad_stream_kernel"),
     ("ln_bwd", r"ln_bwd_kernel"),
 ]
 
