@@ -43,6 +43,10 @@ SIGNATURES = {
     "dg_row_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dg_row_gemm_mask_words": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "dg_row_gemm": (c_int, [_P] * 3 + [c_int64, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P]),
+    "dg_linear_wgrad3": (c_int, [_P] * 6 + [_P, c_size_t, c_int64, c_int, _P]),
+    "dg_row_gemm_pack3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dg_row_gemm_lin3": (c_int, [_P] * 5 + [c_int64, _P, _P, _P, c_int, _P]),
+    "dg_row_gemm_sum3": (c_int, [_P] * 5 + [c_int64, _P, c_int, _P]),
     "dg_linear_wgrad_batch_begin": (c_int, []),
     "dg_linear_wgrad_batch_end": (c_int, [_P]),
     "dg_skinny_linear_fwd": (c_int, [_P] * 4 + [c_int64, c_int, c_int, c_int, _P]),

@@ -24,7 +24,12 @@ namespace dg {
 
 // fp32 implementations (row_gemm.hip)
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract);
-int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream);
+int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream,
+                      const float* w1 = nullptr, const float* w2 = nullptr);
+int row_gemm_f32_lin3(const float* a, const float* packed, float* y0, float* y1, float* y2, int64_t R, const float* b0,
+                      const float* b1, const float* b2, dg_stream_t stream);
+int row_gemm_f32_sum3(const float* a0, const float* a1, const float* a2, const float* packed, float* y, int64_t R,
+                      const float* residual, dg_stream_t stream);
 size_t row_gemm_f32_mask_words(int64_t R, int K, int N);
 int row_gemm_f32_pack_batch(const void* table, int n, int max_rows_cols, dg_stream_t stream);
 size_t row_gemm_f32_ln_bwd_workspace_bytes();
@@ -64,7 +69,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict
 
 // every stale bf16 pack of a network in one launch: blockIdx.y walks a device table of { w, packed, rows, cols, mode }
 __global__ void pack_bf16_batch_kernel(const long long* __restrict__ table, int mb_size) {
-    const long long* e = table + 5 * static_cast<size_t>(blockIdx.y);
+    const long long* e = table + 7 * static_cast<size_t>(blockIdx.y);      // (entries 5, 6: fp32 stacks only)
     const float* w = reinterpret_cast<const float*>(e[0]);
     bf16x8* p = reinterpret_cast<bf16x8*>(e[1]);
     const int rows = static_cast<int>(e[2]), cols = static_cast<int>(e[3]), mode = static_cast<int>(e[4]);
@@ -299,6 +304,30 @@ extern "C" int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols
     if (dtype == DG_DTYPE_BF16) return pack_bf16(w, packed, rows, cols, mode, 32, static_cast<hipStream_t>(stream_));
     if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack: unknown dtype %d", dtype);
     return row_gemm_f32_pack(w, static_cast<float*>(packed), rows, cols, mode, stream_);
+}
+
+extern "C" int dg_row_gemm_pack3(const float* w0, const float* w1, const float* w2, void* packed, int cols, int mode,
+                                 int dtype, dg_stream_t stream_) {
+    if (!w0 || !w1 || !w2 || !packed) return fail(DG_E_ARG, "dg_row_gemm_pack3: null pointer");
+    if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack3: mode must be 0 (forward) or 1 (dgrad)");
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_SHAPE, "dg_row_gemm_pack3: float32 activations only");
+    if (cols != 128) return fail(DG_E_SHAPE, "dg_row_gemm_pack3: three [128,128] weights (got cols = %d)", cols);
+    return row_gemm_f32_pack(w0, static_cast<float*>(packed), 384, cols, mode, stream_, w1, w2);
+}
+
+extern "C" int dg_row_gemm_lin3(const void* a, const void* packed, void* y0, void* y1, void* y2, int64_t R, const float* b0,
+                                const float* b1, const float* b2, int dtype, dg_stream_t stream_) {
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_SHAPE, "dg_row_gemm_lin3: float32 activations only");
+    return row_gemm_f32_lin3(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y0),
+                             static_cast<float*>(y1), static_cast<float*>(y2), R, b0, b1, b2, stream_);
+}
+
+extern "C" int dg_row_gemm_sum3(const void* a0, const void* a1, const void* a2, const void* packed, void* y, int64_t R,
+                                const void* residual, int dtype, dg_stream_t stream_) {
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_SHAPE, "dg_row_gemm_sum3: float32 activations only");
+    return row_gemm_f32_sum3(static_cast<const float*>(a0), static_cast<const float*>(a1), static_cast<const float*>(a2),
+                             static_cast<const float*>(packed), static_cast<float*>(y), R,
+                             static_cast<const float*>(residual), stream_);
 }
 
 extern "C" size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype) {

@@ -883,3 +883,36 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
                        part_b, static_cast<int64_t>(N / 4), db);
     return check_launch("dg_linear_wgrad");
 }
+
+/* dW [384,128] = [dy0 | dy1 | dy2]^T x, db [384]: the weight gradients of three Linear(128,128) that share their input
+ * (q / k / v of an attention block, reference layers.py:111-113 backward) in ONE launch.  float32; workspace as for
+ * dg_linear_wgrad(R, 384, 128); joins a dg_linear_wgrad_batch like any other call.                                  */
+extern "C" int dg_linear_wgrad3(const void* dy0, const void* dy1, const void* dy2, const void* x, float* dw, float* db,
+                                void* workspace, size_t workspace_bytes, int64_t R, int dtype, dg_stream_t stream_) {
+    if (!dy0 || !dy1 || !dy2 || !x || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad3: null pointer");
+    if (dtype != DG_DTYPE_F32) return fail(DG_E_SHAPE, "dg_linear_wgrad3: float32 activations only");
+    if (R < 1) return fail(DG_E_SHAPE, "dg_linear_wgrad3: R = %lld", (long long)R);
+    constexpr int N = 384, K = 128;
+    if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K)) return fail(DG_E_WORKSPACE, "dg_linear_wgrad3: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int S = wgrad_stream_blocks(R, N, K);
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
+    {
+        ProfScope prof(wgrad_prof_key(R, N, K), stream);
+        if (int st = launch_wgrad_stream(static_cast<const float*>(dy0), static_cast<const float*>(x), part_w, part_b, R, N, K, S,
+                                         stream, static_cast<const float*>(dy1), static_cast<const float*>(dy2)))
+            return st;
+    }
+    const int64_t n4 = static_cast<int64_t>(N) * K / 4;
+    const int blocks_w = static_cast<int>((n4 + 15) / 16), blocks_b = db ? (N / 4 + 15) / 16 : 0;
+    if (g_batch_on && g_batch_n < 8) {
+        RedEntry& en = g_batch.e[g_batch_n++];
+        en.part = part_w; en.part_b = part_b; en.out = dw; en.out_b = db;
+        en.n4 = n4; en.n4_b = N / 4; en.S = S; en.blocks_a = blocks_w; en.blocks = blocks_w + blocks_b;
+        return check_launch("dg_linear_wgrad3");
+    }
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks_w + blocks_b), dim3(256), 0, stream, part_w, S, n4, dw, blocks_w,
+                       part_b, static_cast<int64_t>(N / 4), db);
+    return check_launch("dg_linear_wgrad3");
+}

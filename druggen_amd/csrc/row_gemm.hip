@@ -91,6 +91,13 @@ struct Epilogue {
     // to lnb_part in the layout above (half-waves of the four producer waves).
     const float* lna_pre = nullptr;
     float* lna_dz = nullptr;
+    // Three Linears in one launch (q / k / v of an attention block, reference layers.py:111-113 and their backward):
+    //   128 -> 384, S3 kernels: output slabs 4..7 / 8..11 go to y_alt[0] / y_alt[1] (row pitch 128, like y), their bias
+    //   comes from bias_alt[0] / bias_alt[1];
+    //   384 -> 128, A3 kernels: k-chunks 1 / 2 of the A operand are the [R,128] matrices a_alt[0] / a_alt[1].
+    float* y_alt[2] = {nullptr, nullptr};
+    const float* bias_alt[2] = {nullptr, nullptr};
+    const float* a_alt[2] = {nullptr, nullptr};
 };
 
 // Sum over the 32 lanes of a half-wave, result in every lane.  DPP adds inside each 16-lane row
@@ -556,7 +563,10 @@ __device__ __forceinline__ void split_write_h3(const float4 (&set)[PFN], char* p
 // packed fp16x3 weights: [slab][k-step][plane 0/1][lane] x 8 fp16, then float inv_col_scale[32 * slabs] (one scale
 // per output column over the whole contraction).  One 512-thread workgroup per (32-column slab, 128-wide k
 // chunk): thread = (k-step, lane) keeps its 8 values in registers while the column maxima are reduced through LDS.
-__device__ __forceinline__ void pack_weight_h3_block(const float* __restrict__ w, f16x8* __restrict__ p, int rows, int cols,
+// (w1, w2 non-null: the matrix is the vertical stack [w; w1; w2] of three [128, cols] weights -- q / k / v of an
+// attention block packed as ONE 128 -> 384 forward operand or ONE 384 -> 128 input-gradient operand)
+__device__ __forceinline__ void pack_weight_h3_block(const float* __restrict__ w, const float* __restrict__ w1,
+                                                     const float* __restrict__ w2, f16x8* __restrict__ p, int rows, int cols,
                                                      int mode, int n_tiles, int t, int kcb, int kchunks) {
     __shared__ unsigned part[16][32];
     const int k_steps = 8 * kchunks;
@@ -565,7 +575,14 @@ __device__ __forceinline__ void pack_weight_h3_block(const float* __restrict__ w
     const int n_out = mode == 0 ? rows : cols, kdim = mode == 0 ? cols : rows;
     auto at = [&](int k) -> float {
         if (n >= n_out || k >= kdim) return 0.f;
-        return mode == 0 ? w[static_cast<size_t>(n) * cols + k] : w[static_cast<size_t>(k) * cols + n];
+        int r = mode == 0 ? n : k;
+        const int c = mode == 0 ? k : n;
+        const float* ws = w;
+        if (w1) {
+            ws = r < 128 ? w : (r < 256 ? w1 : w2);
+            r &= 127;
+        }
+        return ws[static_cast<size_t>(r) * cols + c];
     };
     float v[8];
     unsigned mx = 0;
@@ -595,21 +612,24 @@ __device__ __forceinline__ void pack_weight_h3_block(const float* __restrict__ w
     if (kcb == 0 && ks == 0 && lane < 32)
         reinterpret_cast<float*>(p + static_cast<size_t>(n_tiles) * k_steps * 2 * 64)[n] = inv_scale_of(e);
 }
-__global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __restrict__ w, f16x8* __restrict__ p, int rows,
+__global__ __launch_bounds__(512) void pack_weight_h3_kernel(const float* __restrict__ w, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, f16x8* __restrict__ p, int rows,
                                                              int cols, int mode, int n_tiles) {
-    pack_weight_h3_block(w, p, rows, cols, mode, n_tiles, blockIdx.x, blockIdx.y, gridDim.y);
+    pack_weight_h3_block(w, w1, w2, p, rows, cols, mode, n_tiles, blockIdx.x, blockIdx.y, gridDim.y);
 }
 // Every weight of a network in ONE launch (after an optimizer step): blockIdx.z walks a device table of
-// { w, packed, rows, cols, mode } (int64 x 5); blocks outside an entry's (slab, k-chunk) grid leave at once.
+// { w, packed, rows, cols, mode, w1, w2 } (int64 x 7; w1 = w2 = 0 unless the entry is a stack of three weights); blocks
+// outside an entry's (slab, k-chunk) grid leave at once.
 __global__ __launch_bounds__(512) void pack_weight_h3_batch_kernel(const long long* __restrict__ table) {
-    const long long* e = table + 5 * static_cast<size_t>(blockIdx.z);
+    const long long* e = table + 7 * static_cast<size_t>(blockIdx.z);
     const float* w = reinterpret_cast<const float*>(e[0]);
     f16x8* p = reinterpret_cast<f16x8*>(e[1]);
     const int rows = static_cast<int>(e[2]), cols = static_cast<int>(e[3]), mode = static_cast<int>(e[4]);
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
     if (static_cast<int>(blockIdx.x) >= nt || static_cast<int>(blockIdx.y) >= kc) return;      // block-uniform
-    pack_weight_h3_block(w, p, rows, cols, mode, nt, blockIdx.x, blockIdx.y, kc);
+    pack_weight_h3_block(w, reinterpret_cast<const float*>(e[5]), reinterpret_cast<const float*>(e[6]), p, rows, cols, mode,
+                         nt, blockIdx.x, blockIdx.y, kc);
 }
 
 // exact three-way split of a float4 into bf16 planes by truncation: h = top 16 bits of x,
@@ -640,7 +660,7 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& h, u32x2& m, u32x
 // tile accumulate into the same registers; N = 384: the three column groups of a tile run back to back on
 // the same planes.  The B fragments of the current (group, chunk) live in 96 VGPRs; when they change
 // per unit they are double-buffered (the next unit's arrive from L2 during this unit's MFMAs).
-template <int KC, int NG, bool EXCH, int NC = 4, bool LNB = false, bool LNA = false>
+template <int KC, int NG, bool EXCH, int NC = 4, bool LNB = false, bool LNA = false, bool S3 = false>
 __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                              float* __restrict__ y, int64_t R, Epilogue ep) {
     // NC = 6 (N = 384 only): six consumer waves, each with two resident 32-column slabs (w and w + 6: 128 VGPRs
@@ -654,6 +674,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     static_assert(KC == 1, "fp16x3: the row scale covers the whole contraction, K = 128 only");
     static_assert(!LNB || (EXCH && NC == 4 && NG == 1), "LayerNorm-backward epilogue: 128 -> 128 exchange kernel");
     static_assert(!LNA || (!EXCH && !LNB && NC == 4 && NG == 1), "LayerNorm-backward prologue: plain 128 -> 128 kernel");
+    static_assert(!S3 || (NG == 3 && NC == 4 && !EXCH), "three outputs: the streaming-B 128 -> 384 kernel (one column group per Linear)");
     constexpr int DEPTH = LNA ? 2 : 3;      // register sets of A chunks the producers keep in flight
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* lds = smem_raw;                              // 2 x { planes[2][64 rows][272 B], inv_row_scale[64] }
@@ -881,7 +902,12 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int n = 32 * slab_of(g, s) + col;
-            bias_g[g * NS + s] = ep.bias ? ep.bias[n] : 0.f;
+            if (S3) {      // slab / 4 selects the Linear, n & 127 its output channel
+                const float* bp = n < 128 ? ep.bias : ep.bias_alt[(n >> 7) - 1];
+                bias_g[g * NS + s] = bp ? bp[n & 127] : 0.f;
+            } else {
+                bias_g[g * NS + s] = ep.bias ? ep.bias[n] : 0.f;
+            }
             cs_g[g * NS + s] = inv_cs[n];
         }
     float4 res[8];   // EXCH: residual rows of the tile, requested before its MFMAs
@@ -1018,14 +1044,16 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 #pragma unroll
                         for (int i = 0; i < 4; ++i) rowv[i] = ld4(xw + (8 * i + (lane >> 3)) * 32 + 4 * (lane & 7));
                         __builtin_amdgcn_wave_barrier();
-                        float* yr = y + (r0 + 32 * m + (lane >> 3)) * N + 32 * slab + 4 * (lane & 7);
+                        constexpr int LDY = S3 ? 128 : N;      // three [R,128] outputs, or one [R,N]
+                        float* yb = S3 ? (slab < 4 ? y : ep.y_alt[(slab >> 2) - 1]) : y;
+                        float* yr = yb + (r0 + 32 * m + (lane >> 3)) * LDY + 32 * (S3 ? (slab & 3) : slab) + 4 * (lane & 7);
                         if (full) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) st4(yr + static_cast<size_t>(8 * i) * N, rowv[i]);
+                            for (int i = 0; i < 4; ++i) st4(yr + static_cast<size_t>(8 * i) * LDY, rowv[i]);
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (r0 + 32 * m + 8 * i + (lane >> 3) < R) st4(yr + static_cast<size_t>(8 * i) * N, rowv[i]);
+                                if (r0 + 32 * m + 8 * i + (lane >> 3) < R) st4(yr + static_cast<size_t>(8 * i) * LDY, rowv[i]);
                         }
                     }
                     GSTAMP(tS)
@@ -1216,7 +1244,7 @@ __device__ __forceinline__ void wait_b_refill(f16x8& b0, f16x8& b1) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
 }
 
-template <bool EXCH>
+template <bool EXCH, bool A3 = false>
 __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* __restrict__ a, const f16x8* __restrict__ packed,
                                                                   float* __restrict__ y, int64_t R, Epilogue ep) {
     constexpr int KC = 3, K = 384, KS = 24;
@@ -1251,19 +1279,22 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
         float4 pf[3][8];
         // loads of a chunk: uniform 64-bit base (tile, k chunk) + a 32-bit per-lane byte offset; rows past the end
         // of a partial tile are clamped on the offset (row-major, so the row term dominates the comparison)
-        const unsigned voff0 = static_cast<unsigned>(pt >> 5) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
+        // A3: the three k-chunks are three separate [R,128] matrices (row pitch 512 B) instead of column blocks of one [R,384]
+        constexpr int APITCH = A3 ? 512 : K * 4;
+        const unsigned voff0 = static_cast<unsigned>(pt >> 5) * APITCH + static_cast<unsigned>(pt & 31) * 16;
         auto fetch = [&](float4 (&set)[8], int c) {
             if (c > nchunks - 1) c = nchunks - 1;
             int ti, pos;
             chunk_map(c, ti, pos);
             const int64_t r0 = tile_row0(ti);
             const int kc = (pos + rot) % KC;
-            const char* base = reinterpret_cast<const char*>(a) + (r0 * K + kc * 128) * 4;
+            const char* base = A3 ? reinterpret_cast<const char*>(kc == 0 ? a : ep.a_alt[kc - 1]) + r0 * 512
+                                  : reinterpret_cast<const char*>(a) + (r0 * K + kc * 128) * 4;
             const int64_t last = R - 1 - r0;   // >= 0
-            const unsigned lim = last >= kTR - 1 ? 0xFFFFFFFFu : static_cast<unsigned>(last) * (K * 4) + static_cast<unsigned>(pt & 31) * 16;
+            const unsigned lim = last >= kTR - 1 ? 0xFFFFFFFFu : static_cast<unsigned>(last) * APITCH + static_cast<unsigned>(pt & 31) * 16;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                unsigned off = voff0 + i * (8 * K * 4);
+                unsigned off = voff0 + i * (8 * APITCH);
                 off = off < lim ? off : lim;
                 if (DG_DBG & 8) set[i] = f4(static_cast<float>(off & 7));
                 else set[i] = ld4(reinterpret_cast<const float*>(base + off));
@@ -1561,13 +1592,16 @@ size_t row_gemm_f32_packed_floats(int n_out, int k_contract) {
     return nt * kc * 16 * 64 * 4;
 }
 
-int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream_) {
+int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream_,
+                      const float* w1, const float* w2) {
     if (!w || !packed) return fail(DG_E_ARG, "dg_row_gemm_pack: null pointer");
+    if ((w1 || w2) && (!w1 || !w2 || rows != 384 || !use_x6()))
+        return fail(DG_E_ARG, "dg_row_gemm_pack3: needs three [128, cols] weights (and the fp16 hi+lo row GEMM)");
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
     if (use_x6()) {
-        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3(nt, kc), dim3(512), 0, static_cast<hipStream_t>(stream_), w,
+        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3(nt, kc), dim3(512), 0, static_cast<hipStream_t>(stream_), w, w1, w2,
                            reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt);
         return check_launch("dg_row_gemm_pack");
     }
@@ -1743,6 +1777,62 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
     if ((dgamma || dbeta) && !(dgamma && dbeta == dgamma + 128 && reduce_batch_try_add(ep.lnb_part, seqs * 8, 256, dgamma)))
         launch_ln_finish(ep.lnb_part, seqs * 8, 2, 128, dgamma, dbeta, stream);
     return check_launch("dg_row_gemm_ln_bwd_in");
+}
+
+
+// Three Linears that share their input in ONE launch: y_i = a W_i^T + b_i (q / k / v of an attention block, reference
+// layers.py:111-113; also their transposed use in the second order).  `packed`: dg_row_gemm_pack3(mode 0).
+int row_gemm_f32_lin3(const float* a, const float* packed, float* y0, float* y1, float* y2, int64_t R, const float* b0,
+                      const float* b1, const float* b2, dg_stream_t stream_) {
+    if (!a || !packed || !y0 || !y1 || !y2) return fail(DG_E_ARG, "dg_row_gemm_lin3: null pointer");
+    if (R < 0) return fail(DG_E_SHAPE, "dg_row_gemm_lin3: negative row count");
+    if (!use_x6()) return fail(DG_E_ARG, "dg_row_gemm_lin3: needs the fp16 hi+lo row GEMM (DG_ROW_GEMM=mfma32 is set)");
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Epilogue ep{b0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    ep.y_alt[0] = y1;
+    ep.y_alt[1] = y2;
+    ep.bias_alt[0] = b1;
+    ep.bias_alt[1] = b2;
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
+    // profiler / roofline: an edge-level launch of this kernel is a 128 -> 384 launch
+    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_N384, stream);
+    // the column-group kernel (B fragments streamed per group: these launches are node-level, one or two tiles per
+    // workgroup, where residency buys nothing; the resident-B instance with three outputs spills 168 B / lane)
+    constexpr int lds3 = kH3Lds + 4 * 32 * 32 * 4;
+    DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 3, false, 4, false, false, true>), lds3);
+    hipLaunchKernelGGL((row_gemm_h3_kernel<1, 3, false, 4, false, false, true>), dim3(seqs), dim3(512), lds3, stream, a,
+                       reinterpret_cast<const f16x8*>(packed), y0, R, ep);
+    return check_launch("dg_row_gemm_lin3");
+}
+
+// y = a0 B0 + a1 B1 + a2 B2 (+ residual): the input gradient of those three Linears in ONE launch -- a 384 -> 128
+// contraction whose k-chunks are three separate [R,128] matrices.  `packed`: dg_row_gemm_pack3(mode 1).
+int row_gemm_f32_sum3(const float* a0, const float* a1, const float* a2, const float* packed, float* y, int64_t R,
+                      const float* residual, dg_stream_t stream_) {
+    if (!a0 || !a1 || !a2 || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm_sum3: null pointer");
+    if (R < 0) return fail(DG_E_SHAPE, "dg_row_gemm_sum3: negative row count");
+    if (!use_x6()) return fail(DG_E_ARG, "dg_row_gemm_sum3: needs the fp16 hi+lo row GEMM (DG_ROW_GEMM=mfma32 is set)");
+    if (R == 0) return 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Epilogue ep{nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    ep.a_alt[0] = a1;
+    ep.a_alt[1] = a2;
+    const int64_t tiles = (R + kTR - 1) / kTR;
+    const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
+    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_K384, stream);
+    constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;
+    if (residual) {
+        DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<true, true>), lds384);
+        hipLaunchKernelGGL((row_gemm_h3_k384_kernel<true, true>), dim3(seqs), dim3(512), lds384, stream, a0,
+                           reinterpret_cast<const f16x8*>(packed), y, R, ep);
+    } else {
+        DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<false, true>), lds384);
+        hipLaunchKernelGGL((row_gemm_h3_k384_kernel<false, true>), dim3(seqs), dim3(512), lds384, stream, a0,
+                           reinterpret_cast<const f16x8*>(packed), y, R, ep);
+    }
+    return check_launch("dg_row_gemm_sum3");
 }
 
 }  // namespace dg

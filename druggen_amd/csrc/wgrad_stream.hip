@@ -63,6 +63,8 @@ constexpr int kHdr = 2 * kStageBytes;              // tags [2][4] u32, then rati
 
 template <int NT, int KT, int CN, int CK>
 __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_kernel(const float* __restrict__ dy,
+                                                                                     const float* __restrict__ dy1,
+                                                                                     const float* __restrict__ dy2,
                                                                                      const float* __restrict__ x,
                                                                                      float* __restrict__ part_w,
                                                                                      float* __restrict__ part_b, int64_t R) {
@@ -92,9 +94,12 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         __builtin_amdgcn_s_setprio(3);
         const int p = w - kConsumers;
         const bool is_dy = p * CW < N;
-        const float* src = is_dy ? dy : x;
-        const int LD = is_dy ? N : K;
-        const int coff = is_dy ? p * CW : p * CW - N;
+        // dy1 / dy2 non-null (N = 384, CW = 128): the three 128-column blocks of dy are three separate [R,128] matrices
+        // (dq, dk, dv of an attention block: one launch gives the stacked weight gradient of q / k / v)
+        const bool three = dy1 != nullptr && is_dy;
+        const float* src = three ? (p == 0 ? dy : (p == 1 ? dy1 : dy2)) : (is_dy ? dy : x);
+        const int LD = three ? 128 : (is_dy ? N : K);
+        const int coff = three ? 0 : (is_dy ? p * CW : p * CW - N);
         const int cq = lane % LPR, rg = lane / LPR;
         const unsigned voff0 = static_cast<unsigned>((8 * rg) * LD + coff + 4 * cq) * 4u;
         const int rowb = LD * 4;
@@ -353,13 +358,15 @@ int wgrad_stream_blocks(int64_t R, int N, int K) {
 }
 
 int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream) {
+                        hipStream_t stream, const float* dy1, const float* dy2) {
+    if ((dy1 || dy2) && (!dy1 || !dy2 || N != 384 || K != 128))
+        return fail(DG_E_ARG, "wgrad_stream: three dy matrices need N = 384, K = 128");
     const int lds = kHdr + 64 + 3 * (N + K) * 4;
 #define DG_WS_LAUNCH(NT_, KT_, CN_, CK_)                                                                          \
     {                                                                                                            \
         DG_OPT_IN_LDS((&wgrad_stream_kernel<NT_, KT_, CN_, CK_>), lds);                                           \
         hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_>), dim3(blocks), dim3(64 * (kConsumers + kProducers)), \
-                           lds, stream, dy, x, part_w, part_b, R);                                              \
+                           lds, stream, dy, dy1, dy2, x, part_w, part_b, R);                                    \
     }
     if (N == 128 && K == 128) DG_WS_LAUNCH(4, 4, 4, 2)
     else if (N == 384 && K == 128) DG_WS_LAUNCH(12, 4, 4, 2)

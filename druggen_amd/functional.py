@@ -370,6 +370,8 @@ def _wgrad_many(items, open_batch=True):
     of an attention block used to cost six reduce launches.  Shapes outside the MFMA kernel take their usual path."""
     lib = _lib.load()
     ref = items[0][0]
+    if any(isinstance(dy, tuple) for dy, _, _ in items):      # a (dq, dk, dv) triple: one stacked [384,128] gradient
+        return _wgrad_many_mixed(items, open_batch)
     ok = (ref.is_cuda and len(items) <= 8 and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
           and all(dy.dtype == x.dtype and dy.shape[1] > 16 and x.shape[1] > 16 for dy, x, _ in items))
     needs = [int(lib.dg_linear_wgrad_workspace_bytes(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _ in items] if ok else []
@@ -393,6 +395,27 @@ def _wgrad_many(items, open_batch=True):
         with _reduce_batch(ref, on=open_batch):
             for (dy, x, b), off, n in zip(items, offs, needs):
                 out.append(_wgrad(dy, x, b, ws=ws[off:off + n]))
+    return out
+
+
+def _wgrad_many_mixed(items, open_batch=True):
+    """``_wgrad_many`` when an item's dy is a 3-tuple of [R,128] float32 matrices sharing x (``_wgrad3``).  Same batching:
+    private workspaces, one reduce launch."""
+    lib = _lib.load()
+    ref = items[0][1]
+    needs = [int(lib.dg_linear_wgrad_workspace_bytes(x.shape[0], 384 if isinstance(dy, tuple) else dy.shape[1], x.shape[1]))
+             for dy, x, _ in items]
+    offs, total = [], 0
+    for n in needs:
+        offs.append(total)
+        total += (n + 255) // 256 * 256
+    out = []
+    with _dev(ref):
+        ws = _scratch(ref, total, "wgrad_batch")
+        batch = open_batch and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
+        with _reduce_batch(ref, on=batch):
+            for (dy, x, b), off, n in zip(items, offs, needs):
+                out.append(_wgrad3(dy, x, b, ws=ws[off:off + n]) if isinstance(dy, tuple) else _wgrad(dy, x, b, ws=ws[off:off + n]))
     return out
 
 
@@ -602,6 +625,82 @@ def packed_weight(w, mode: int, dtype=torch.float32):
     return packed
 
 
+_pack3_cache = {}
+
+
+def packed_weight3(w0, w1, w2, mode: int):
+    """``packed_weight`` for the vertical stack [w0; w1; w2] of three float32 [128,128] weights (q / k / v of an attention
+    block) as ONE operand: mode 0 -> the 128 -> 384 forward operand of ``lin3``, mode 1 -> the 384 -> 128 input-gradient
+    operand of ``sum3`` (dg_row_gemm_pack3).  Cached per (storages, versions) like ``packed_weight``."""
+    key = (id(w0), id(w1), id(w2), mode)
+    ws = (w0, w1, w2)
+    hit = _pack3_cache.get(key)
+    if (hit is not None and all(r() is w for r, w in zip(hit[0], ws)) and hit[1] == tuple(w._version for w in ws)
+            and hit[3] == tuple(w.data_ptr() for w in ws) and hit[4] == _weights_epoch):
+        return hit[2]
+    if len(_pack3_cache) > 1024:
+        for k in [k for k, v in _pack3_cache.items() if any(r() is None for r in v[0])]:
+            del _pack3_cache[k]
+    lib = _lib.load()
+    n_out, k = (384, 128) if mode == 0 else (128, 384)
+    packed = torch.empty(int(lib.dg_row_gemm_packed_bytes(n_out, k, 0)), dtype=torch.uint8, device=w0.device)
+    wd = [_c(w.detach()) for w in ws]
+    with _dev(w0):
+        _lib.check(lib.dg_row_gemm_pack3(_lib.fptr(wd[0]), _lib.fptr(wd[1]), _lib.fptr(wd[2]), packed.data_ptr(), 128, mode, 0,
+                                         _lib.stream_of(w0)), "dg_row_gemm_pack3")
+    _pack3_cache[key] = (tuple(weakref.ref(w) for w in ws), tuple(w._version for w in ws), packed,
+                         tuple(w.data_ptr() for w in ws), _weights_epoch)
+    return packed
+
+
+def lin3_supported(x2, ws) -> bool:
+    """Three Linear(128,128) per launch (dg_row_gemm_lin3 / _sum3, dg_linear_wgrad3): float32 rows on the fp16 hi + lo
+    kernels.  DG_QKV=separate keeps three launches (A/B measurements)."""
+    return (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[-1] == 128 and _h3_row_gemm()
+            and all(tuple(w.shape) == (128, 128) and w.dtype == torch.float32 for w in ws)
+            and os.environ.get("DG_QKV", "fused") != "separate")
+
+
+def lin3(x2, ws, bs):
+    """(x2 w0^T + b0, x2 w1^T + b1, x2 w2^T + b2) in one launch; ``bs`` entries may be None."""
+    R = x2.shape[0]
+    lib = _lib.load()
+    ys = [torch.empty(R, 128, dtype=x2.dtype, device=x2.device) for _ in range(3)]
+    with _dev(x2):
+        _lib.check(lib.dg_row_gemm_lin3(_lib.ptr(x2), packed_weight3(*ws, 0).data_ptr(), _lib.ptr(ys[0]), _lib.ptr(ys[1]),
+                                        _lib.ptr(ys[2]), R, _lib.fptr(bs[0]), _lib.fptr(bs[1]), _lib.fptr(bs[2]), 0,
+                                        _lib.stream_of(x2)), "dg_row_gemm_lin3")
+    _account(_gemm_key(R, 128, 384), 4 * R * (128 + 384), 2 * R * 128 * 384)
+    return ys
+
+
+def sum3(a0, a1, a2, ws, residual=None):
+    """a0 w0 + a1 w1 + a2 w2 (+ residual): the input gradient of three Linears that share their input, one launch."""
+    R = a0.shape[0]
+    lib = _lib.load()
+    y = torch.empty(R, 128, dtype=a0.dtype, device=a0.device)
+    with _dev(a0):
+        _lib.check(lib.dg_row_gemm_sum3(_lib.ptr(a0), _lib.ptr(a1), _lib.ptr(a2), packed_weight3(*ws, 1).data_ptr(), _lib.ptr(y),
+                                        R, _lib.ptr(residual), 0, _lib.stream_of(a0)), "dg_row_gemm_sum3")
+    _account(_gemm_key(R, 384, 128), 4 * R * (384 + 128 * (1 + (residual is not None))), 2 * R * 384 * 128)
+    return y
+
+
+def _wgrad3(dys, x2, want_bias, ws=None):
+    """dW [384,128] = [dy0 | dy1 | dy2]^T x2 (+ db [384]): three weight gradients in one launch (dg_linear_wgrad3)."""
+    R = x2.shape[0]
+    lib = _lib.load()
+    dw = torch.empty(384, 128, dtype=torch.float32, device=x2.device)
+    db = torch.empty(384, dtype=torch.float32, device=x2.device) if want_bias else None
+    with _dev(x2):
+        if ws is None:
+            ws = _scratch(x2, int(lib.dg_linear_wgrad_workspace_bytes(R, 384, 128)), "wgrad")
+        _lib.check(lib.dg_linear_wgrad3(_lib.ptr(dys[0]), _lib.ptr(dys[1]), _lib.ptr(dys[2]), _lib.ptr(x2), _lib.ptr(dw),
+                                        _lib.ptr(db), ws.data_ptr(), ws.numel(), R, 0, _lib.stream_of(x2)), "dg_linear_wgrad3")
+    _account(_wgrad_key(R, 384, 128), 4 * R * (384 + 128), 2 * R * 384 * 128)
+    return dw, db
+
+
 _repack_tables = {}
 
 
@@ -617,36 +716,53 @@ def repack_params(params) -> int:
     ids = {id(p) for p in params}
     total = 0
     for dtype in (torch.float32, torch.bfloat16):
-        entries = []
+        entries = []      # (cache, key, weights, packed, mode)
         for key, hit in _pack_cache.items():
             if key[0] in ids and key[2] == dtype:
                 w = hit[0]()
                 if (w is not None and w.is_cuda and w.is_contiguous() and hit[3] == w.data_ptr()
                         and (dtype == torch.float32 or (w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0))):
-                    entries.append((key, w, hit[2]))
+                    entries.append((_pack_cache, key, (w,), hit[2], key[1]))
+        if dtype == torch.float32:
+            for key, hit in _pack3_cache.items():      # stacks of three weights (q / k / v)
+                if key[0] in ids:
+                    ws = tuple(r() for r in hit[0])
+                    if (all(w is not None and w.is_cuda and w.is_contiguous() for w in ws)
+                            and hit[3] == tuple(w.data_ptr() for w in ws)):
+                        entries.append((_pack3_cache, key, ws, hit[2], key[3]))
         if len(entries) >= 2:
             total += _repack_entries(entries, dtype)
     return total
 
 
 def _repack_entries(entries, dtype) -> int:
-    dev = entries[0][1].device
-    entries = [e for e in entries if e[1].device == dev]
-    sig = (dev, dtype, tuple(k for k, _, _ in entries), tuple(p.data_ptr() for _, _, p in entries))
+    dev = entries[0][2][0].device
+    entries = [e for e in entries if e[2][0].device == dev]
+    sig = (dev, dtype, tuple((id(c), k) for c, k, _, _, _ in entries), tuple(p.data_ptr() for _, _, _, p, _ in entries))
     tab = _repack_tables.get(sig)
     if tab is None:
         if len(_repack_tables) > 16:
             _repack_tables.clear()
-        rows = [[w.data_ptr(), packed.data_ptr(), w.shape[0], w.shape[1], key[1]] for key, w, packed in entries]
+        rows = []
+        for _, _, ws, packed, mode in entries:
+            if len(ws) == 1:
+                rows.append([ws[0].data_ptr(), packed.data_ptr(), ws[0].shape[0], ws[0].shape[1], mode, 0, 0])
+            else:      # [w0; w1; w2]: 384 stacked rows
+                rows.append([ws[0].data_ptr(), packed.data_ptr(), 384, ws[0].shape[1], mode, ws[1].data_ptr(), ws[2].data_ptr()])
         tab = torch.tensor(rows, dtype=torch.int64, device=dev)
         _repack_tables[sig] = tab
     lib = _lib.load()
-    w0 = entries[0][1]
+    w0 = entries[0][2][0]
     with _dev(w0):
-        _lib.check(lib.dg_row_gemm_pack_batch(tab.data_ptr(), len(entries), max(max(w.shape) for _, w, _ in entries),
+        _lib.check(lib.dg_row_gemm_pack_batch(tab.data_ptr(), len(entries),
+                                              max(384 if len(ws) == 3 else max(ws[0].shape) for _, _, ws, _, _ in entries),
                                               _lib.DTYPES[dtype], _lib.stream_of(w0)), "dg_row_gemm_pack_batch")
-    for key, w, packed in entries:
-        _pack_cache[key] = (weakref.ref(w), w._version, packed, w.data_ptr(), _weights_epoch)
+    for cache, key, ws, packed, _ in entries:
+        if len(ws) == 1:
+            cache[key] = (weakref.ref(ws[0]), ws[0]._version, packed, ws[0].data_ptr(), _weights_epoch)
+        else:
+            cache[key] = (tuple(weakref.ref(w) for w in ws), tuple(w._version for w in ws), packed,
+                          tuple(w.data_ptr() for w in ws), _weights_epoch)
     return len(entries)
 
 
@@ -1181,9 +1297,12 @@ class _AttnBlock(Function):
         x1f, yf = _c(x1).reshape(-1, C), _c(y).reshape(-1, C)
         adt = x1f.dtype
         pw = lambda w_, m_: packed_weight(w_, m_, adt)
-        q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
-        k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
-        v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
+        if lin3_supported(x1f, (wq, wk, wv)):      # q, k, v share their input: one launch
+            q, k, v = lin3(x1f, (wq, wk, wv), (bq, bk, bv))
+        else:
+            q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
+            k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
+            v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
         e = row_gemm(yf, pw(we, 0), C, C, bias=be)
         lib = _lib.load()
         s = torch.empty_like(e) if need_edge else None
@@ -1349,19 +1468,29 @@ class _AttnBlockBwd(Function):
             dzp, dgp, dbp = row_gemm_ln_bwd(def_, pw(we, 1), C, dz4, ppre, pgamma, pmean, prstd)
         elif want_y:
             dy = row_gemm(def_, pw(we, 1), C, C, residual=dz4).view(y.shape)      # + ln4 residual path
-        if want_x:
+        use3 = lin3_supported(dqf, (wq, wk, wv))      # dq Wq + dk Wk + dv Wv and the three weight gradients: one launch each
+        if want_x and use3:
+            dx1 = sum3(dqf, dkf, dvf, (wq, wk, wv), residual=dz3).view(x1.shape)   # + ln3 residual path
+        elif want_x:
             t = row_gemm(dqf, pw(wq, 1), C, C, residual=dz3)                       # + ln3 residual path
             t = row_gemm(dkf, pw(wk, 1), C, C, residual=t)
             dx1 = row_gemm(dvf, pw(wv, 1), C, C, residual=t).view(x1.shape)
         gw = [None] * 12
         if wants_w:
-            items = [(dqf, x1f, True), (dkf, x1f, True), (dvf, x1f, True), (def_, yf, True), (dz3, o, True)]
+            qkv_items = [((dqf, dkf, dvf), x1f, True)] if use3 else [(dqf, x1f, True), (dkf, x1f, True), (dvf, x1f, True)]
+            items = qkv_items + [(def_, yf, True), (dz3, o, True)]
             if need_edge:
                 items.append((dz4, s, True))
             res = _wgrad_many(items, open_batch=not inb)
-            (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]), (gw[6], gw[7]), (gw[10], gw[11]) = res[:5]
+            if use3:      # rows 0..127 / 128..255 / 256..383 of the stacked gradient
+                (w3, b3), res = res[0], res[1:]
+                gw[0:6] = [w3[0:128], b3[0:128], w3[128:256], b3[128:256], w3[256:384], b3[256:384]]
+            else:
+                (gw[0], gw[1]), (gw[2], gw[3]), (gw[4], gw[5]) = res[:3]
+                res = res[3:]
+            (gw[6], gw[7]), (gw[10], gw[11]) = res[:2]
             if need_edge:
-                gw[8], gw[9] = res[5]
+                gw[8], gw[9] = res[2]
         ctx.save_for_backward(x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3,
                               mean4, rstd4, pre4, dx2f, dy2f, dz3, dz4, do, ds, dq, dk, dv, de)
         ctx.cfg = (alpha, need_edge, (B, N, C), dx2.shape, None if dy2 is None else dy2.shape)
@@ -1389,9 +1518,13 @@ class _AttnBlockBwd(Function):
         tyf = _c(cast(ty)).reshape(-1, C) if ty is not None else torch.zeros(RE, C, dtype=adt, device=q.device)
         dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
         # adjoints of dq, dk, dv, de (dx1 = dz3 + dq Wq + dk Wk + dv Wv ; dy = dz4 + de We)
-        tq = row_gemm(t1f, pw(wq, 0), C, C)
-        tk = row_gemm(t1f, pw(wk, 0), C, C)
-        tv = row_gemm(t1f, pw(wv, 0), C, C)
+        use3 = lin3_supported(t1f, (wq, wk, wv))
+        if use3:
+            tq, tk, tv = lin3(t1f, (wq, wk, wv), (None, None, None))
+        else:
+            tq = row_gemm(t1f, pw(wq, 0), C, C)
+            tk = row_gemm(t1f, pw(wk, 0), C, C)
+            tv = row_gemm(t1f, pw(wv, 0), C, C)
         te = row_gemm(tyf, pw(we, 0), C, C)
         qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         gq, gk, gv, ge, gws, gwo = _attn_bwd2_launch(qv, kv, vv, ev, ds, do, tq.view(B, N, C), tk.view(B, N, C),
@@ -1405,13 +1538,20 @@ class _AttnBlockBwd(Function):
             z4bar, dy2bar, g4bar = _ln_bwd2_rows(pre4, g4, mean4, rstd4, dy2f, adz4)
         gW = [None] * 12
         if with_w:
-            items = [(dqf, t1f, False), (dkf, t1f, False), (dvf, t1f, False), (def_, tyf, False), (dz3, gwo.view(-1, C), False)]
+            qkv_items = [((dqf, dkf, dvf), t1f, False)] if use3 else [(dqf, t1f, False), (dkf, t1f, False), (dvf, t1f, False)]
+            items = qkv_items + [(def_, tyf, False), (dz3, gwo.view(-1, C), False)]
             if need_edge:
                 items.append((dz4, gws.view(-1, C), False))
             res = _wgrad_many(items)
-            gW[0], gW[2], gW[4], gW[6], gW[10] = (r[0] for r in res[:5])
+            if use3:
+                w3, res = res[0][0], res[1:]
+                gW[0], gW[2], gW[4] = w3[0:128], w3[128:256], w3[256:384]
+            else:
+                gW[0], gW[2], gW[4] = (r[0] for r in res[:3])
+                res = res[3:]
+            gW[6], gW[10] = res[0][0], res[1][0]
             if need_edge:
-                gW[8] = res[5][0]
+                gW[8] = res[2][0]
         # The outputs depend on x1 / y only through the forward intermediates: their adjoints
         # (z3bar, z4bar at the pre-LayerNorm sums; gq, gk, gv, ge) go to the forward node.
         # inputs: x1, y, wq,bq, wk,bk, wv,bv, we,be, woe,boe, won,bon, g3, g4, q,k,v,e, s,o,

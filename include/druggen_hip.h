@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 215            /* 0.2.1: + fused attention half (dg_attn_half_*) */
+#define DG_VERSION 216            /* 0.2.2: + three Linears per launch (dg_row_gemm_lin3 / _sum3 / _pack3, dg_linear_wgrad3) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -167,6 +167,13 @@ int dg_linear_wgrad(const void* dy, const void* dy_mask, const void* x, float* d
                     void* workspace, size_t workspace_bytes,
                     int64_t R, int N, int K, int dtype, dg_stream_t stream);
 
+/* dW [384,128] = [dy0 | dy1 | dy2]^T x and db [384] (nullable): the weight gradients of three Linear(128,128) that share
+ * their input x [R,128] -- q / k / v of an attention block (layers.py:111-113 backward) -- in ONE launch; rows 0..127 /
+ * 128..255 / 256..383 of dW (and of db) are the three gradients.  float32 only (others DG_E_SHAPE); workspace as for
+ * dg_linear_wgrad(R, 384, 128).                                                                                     */
+int dg_linear_wgrad3(const void* dy0, const void* dy1, const void* dy2, const void* x, float* dw, float* db,
+                     void* workspace, size_t workspace_bytes, int64_t R, int dtype, dg_stream_t stream);
+
 /* Deferred reduces: between _batch_begin() and _batch_end() every dg_linear_wgrad call with N > 16 only runs its
  * split-K kernel and records its fixed-order reduce; _batch_end() runs up to 8 recorded reduces in ONE launch (a 9th
  * call reduces at once).  Each call of a batch needs its OWN workspace; dw / db are complete after _batch_end().  The
@@ -199,9 +206,23 @@ int dg_linear_wgrad_batch_end(dg_stream_t stream);
 size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype);
 int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols, int mode, int dtype, dg_stream_t stream);
 /* Many packs in one launch (after an optimizer step every weight of the network is stale at once): `table` is a DEVICE
- * array of n entries { const float* w; void* packed; int64 rows; int64 cols; int64 mode } (5 x int64 each), max_dim >=
- * every rows / cols; for DG_DTYPE_BF16 every rows / cols must be a multiple of 32.                                    */
+ * array of n entries { const float* w; void* packed; int64 rows; int64 cols; int64 mode; const float* w1; const float*
+ * w2 } (7 x int64 each; w1 = w2 = NULL except for a dg_row_gemm_pack3 stack, where rows = 384), max_dim >= every rows /
+ * cols; for DG_DTYPE_BF16 every rows / cols must be a multiple of 32 (and w1 / w2 are ignored).                      */
 int dg_row_gemm_pack_batch(const void* table, int n, int max_dim, int dtype, dg_stream_t stream);
+/* Three Linear(128,128) that share their input (q / k / v of an attention block, layers.py:111-113) as ONE operand:
+ *   dg_row_gemm_pack3   the vertical stack [w0; w1; w2] ([384,128]) packed like dg_row_gemm_pack (mode 0: the 128 -> 384
+ *                       forward operand; mode 1: the 384 -> 128 input-gradient operand); dg_row_gemm_packed_bytes(384, 128)
+ *                       resp. (128, 384) bytes;
+ *   dg_row_gemm_lin3    y_i [R,128] = a [R,128] . w_i^T + b_i (b_i nullable), i = 0..2, one launch (mode-0 pack);
+ *   dg_row_gemm_sum3    y [R,128] = a0 . w0 + a1 . w1 + a2 . w2 (+ residual [R,128], nullable), one launch (mode-1 pack).
+ * float32 activations only (DG_E_SHAPE otherwise: callers keep three dg_row_gemm launches for bfloat16).              */
+int dg_row_gemm_pack3(const float* w0, const float* w1, const float* w2, void* packed, int cols, int mode, int dtype,
+                      dg_stream_t stream);
+int dg_row_gemm_lin3(const void* a, const void* packed, void* y0, void* y1, void* y2, int64_t R, const float* b0,
+                     const float* b1, const float* b2, int dtype, dg_stream_t stream);
+int dg_row_gemm_sum3(const void* a0, const void* a1, const void* a2, const void* packed, void* y, int64_t R,
+                     const void* residual, int dtype, dg_stream_t stream);
 size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype);
 int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N,
                 const float* bias, int relu, unsigned* relu_bits_out, const unsigned* mask_bits,

@@ -159,6 +159,50 @@ def test_batched_repack_equals_single_packs(dtype):
     assert torch.equal(keep, keep0)
 
 
+@pytest.mark.parametrize("R", [1, 63, 200, 4097, 23040])
+def test_three_linears_per_launch_match_three_launches(R):
+    """q / k / v of an attention block (reference layers.py:111-113) as ONE launch per direction: dg_row_gemm_lin3 (three
+    outputs), dg_row_gemm_sum3 (dq Wq + dk Wk + dv Wv + residual), dg_linear_wgrad3 (stacked [384,128] weight gradient)
+    against the fp64 contractions AND against the three separate launches; the stacked packs refreshed by the batched
+    repack equal fresh packs."""
+    from druggen_amd import functional as dgf
+    ws = [(_gen((128, 128), 30 + i) * 0.2).float().cuda() for i in range(3)]
+    bs = [_gen((128,), 40 + i).float().cuda() for i in range(3)]
+    x = _gen((R, 128), 50).float().cuda()
+    dys = [_gen((R, 128), 60 + i).float().cuda() for i in range(3)]
+    res = _gen((R, 128), 70).float().cuda()
+    assert dgf.lin3_supported(x, ws)
+    ys = dgf.lin3(x, ws, bs)
+    for y, w, b in zip(ys, ws, bs):
+        assert _rel(y, x.double().cpu() @ w.double().cpu().t() + b.double().cpu()) < TOL
+        one = dgf.row_gemm(x, dgf.packed_weight(w, 0), 128, 128, bias=b)
+        assert _rel(y, one.double().cpu()) < 2e-6
+    nb = dgf.lin3(x, ws, (None, None, None))
+    assert _rel(nb[1], x.double().cpu() @ ws[1].double().cpu().t()) < TOL
+    want = sum(d.double().cpu() @ w.double().cpu() for d, w in zip(dys, ws))
+    assert _rel(dgf.sum3(*dys, ws), want) < TOL
+    assert _rel(dgf.sum3(*dys, ws, residual=res), want + res.double().cpu()) < TOL
+    dw, db = dgf._wgrad3(dys, x, True)
+    for i, d in enumerate(dys):
+        assert _rel(dw[128 * i:128 * (i + 1)], d.double().cpu().t() @ x.double().cpu()) < TOL
+        assert _rel(db[128 * i:128 * (i + 1)], d.double().cpu().sum(0)) < TOL
+        one, _ = dgf._wgrad(d, x, True)
+        assert _rel(dw[128 * i:128 * (i + 1)], one.double().cpu()) < 2e-6
+    dw2, _ = dgf._wgrad3(dys, x, False)
+    assert torch.equal(dw, dw2)
+    # an "optimizer step", then the batched repack of everything cached for these weights
+    packs = [(m, dgf.packed_weight3(*ws, m)) for m in (0, 1)]
+    for w in ws:
+        w.mul_(1.25).add_(0.01)
+    assert dgf.repack_params(ws) >= 2
+    for m, p in packs:
+        again = dgf.packed_weight3(*ws, m)
+        assert again.data_ptr() == p.data_ptr()
+        dgf._pack3_cache.pop((id(ws[0]), id(ws[1]), id(ws[2]), m))
+        assert torch.equal(dgf.packed_weight3(*ws, m), p)
+    assert _rel(dgf.lin3(x, ws, bs)[2], x.double().cpu() @ ws[2].double().cpu().t() + bs[2].double().cpu()) < TOL
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
