@@ -25,6 +25,17 @@
 #include "bf16.h"
 #include "wgrad_stream.h"
 
+// Developer builds only (-DWS_DBG=<bits>, loaded through DG_LIB; scripts/build_variant.sh): ablations that time the
+// kernel with a phase removed -- 1: no MFMAs, 2: raw stores instead of the hi / lo split, 4: no LDS writes, 8: no
+// fragment reads, 16: no global loads.  The shipped library is built with WS_DBG = 0: every such block folds away.
+// Measured at R = 518 400, 384 x 128 (profiles/r04_wgrad_ablation.txt): full 268-272 us; without MFMAs 211-215 (the
+// same with the split, the LDS writes and the fragment reads removed as well: the load stream alone); without global
+// loads 147; nothing but barriers + partial sums + the reduce launch 59.  Refilling each row pair's registers right
+// after its split (loads issued ~60 % earlier) measured 279 vs 270 us: the stream is not starved for issue slots --
+// the MFMA phase costs clock (1.5 GHz against 1.93 GHz for the 128 x 128 shape, SQ_BUSY_CU_CYCLES / duration).
+#ifndef WS_DBG
+#define WS_DBG 0
+#endif
 namespace dg {
 namespace {
 
@@ -132,8 +143,10 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(src) + r0 * LD, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff0, i * rowb, 0));
+            for (int i = 0; i < 8; ++i) {
+                if (WS_DBG & 16) set[i] = f4(static_cast<float>(i + t));
+                else set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff0, i * rowb, 0));
+            }
         };
         auto process = [&](float4 (&set)[8], int t) {
             const bool live = t < T;
@@ -175,12 +188,21 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     unsigned h, l;
-                    ws_split2(comp4(set[2 * pr], j), comp4(set[2 * pr + 1], j), sc[j], h, l);
+                    if (WS_DBG & 2) {
+                        h = __float_as_uint(comp4(set[2 * pr], j));
+                        l = __float_as_uint(comp4(set[2 * pr + 1], j));
+                    } else {
+                        ws_split2(comp4(set[2 * pr], j), comp4(set[2 * pr + 1], j), sc[j], h, l);
+                    }
                     hw[pr] = h;
                     lw[pr] = l;
                 }
-                *reinterpret_cast<u32x4*>(st + wa[j]) = hw;
-                *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
+                if (WS_DBG & 4) {
+                    asm volatile("" ::"v"(hw), "v"(lw));
+                } else {
+                    *reinterpret_cast<u32x4*>(st + wa[j]) = hw;
+                    *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
+                }
             }
             if (part_b && is_dy && live) {
 #pragma unroll
@@ -255,6 +277,13 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                 const char* st = smem + (t & 1) * kStageBytes;
                 f16x8 yh[TN], yl[TN], xh[TK], xl[TK];
                 auto read_frags = [&](int u) {
+                    if (WS_DBG & 8) {
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) yh[i] = yl[i] = f16x8{};
+#pragma unroll
+                        for (int j = 0; j < TK; ++j) xh[j] = xl[j] = f16x8{};
+                        return;
+                    }
 #pragma unroll
                     for (int i = 0; i < TN; ++i) {
                         yh[i] = *reinterpret_cast<const f16x8*>(st + off_y + (u * NTILES + i) * 2048);
@@ -288,9 +317,11 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
 #pragma unroll
                         for (int i = 0; i < TN; ++i)
 #pragma unroll
-                            for (int j = 0; j < TK; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? yl[i] : yh[i], part == 1 ? xl[j] : xh[j],
-                                                                                  acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < TK; ++j) {
+                                if (WS_DBG & 1) asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xl[j]), "v"(xh[j]));
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? yl[i] : yh[i], part == 1 ? xl[j] : xh[j],
+                                                                                       acc[i][j], 0, 0, 0);
+                            }
                 }
             }
             __syncthreads();
