@@ -134,6 +134,20 @@ class GANStep:
             raise ValueError("memory='low' differentiates the terms of the default discriminator_loss one by one: it "
                              "cannot run a custom d_loss_fn / g_loss_fn (use memory='fast' or 'auto')")
         self.memory = memory
+        # bench.py --gpus N: HIP events around the two gradient all-reduces of every step ((start, stop) pairs on the
+        # launch stream; None = off)
+        self.collective_events = None
+
+    def time_collectives(self, on: bool = True) -> None:
+        """Start (or stop) recording a pair of HIP events around every gradient all-reduce."""
+        self.collective_events = [] if on else None
+
+    def collective_ms(self):
+        """(all-reduces timed, total ms between their events) since ``time_collectives()``; synchronises the events."""
+        ev = self.collective_events or []
+        if ev:
+            ev[-1][1].synchronize()
+        return len(ev), float(sum(a.elapsed_time(b) for a, b in ev))
 
     def _low_memory(self, gen_edge) -> bool:
         if self.memory != "auto":
@@ -173,11 +187,18 @@ class GANStep:
                 return
             ws = bucket.world_size()
             if ws > 1:
+                timed = self.collective_events is not None and flat.is_cuda
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 if dist.get_backend(self.group) == "nccl":
                     dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
                 else:
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                     flat.div_(ws)
+                if timed:
+                    e1.record()
+                    self.collective_events.append((e0, e1))
             opt.step(packed=True)
         else:
             bucket.all_reduce_mean()

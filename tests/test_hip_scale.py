@@ -245,6 +245,25 @@ def test_two_gpu_rccl_bench_keeps_replicas_identical(tmp_path):
     assert out["config"]["global_batch"] == 128
 
 
+def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
+    cuda:0 and the `gloo` backend (DG_DIST_BACKEND: the functional twin of the RCCL run, which needs two GPUs): the line
+    must carry n_gpus = 2, the per-rank time of the two gradient all-reduces per step and replicas_identical = true
+    without any extra flag."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extra", "--batch", "8", "--vertexes", "9", "--depth", "1"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
+    assert out["replicas_identical"] is True
+    ar = out["allreduce"]
+    assert len(ar["per_rank_ms_per_step"]) == 2 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
+
+
 def test_dataparallel_replicas_on_one_device_run_the_gradient_penalty():
     """The reference's --parallel path (train.py:220-223) wraps D in nn.DataParallel: replicas are THREADS.  Two replicas
     on cuda:0 (device_ids=[0, 0]) go through discriminator_loss -- the batched D(real, fake) forward, the gradient
