@@ -259,6 +259,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
+    n_ar, ms_ar = stepper.collective_ms() if world > 1 else (0, 0.0)      # the timed steps' all-reduces only
+    stepper.time_collectives(False)
     attn_stats = {k: (_lib.prof_read(k), dgf.traffic_bytes(k)) for k in attn_kernels}
     # per-kernel table of every HIP kernel: two extra, untimed, fully instrumented steps
     _lib.prof_reset()
@@ -280,8 +282,6 @@ def main():
     if world > 1:
         # what an N-GPU line needs to explain itself: the time between the events around the two all-reduces of a step
         # on every rank (includes waiting for the slowest rank), and whether the replicas still hold identical weights
-        n_ar, ms_ar = stepper.collective_ms()
-        stepper.time_collectives(False)
         mine = torch.tensor([ms_ar / max(1, args.steps)], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
