@@ -141,6 +141,12 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     float4* red = kv + 2 * JPL * 64;  // [(RW-1)][2*JPL][64]
     const int lane = threadIdx.x & 63;
     const int rw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // fp32 + ADDE: the row's add_e slots travel HBM -> LDS by LDS-DMA into a wave-private stash (JPL KiB per wave, lane-
+    // linear) when the row is requested and are read back one slot at a time right before their store.  Held in
+    // registers from the request to the store they were 4 JPL registers too many: 156 B / lane of scratch, each slot
+    // spilled after its load and reloaded at its store (279 us against 199 us for the plain kernel at configs[1]).
+    constexpr bool STASH = ADDE && std::is_same<T, float>::value;
+    float4* stash = red + (RW - 1) * 2 * JPL * 64 + rw * JPL * 64;      // [RW][JPL][64] behind the reduction area
     // XCD-aware placement (speed only; workgroup id -> XCD is id % 8): the SL channel slices of a molecule get
     // consecutive ids on ONE XCD, so they run at the same time behind the same L2.  With bf16 rows a slice covers
     // 64 of the 128 bytes of a cache line: the other half is then an L2 hit instead of a second HBM fetch.
@@ -166,16 +172,22 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     // fp32 rows cost 4 registers per slot: no room for the second set, and that variant sits at the HBM roof already.
     constexpr bool PF = !std::is_same<T, float>::value;
     typedef typename raw4<T>::type Raw;
-    Raw re[JPL], rws[JPL], rae[ADDE ? JPL : 1], rq, rwo;
+    Raw re[JPL], rws[JPL], rae[(ADDE && !STASH) ? JPL : 1], rq, rwo;
     auto request = [&](int i) {
         const size_t row = static_cast<size_t>(b) * N + i;
+        if (STASH) {      // first: every later wait for a register load of this row then covers them
+            const unsigned sb = lds_byte_address(stash);
+#pragma unroll
+            for (int t = 0; t < JPL; ++t)
+                dma16_async(reinterpret_cast<const float*>(add_e + row * NC + L.off[t]), sb + t * 1024);
+        }
         rq = ld_raw(q + row * C + L.c0);
         rwo = ld_raw(wo + row * C + L.c0);
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             re[t] = ld_raw_stream(e + row * NC + L.off[t]);
             if (ws) rws[t] = ld_raw_stream(ws + row * NC + L.off[t]);
-            if (ADDE) rae[ADDE ? t : 0] = ld_raw_stream(add_e + row * NC + L.off[t]);
+            if (ADDE && !STASH) rae[(ADDE && !STASH) ? t : 0] = ld_raw_stream(add_e + row * NC + L.off[t]);
         }
     };
     if (PF && rw < N) request(rw);
@@ -188,12 +200,12 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
         const float4 woi = cvt_raw(rwo);
         T* der = de + row * NC;
         float4 ee[JPL], wss[JPL], pe[JPL];
-        Raw hae[ADDE ? JPL : 1];      // still packed: converted at the store
+        Raw hae[(ADDE && !STASH) ? JPL : 1];      // still packed: converted at the store
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             ee[t] = cvt_raw(re[t]);
             wss[t] = ws ? cvt_raw(rws[t]) : f4(0.f);
-            if (ADDE) hae[ADDE ? t : 0] = rae[ADDE ? t : 0];
+            if (ADDE && !STASH) hae[(ADDE && !STASH) ? t : 0] = rae[(ADDE && !STASH) ? t : 0];
         }
         if (PF && i + RW < N) request(i + RW);
         float4 m = f4(kNegBig);
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
         const float4 inv = rcp4(l);
         const float4 abar = A * inv;
         float4 dqa = f4(0.f);
+        if (STASH) wait_all_vmem();      // the row's DMA (issued a row of arithmetic ago) has landed; own lanes only: no barrier
 #pragma unroll
         for (int t = 0; t < JPL; ++t) {
             const float4 kk = kv[(0 * JPL + t) * 64 + kl];
@@ -228,7 +241,8 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
             dkk[t] = fma4(dsg, aq, dkk[t]);
             const float4 g1 = fma4(f4(2.f), ee[t], f4(1.f));
             float4 dev = ds * aq * kk * g1;
-            if (ADDE) dev += cvt_raw(hae[ADDE ? t : 0]);
+            if (STASH) dev += stash[t * 64 + kl];
+            else if (ADDE) dev += cvt_raw(hae[(ADDE && !STASH) ? t : 0]);
             if (L.jok[t] && L.cok) st4_stream(der + L.off[t], dev);
             __builtin_amdgcn_sched_barrier(0);   // one slot at a time: bounds the live temporaries
         }
@@ -541,7 +555,7 @@ extern "C" int dg_attn_core_bwd_add(const void* q_, const void* k_, const void* 
     ProfScope prof(DG_K_ATTN_BWD, stream);
 #define LAUNCH_T(T, LQS, JPL, RW_)                                                                              \
     {                                                                                                           \
-        constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL) * 64 * 16;                                          \
+        constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL + RW_ * JPL) * 64 * 16;   /* + the add_e stash */    \
         if (add_e_) {                                                                                           \
             DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_, true>), lds);                                      \
             hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_, true>), grid, block, lds, stream,              \

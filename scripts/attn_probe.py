@@ -21,6 +21,7 @@ ws, wo = mk(B, N, N, C), mk(B, N, C)
 tq, tk, tv, te = mk(B, N, C), mk(B, N, C), mk(B, N, C), mk(B, N, N, C)
 for name, fn in (("fwd", lambda: dgf._AttnCore.apply(q, k, v, e, 0.25, True)),
                  ("bwd", lambda: dgf._attn_bwd_launch(q, k, v, e, ws, wo, 0.25)),
+                 ("bwd+add_e", lambda: dgf._attn_bwd_launch(q, k, v, e, ws, wo, 0.25, add_e=te)),
                  ("bwd2", lambda: dgf._attn_bwd2_launch(q, k, v, e, ws, wo, tq, tk, tv, te, 0.25))):
     fn()
     torch.cuda.synchronize()
