@@ -32,5 +32,5 @@ for name, fn in (("fwd", lambda: dgf._AttnCore.apply(q, k, v, e, 0.25, True)),
     us = (time.perf_counter() - t0) / reps * 1e6
     es = q.element_size()
     nb = {"fwd": es * B * (2 * N * N * C + 4 * N * C), "bwd": es * B * (3 * N * N * C + 7 * N * C),
-          "bwd2": es * B * (5 * N * N * C + 11 * N * C)}[name]
+          "bwd+add_e": es * B * (4 * N * N * C + 7 * N * C), "bwd2": es * B * (5 * N * N * C + 11 * N * C)}[name]
     print(f"attn_{name} B={B} {dt}: {us:9.1f} us  {nb / us / 1e6:7.2f} TB/s algorithmic")
