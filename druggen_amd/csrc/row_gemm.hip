@@ -28,7 +28,8 @@
 
 // Developer builds only (-DDG_DBG=<bits>, loaded through DG_LIB; scripts/gemm_phases.py, scripts/gemm_variants.py;
 // results in profiles/r02_gemm_*_phases.txt).  16: s_memtime phase stamps of workgroup 17 written to ep.rstd;
-// K = 384 kernel ablations: 1 = no MFMAs, 2 = raw LDS writes instead of the fp16 split, 8 = no global fetch.
+// K = 384 kernel ablations: 1 = no MFMAs, 2 = raw LDS writes instead of the fp16 split, 8 = no global fetch; K = 128
+// kernels (direct epilogue): 1 = no MFMAs, 4 = no result stores, 8 = no global fetch (profiles/r04_gemm_ablation.txt).
 // The shipped library is built with DG_DBG = 0: every such block folds away.
 #ifndef DG_DBG
 #define DG_DBG 0
@@ -832,7 +833,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
             for (int i = 0; i < PFN; ++i) {
                 unsigned off = voff0 + i * (2 * NM * K * 4);   // 64 NM threads = 2 NM rows per step
                 off = off < lim ? off : lim;
-                set[i] = ld4(reinterpret_cast<const float*>(base + off));
+                if (DG_DBG & 8) set[i] = f4(static_cast<float>(off & 7));
+                else set[i] = ld4(reinterpret_cast<const float*>(base + off));
             }
         };
         auto write = [&](const float4 (&set)[PFN], int64_t chunk) {   // chunks past the end land in the idle buffer
@@ -997,10 +999,18 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[s][TB[t]][ks & 3], acc[s][m], 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) {
+                        if (DG_DBG & 1) asm volatile("" ::"v"(f[m][TA[t]]), "v"(bfr[s][TB[t]][ks & 3]));
+                        else acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[m][TA[t]], bfr[s][TB[t]][ks & 3], acc[s][m], 0, 0, 0);
+                    }
         }
         GSTAMP(tM)
+        // The ReLU mask words were requested before the MFMA phase and have long arrived, but hipcc placed the wait for
+        // mask word s at its first use -- behind the stores of slab s - 1 -- as vmcnt(0): the wave sat out an HBM write
+        // round trip per tile.  Waiting HERE (nothing is outstanding but last tile's stores, issued a whole MFMA phase
+        // ago) tells the compiler's scoreboard that every earlier load is back: the slabs' stores then stream without a
+        // wait between them (128 -> 384: 310 -> 296 us at R = 518 400, A/B in one call).
+        if (BITS_IN) wait_all_vmem_visible();
         if (!EXCH && kc == KC - 1) {
             // direct epilogue from the accumulator layout, one (slab, 32-row block) at a time
             constexpr bool BITS = NG == 3 || NC == 6;   // ReLU bit masks in / out: only the fc1-shaped launches use them
@@ -1047,7 +1057,10 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
                         constexpr int LDY = S3 ? 128 : N;      // three [R,128] outputs, or one [R,N]
                         float* yb = S3 ? (slab < 4 ? y : ep.y_alt[(slab >> 2) - 1]) : y;
                         float* yr = yb + (r0 + 32 * m + (lane >> 3)) * LDY + 32 * (S3 ? (slab & 3) : slab) + 4 * (lane & 7);
-                        if (full) {
+                        if (DG_DBG & 4) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(rowv[i].x), "v"(rowv[i].y), "v"(rowv[i].z), "v"(rowv[i].w));
+                        } else if (full) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) st4(yr + static_cast<size_t>(8 * i) * LDY, rowv[i]);
                         } else {
