@@ -2,9 +2,9 @@
 # Round-end evidence: bench lines of every BASELINE config, rocprofv3 kernel-trace summaries of the headline (c2, fp32)
 # and configs[2] (c3, bf16) steps, FETCH_SIZE / WRITE_SIZE passes of both (-> profiles/traffic.json).  Everything lands in
 # gpurun_out/<tag>/ ; copy what should be judged into profiles/.
-#   gpurun -- 'scripts/collect_profiles.sh r03 <commit>'
+#   gpurun -- 'scripts/collect_profiles.sh r04 <commit>'
 set -u
-tag=${1:-r03}; commit=${2:-unknown}
+tag=${1:-r04}; commit=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -31,8 +31,8 @@ cd $R
 # ---- SQ counters of the kernels this round worked on (one rocprofv3 pass per counter group, kernel trace only)
 scripts/pmc_run.sh $tag/pmc_half attn_half -- python $R/scripts/half_probe.py 2048 45 > $O/pmc_attn_half_fwd.txt 2>&1
 scripts/pmc_run.sh $tag/pmc_hb attn_half_bwd -- python $R/scripts/half_bwd_probe.py 2048 45 > $O/pmc_attn_half_bwd.txt 2>&1
-scripts/pmc_run.sh $tag/pmc_wg wgrad_kernel -- python $R/scripts/wgrad_probe.py > $O/pmc_wgrad.txt 2>&1
-python scripts/wgrad_probe.py > $O/wgrad_probe_h3.txt 2>&1; DG_WGRAD=x6 python scripts/wgrad_probe.py > $O/wgrad_probe_x6.txt 2>&1
+scripts/pmc_run.sh $tag/pmc_wg wgrad_stream -- python $R/scripts/wgrad_probe.py > $O/pmc_wgrad.txt 2>&1
+python scripts/wgrad_probe.py > $O/wgrad_probe_h3.txt 2>&1; DG_WGRAD=sym python scripts/wgrad_probe.py > $O/wgrad_probe_sym.txt 2>&1
 python scripts/lnb_probe.py > $O/lnb_probe.txt 2>&1
 rm -rf $O/pmc_half $O/pmc_hb $O/pmc_wg $O/*.p[0-9].log
 cp profiles/traffic.json $O/traffic.json 2>/dev/null || echo '{"records": []}' > $O/traffic.json
