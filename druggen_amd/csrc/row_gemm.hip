@@ -22,6 +22,7 @@
 //   * LayerNorm epilogue: the 64x128 result tile is exchanged through LDS so that each wave
 //     normalises whole rows (32 lanes x float4, 5-step butterflies) and stores full 512 B rows.
 #include "common.h"
+#include "row_gemm_n384.h"
 
 #include <cstring>
 #include <type_traits>
@@ -1636,7 +1637,7 @@ int row_gemm_f32_pack_batch(const void* table, int n, int max_rows_cols, dg_stre
 
 size_t row_gemm_f32_mask_words(int64_t R, int K, int N) {
     // geometry of the direct-epilogue kernels (see the launch table in dg_row_gemm)
-    if (K == 128 && N == 384) return static_cast<size_t>((R + 31) / 32) * 12 * 64;
+    if (K == 128 && N == 384) return static_cast<size_t>((R + 31) / 32) * 12 * 64;      // (>= row_gemm_n384_mask_words(R))
     if (K == 128 && N == 128) return static_cast<size_t>((R + 63) / 64) * 8 * 64;   // upper bound over variants
     return 0;
 }
@@ -1676,6 +1677,13 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
                            reinterpret_cast<const f16x8*>(packed), y, R, ep);                                      \
     }
         static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
+        // default: producer / consumer kernel (row_gemm_n384.hip); DG_GEMM_N384=resident | stream select the round-2/3
+        // kernels (A/B measurements).  The three write their ReLU bit masks in layouts of their own: a process uses one.
+        static const bool pc_n = !getenv("DG_GEMM_N384") || strcmp(getenv("DG_GEMM_N384"), "pc") == 0;
+        if (K == 128 && N == 384 && pc_n) {
+            if (int st = launch_row_gemm_n384(a, packed, y, R, bias, relu, relu_bits_out, mask_bits, stream)) return st;
+            return check_launch("dg_row_gemm");
+        }
         if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)
             constexpr int lds6 = kH3Lds + 6 * 32 * 32 * 4;
             DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), lds6);

@@ -1,0 +1,14 @@
+// Producer / consumer 128 -> 384 row GEMM (row_gemm_n384.hip), launched by dg_row_gemm (row_gemm.hip).
+#pragma once
+
+#include "common.h"
+
+namespace dg {
+
+// ReLU bit-mask words of a launch over R rows (one word per lane, consumer wave and 32-row stage)
+size_t row_gemm_n384_mask_words(int64_t R);
+// y [R,384] = epi(a [R,128] . B): bias, ReLU (+ bit mask out), bit mask in; `packed` from dg_row_gemm_pack (fp16 hi + lo)
+int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream);
+
+}  // namespace dg

@@ -1,0 +1,301 @@
+// 128 -> 384 row GEMM (fc1 of the feed-forward: y = relu(x W1^T + b1), reference src/model/layers.py:50-51, and its
+// twin in the backward, dh = (dz W2) * relu-mask), fp32 rows, producer / consumer form.
+//
+// Same arithmetic as row_gemm.hip (fp16 hi + lo planes under an exact power-of-two scale per ROW of the activation
+// chunk and per output COLUMN of the weight, three MFMA products, fp32 accumulation, inverse scales in the epilogue),
+// same packed weight (dg_row_gemm_pack).  What differs is who touches global memory.  In the 6 + 2 wave kernel
+// (row_gemm_h3_kernel<1,1,false,6>) every consumer wave ran its MFMA phase, then scaled / masked / transposed / stored
+// its own 2 x 2 blocks, and two of the four SIMDs hosted two consumer waves in lock step: the kernel's phases added up
+// instead of overlapping (profiles/r04_gemm_ablation.txt: no MFMAs 211 us, no stores 206, no fetch 211, none of the
+// three 88 of 296).  Here a workgroup is 12 waves, 3 per SIMD:
+//
+//   waves 8..11  producers: every global access.  A rows HBM -> registers (16-byte buffer loads whose range ends at the
+//                last row: no clamps, no tail branch; three stages deep) -> row maximum -> hi / lo planes in LDS; and
+//                the FINISHED output tile of the previous stage LDS -> HBM as whole 1536-byte rows, 16 bytes per lane.
+//   waves 0..7   consumers: wave w owns output channels [48 w, 48 w + 48) with its weight fragments resident (96
+//                VGPRs, gathered once from the packed weight).  Swapped product on v_mfma_f32_16x16x32_f16 (weights =
+//                A operand, activations = B operand): a lane ends up with 4 consecutive channels of ONE row.  Per
+//                32-row stage: 16 ds_read_b128, 72 MFMAs, then scale + bias + ReLU (+ bit masks) and one 16-byte LDS
+//                write per block into the output tile.  No global memory operation at all: the ReLU mask words travel
+//                through LDS too (a consumer that stored its own word waited for that store, vmcnt(0), every stage).
+//   one s_barrier per stage; planes and output tile double-buffered.
+#include "common.h"
+#include "row_gemm_n384.h"
+
+namespace dg {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSR = 32;                                  // rows per stage
+constexpr int kPlane = 16 * 512;                         // [k-step 4][k-quarter 4][row 32 (xor-swizzled)][16 B]
+constexpr int kStage = 2 * kPlane + 128;                 // hi, lo, inverse row scales [32]
+constexpr int kOut = kSR * 96 * 16;                      // output tile: [row 32][16-byte slot 96 (xor row & 7)]
+constexpr int kOffOut = 2 * kStage;
+constexpr int kOffTab = kOffOut + 2 * kOut;              // inverse column scales [384], bias [384]
+constexpr int kOffBitsIn = kOffTab + 2 * 384 * 4;        // ReLU mask words of a stage [2][8 waves][64 lanes] (with the planes)
+constexpr int kOffBitsOut = kOffBitsIn + 2 * 2048;       // ... written by the consumers [2][8][64] (with the output tile)
+constexpr int kLds = kOffBitsOut + 2 * 2048;
+constexpr int kCons = 8, kProd = 4, kDepth = 3;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned umax_dpp(unsigned x) {
+    const unsigned moved = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xF, 0xF, true));
+    return x > moved ? x : moved;
+}
+
+struct Epi {
+    const float* bias;            // [384] or null
+    const unsigned* mask_bits;    // [stages][8][64] words written by a launch with relu_bits of the SAME geometry, or null
+    unsigned* relu_bits;          // optional output, same layout: bit (rb * 3 + cb) * 4 + i = (v > 0)
+    int relu;
+};
+
+__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const float* __restrict__ a,
+                                                                           const f16x8* __restrict__ packed,
+                                                                           float* __restrict__ y, int64_t R, Epi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const tab = reinterpret_cast<float*>(smem + kOffTab);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t total = (R + kSR - 1) / kSR;
+    const int64_t q = total / gridDim.x, rem = total % gridDim.x;
+    const int64_t s_lo = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int T = static_cast<int>(q + (blockIdx.x < rem ? 1 : 0));      // >= 1
+    const int TP = (T + kDepth - 1) / kDepth * kDepth;
+
+    if (w >= kCons) {
+        // ------------------------------------------------------------------------------------------ producers
+        __builtin_amdgcn_s_setprio(3);
+        const int pt = threadIdx.x - 64 * kCons;
+        const int hw = pt >> 5, l32 = pt & 31;
+        // tables for the consumers' epilogue (once)
+        {
+            const float* inv_cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(12) * 8 * 2 * 64);
+            for (int i = pt; i < 384; i += 64 * kProd) {
+                tab[i] = inv_cs[i];
+                tab[384 + i] = ep.bias ? ep.bias[i] : 0.f;
+            }
+        }
+        float4 pf[kDepth][4];
+        u32x2 mk[kDepth];      // this thread's two mask words of the stage (words 2 pt, 2 pt + 1 of its 512)
+        const unsigned voff = static_cast<unsigned>(hw) * 512u + static_cast<unsigned>(l32) * 16u;
+        auto fetch = [&](float4 (&set)[4], u32x2& mword, int t) {
+            if (t > T - 1) t = T - 1;
+            // (a null mask: a zero-sized range, every word reads as 0 and is replaced by all-ones in split())
+            const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned*>(ep.mask_bits ? ep.mask_bits + (s_lo + t) * 512 : reinterpret_cast<const unsigned*>(a)), 0,
+                ep.mask_bits ? 2048 : 0, 0x00020000);
+            mword = __builtin_amdgcn_raw_buffer_load_b64(rmask, static_cast<unsigned>(pt) * 8u, 0, 0);
+            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t left = (R - r0) * 512;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a) + r0 * 128, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)      // rows hw + 8 i
+                set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * 4096, 0));
+        };
+        // float4 column c = l32 covers k = 4c .. 4c + 3: block b = c >> 1 (k-step c >> 3, quarter (c >> 1) & 3), half c & 1;
+        // row r of block b sits at position r ^ (b & 7)
+        const int blk = l32 >> 1;
+        const unsigned wbase = static_cast<unsigned>(blk * 512 + (l32 & 1) * 8);
+        auto split = [&](float4 (&set)[4], const u32x2& mword, int t) {      // stage t -> planes[t & 1]
+            char* const pl = smem + (t & 1) * kStage;
+            *reinterpret_cast<u32x2*>(smem + kOffBitsIn + (t & 1) * 2048 + pt * 8) = ep.mask_bits ? mword : u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+            unsigned m[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4& v = set[i];
+                float t0, u;
+                // (volatile: the first use of the loads stays behind the previous iteration's barrier)
+                asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t0) : "v"(v.x), "v"(v.y), "v"(v.z));
+                asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(u) : "v"(v.w), "v"(t0));
+                m[i] = __float_as_uint(u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = umax_dpp<0xB1>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = umax_dpp<0x4E>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = umax_dpp<0x141>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = umax_dpp<0x140>(m[i]);
+            float sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto r = __builtin_amdgcn_permlane16_swap(m[i], m[i], false, false);
+                const unsigned xm = r[0] > r[1] ? r[0] : r[1];
+                unsigned e = xm >> 23;
+                e = e < 15u ? 15u : e;
+                m[i] = e;
+                sc[i] = __uint_as_float((268u - e) << 23);      // 2^(14 - (e - 127)): the row maximum lands in [2^14, 2^15)
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4& v = set[i];
+                f32x2 xa = f32x2{v.x, v.y} * sc[i], xb = f32x2{v.z, v.w} * sc[i];
+                const f16x2 ha = __builtin_convertvector(xa, f16x2), hb = __builtin_convertvector(xb, f16x2);
+                xa -= __builtin_convertvector(ha, f32x2);
+                xb -= __builtin_convertvector(hb, f32x2);
+                const f16x2 la = __builtin_convertvector(xa, f16x2), lb = __builtin_convertvector(xb, f16x2);
+                const int row = hw + 8 * i;
+                const unsigned off = wbase + static_cast<unsigned>((row ^ (blk & 7)) * 16);
+                *reinterpret_cast<u32x2*>(pl + off) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+                *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+            }
+            if (l32 == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float*>(pl + 2 * kPlane + (hw + 8 * i) * 4) = __uint_as_float((m[i] - 14u) << 23);
+            }
+        };
+        // finished output tile of stage t: LDS -> HBM, whole rows.  Thread (hw, l32) moves, for row hw + 8 k and piece q,
+        // the 16 bytes at LDS slot 32 q + l32; their channel slot is that position ^ (row & 7) = ^ hw.
+        const unsigned ooff = static_cast<unsigned>(hw) * 1536u + static_cast<unsigned>(l32) * 16u;
+        const unsigned goff = static_cast<unsigned>(hw) * 1536u + static_cast<unsigned>(l32 ^ hw) * 16u;
+        auto store_out = [&](int t) {
+            const bool ok = t >= 0 && t < T;
+            const int tc = ok ? t : 0;
+            const int64_t r0 = (s_lo + tc) * kSR;
+            const int64_t left = (R - r0) * 1536;
+            const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 384, 0, bytes, 0x00020000);
+            const char* ot = smem + kOffOut + (tc & 1) * kOut;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int k = i / 3, qq = i % 3;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ooff + k * 8 * 1536 + qq * 512);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, goff, k * 8 * 1536 + qq * 512, 0);
+            }
+            // the stage's ReLU bit words (written by the consumers next to the tile)
+            const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(
+                ep.relu_bits ? ep.relu_bits + (s_lo + tc) * 512 : reinterpret_cast<unsigned*>(y), 0, (ok && ep.relu_bits) ? 2048 : 0,
+                0x00020000);
+            const u32x2 bw = *reinterpret_cast<const u32x2*>(smem + kOffBitsOut + (tc & 1) * 2048 + pt * 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bw, rbits, static_cast<unsigned>(pt) * 8u, 0, 0);
+        };
+        fetch(pf[0], mk[0], 0);
+        fetch(pf[1], mk[1], 1);
+        fetch(pf[2], mk[2], 2);
+        split(pf[0], mk[0], 0);
+        fetch(pf[0], mk[0], 3);
+        __syncthreads();
+        for (int t = 0; t < TP; t += 3) {
+            // iteration t: the consumers are on stage t; planes of stage t + 1 are written, the output tile of stage t - 1 leaves
+            split(pf[1], mk[1], t + 1);
+            fetch(pf[1], mk[1], t + 4);
+            store_out(t - 1);
+            __syncthreads();
+            split(pf[2], mk[2], t + 2);
+            fetch(pf[2], mk[2], t + 5);
+            store_out(t);
+            __syncthreads();
+            split(pf[0], mk[0], t + 3);
+            fetch(pf[0], mk[0], t + 6);
+            store_out(t + 1);
+            __syncthreads();
+        }
+        store_out(TP - 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- consumers
+    const int n = lane & 15, kq = lane >> 4;
+    // weight fragments from the packed operand (32-column slabs x 16-deep k-steps, lane = (column, k half)): channel
+    // 48 w + 16 cb + n, k = 32 ks + 8 kq .. + 7  ->  slab t, k-step 2 ks + (kq >> 1), lane (kq & 1) * 32 + column
+    f16x8 wf[3][4][2];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+        const int ch = 48 * w + 16 * cb + n;
+        const int tslab = ch >> 5, col = ch & 31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[cb][ks][p] = packed[(static_cast<size_t>(tslab * 8 + 2 * ks + (kq >> 1)) * 2 + p) * 64 + (kq & 1) * 32 + col];
+    }
+    // activation fragment of lane (row n, quarter kq) in k-step ks: block 4 ks + kq, position (16 rb + n) ^ ((4 ks + kq) & 7)
+    const unsigned xo_e = static_cast<unsigned>(kq * 512 + ((n ^ kq) * 16));            // even k-steps
+    const unsigned xo_o = static_cast<unsigned>(kq * 512 + ((n ^ (4 + kq)) * 16));      // odd k-steps
+    const unsigned relu_sel = ep.relu ? 0xFFFFFFFFu : 0u;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // weight fragments are in registers
+    __syncthreads();                         // stage 0 is in planes[0], the tables are written
+    for (int t = 0; t < TP; ++t) {
+        if (t < T) {
+            const char* pl = smem + (t & 1) * kStage;
+            const unsigned bits = *reinterpret_cast<const unsigned*>(smem + kOffBitsIn + (t & 1) * 2048 + (w * 64 + lane) * 4);
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 xh[2], xl[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const char* p0 = pl + ks * 2048 + rb * 256 + ((ks & 1) ? xo_o : xo_e);
+                    xh[rb] = *reinterpret_cast<const f16x8*>(p0);
+                    xl[rb] = *reinterpret_cast<const f16x8*>(p0 + kPlane);
+                }
+                // lo.hi, hi.lo, hi.hi: smallest terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 3; ++cb)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb][ks][term == 0 ? 1 : 0],
+                                                                                term == 1 ? xl[rb] : xh[rb], acc[rb][cb], 0, 0, 0);
+            }
+            // epilogue: lane (row n of block rb, channel group kq) holds channels 48 w + 16 cb + 4 kq + i of its row
+            char* ot = smem + kOffOut + (t & 1) * kOut;
+            unsigned newbits = 0;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int row = 16 * rb + n;
+                const float rs = *reinterpret_cast<const float*>(pl + 2 * kPlane + row * 4);
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    const int c0 = 48 * w + 16 * cb + 4 * kq;
+                    const float4 cs = ld4(tab + c0), bs = ld4(tab + 384 + c0);
+                    float v[4] = {fmaf(acc[rb][cb][0], rs * cs.x, bs.x), fmaf(acc[rb][cb][1], rs * cs.y, bs.y),
+                                  fmaf(acc[rb][cb][2], rs * cs.z, bs.z), fmaf(acc[rb][cb][3], rs * cs.w, bs.w)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int bit = (rb * 3 + cb) * 4 + i;
+                        newbits |= (v[i] > 0.f ? 1u : 0u) << bit;
+                        v[i] = __uint_as_float((__float_as_uint(fmaxf(v[i], 0.f)) & relu_sel) | (__float_as_uint(v[i]) & ~relu_sel));
+                        v[i] = (bits >> bit) & 1u ? v[i] : 0.f;
+                    }
+                    const int slot = (c0 >> 2) ^ (row & 7);
+                    *reinterpret_cast<float4*>(ot + row * 1536 + slot * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            *reinterpret_cast<unsigned*>(smem + kOffBitsOut + (t & 1) * 2048 + (w * 64 + lane) * 4) = newbits;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t row_gemm_n384_mask_words(int64_t R) { return static_cast<size_t>((R + kSR - 1) / kSR) * kCons * 64; }
+
+int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream) {
+    const int64_t stages = (R + kSR - 1) / kSR;
+    const int blocks = static_cast<int>(stages < 256 ? stages : 256);
+    Epi ep{bias, mask_bits, relu_bits, relu};
+    DG_OPT_IN_LDS((&row_gemm_n384_kernel), kLds);
+    hipLaunchKernelGGL(row_gemm_n384_kernel, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a,
+                       static_cast<const f16x8*>(packed), y, R, ep);
+    return 0;
+}
+
+}  // namespace dg
