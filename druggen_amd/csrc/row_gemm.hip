@@ -23,6 +23,7 @@
 //     normalises whole rows (32 lanes x float4, 5-step butterflies) and stores full 512 B rows.
 #include "common.h"
 #include "row_gemm_n384.h"
+#include "row_gemm_k384.h"
 
 #include <cstring>
 #include <type_traits>
@@ -1682,6 +1683,14 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         static const bool pc_n = !getenv("DG_GEMM_N384") || strcmp(getenv("DG_GEMM_N384"), "pc") == 0;
         if (K == 128 && N == 384 && pc_n) {
             if (int st = launch_row_gemm_n384(a, packed, y, R, bias, relu, relu_bits_out, mask_bits, stream)) return st;
+            return check_launch("dg_row_gemm");
+        }
+        // 384 -> 128: producer / consumer kernel (row_gemm_k384.hip) by default; DG_GEMM_K384=paired selects the round-2/3
+        // kernel (two tiles per B set, epilogue in the mover waves) for A/B measurements
+        static const bool pc_k = !getenv("DG_GEMM_K384") || strcmp(getenv("DG_GEMM_K384"), "pc") == 0;
+        if (K == 384 && pc_k) {
+            if (int st = launch_row_gemm_k384(a, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream))
+                return st;
             return check_launch("dg_row_gemm");
         }
         if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)

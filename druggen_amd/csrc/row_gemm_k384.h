@@ -1,0 +1,14 @@
+// Producer / consumer 384 -> 128 row GEMM (row_gemm_k384.hip), launched by dg_row_gemm (row_gemm.hip).
+#pragma once
+
+#include "common.h"
+
+namespace dg {
+
+// y [R,128] = LN?(a [R,384] . B + bias (+ relu) + residual?); `packed` from dg_row_gemm_pack (fp16 hi + lo, K = 384);
+// gamma != NULL: LayerNorm epilogue, writes mean / rstd [R] and, if pre_ln != NULL, the pre-LayerNorm sum
+int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+                         const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
+                         float* pre_ln, float eps, hipStream_t stream);
+
+}  // namespace dg

@@ -1,0 +1,348 @@
+// 384 -> 128 row GEMM (fc2 of the feed-forward + residual + LayerNorm: y = LN(x + h W2^T + b2), reference
+// src/model/layers.py:52-53,191-192; and dx = dz + dh W1 in the backward), fp32 rows, producer / consumer form -- the twin
+// of row_gemm_n384.hip.
+//
+// Arithmetic as in row_gemm.hip's K = 384 kernel: fp16 hi + lo planes, one exact power-of-two scale per (row, 128-wide
+// chunk) of the activation and per output column of the weight, three MFMA products; each chunk's products go to their own
+// accumulator set, which is folded `acc += part * (row scale * column scale)` (row AND column inverse scale: folding with
+// the row scale alone overflows for rows above ~2^90).  Same packed weight (dg_row_gemm_pack).
+//
+//   waves 8..11  producers: every global access.  16-row stages: the stage's 16 x 3 (row, chunk) pieces of 512 bytes are
+//                streamed HBM -> registers (one half-wave per piece: both the row maximum of a chunk and, later, the
+//                LayerNorm sums of a row are DPP reductions; buffer loads whose range ends at the last row; three stages =
+//                72 KiB deep) -> hi / lo planes in LDS.  The finished output tile of the previous stage comes back from
+//                LDS, gets its residual row, LayerNorm, and leaves as whole 512-byte rows (y, the pre-LayerNorm sum, the
+//                row statistics) through range-checked buffer stores: no branch in the loop.
+//   waves 0..7   consumers: wave w owns output channels [16 w, 16 w + 16) with its weight fragments resident (12 k-steps x
+//                2 planes = 96 VGPRs).  Swapped product on v_mfma_f32_16x16x32_f16: a lane ends up with 4 consecutive
+//                channels of ONE row.  Per stage 24 ds_read_b128, 36 MFMAs, three folds, + bias (ReLU), one 16-byte LDS
+//                write.  No global memory operation.
+//   one s_barrier per stage; planes and output tile double-buffered.
+#include "common.h"
+#include "row_gemm_k384.h"
+
+namespace dg {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSR = 16;                                  // rows per stage
+constexpr int kPlane = 48 * 256;                         // [chunk 3][k-step 4][k-quarter 4][row 16 (xor-swizzled)][16 B]
+constexpr int kStage = 2 * kPlane + 256;                 // hi, lo, inverse scales [16 rows][3 chunks] (+ pad)
+constexpr int kOut = kSR * 32 * 16;                      // output tile: [row 16][16-byte slot 32 (xor row & 7)]
+constexpr int kOffOut = 2 * kStage;
+constexpr int kOffTab = kOffOut + 2 * kOut;              // gamma [128], beta [128]
+constexpr int kLds = kOffTab + 2 * 128 * 4;
+constexpr int kCons = 8, kProd = 4, kDepth = 3;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned umax_dpp(unsigned x) {
+    const unsigned moved = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xF, 0xF, true));
+    return x > moved ? x : moved;
+}
+template <int CTRL>
+__device__ __forceinline__ float sum_dpp(float x) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true);
+    return x + __int_as_float(moved);
+}
+// sum over the 32 lanes of a half-wave, result in every lane (DPP inside the 16-lane rows, two scalar reads across)
+__device__ __forceinline__ float half_wave_total(float x, bool upper) {
+    x = sum_dpp<0xB1>(x);
+    x = sum_dpp<0x4E>(x);
+    x = sum_dpp<0x141>(x);
+    x = sum_dpp<0x140>(x);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return upper ? r2 + r3 : r0 + r1;
+}
+
+// acc += A . B on v_mfma_f32_16x16x32_f16, ALWAYS in place (result registers = accumulator input).  Through the builtin hipcc
+// renamed the destination of some MFMAs and put them one slot behind the MFMA that produced their accumulator input; lanes
+// 48..63 of that input were then still being written (a few wrong columns per launch, never the same ones: the result
+// latency of this gfx950 opcode is longer than the hazard tables assume).  In-place chains are interlocked by the hardware;
+// what the compiler no longer sees -- a vector read of a result -- is fenced by mfma_results_ready().
+__device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// first MFMA of a chain: accumulator input = the constant 0 (no vector write of the accumulator in front of the chain)
+__device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+struct EpiK {
+    const float* bias;        // [128] or null
+    const float* residual;    // [R,128] or null
+    const float* gamma;       // LayerNorm or null
+    const float* beta;
+    float* mean;
+    float* rstd;
+    float* pre;               // optional [R,128]: the pre-LayerNorm sum
+    float eps;
+    int relu;
+};
+
+template <bool RES, bool LN>
+__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const float* __restrict__ a,
+                                                                           const f16x8* __restrict__ packed,
+                                                                           float* __restrict__ y, int64_t R, EpiK ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const tab = reinterpret_cast<float*>(smem + kOffTab);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t total = (R + kSR - 1) / kSR;
+    const int64_t q = total / gridDim.x, rem = total % gridDim.x;
+    const int64_t s_lo = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
+    const int T = static_cast<int>(q + (blockIdx.x < rem ? 1 : 0));      // >= 1
+    const int TP = (T + kDepth - 1) / kDepth * kDepth;
+
+    if (w >= kCons) {
+        // ------------------------------------------------------------------------------------------ producers
+        __builtin_amdgcn_s_setprio(3);
+        const int pt = threadIdx.x - 64 * kCons;
+        const int hw = pt >> 5, l32 = pt & 31;
+        const bool upper = (lane & 32) != 0;
+        if (LN && pt < 128) {
+            tab[pt] = ep.gamma[pt];
+            tab[128 + pt] = ep.beta[pt];
+        }
+        float4 pf[kDepth][6];
+        // half-wave hw streams rows 2 hw, 2 hw + 1 of the stage: six consecutive 512-byte pieces (row-major, chunk minor)
+        const unsigned voff = static_cast<unsigned>(hw) * 3072u + static_cast<unsigned>(l32) * 16u;
+        auto fetch = [&](float4 (&set)[6], int t) {
+            if (t > T - 1) t = T - 1;
+            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t left = (R - r0) * 1536;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * 512, 0));
+        };
+        // piece i of the thread: row 2 hw + i / 3, chunk i % 3; float4 column c = l32 of the chunk covers k = 4c .. 4c + 3:
+        // block (chunk, c >> 1), half c & 1; row r of a block sits at position r ^ (block & 7)
+        const int blk = l32 >> 1;
+        auto split = [&](float4 (&set)[6], int t) {      // stage t -> planes[t & 1]
+            char* const pl = smem + (t & 1) * kStage;
+            unsigned m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4& v = set[i];
+                float t0, u;
+                // (volatile: the first use of the loads stays behind the previous iteration's barrier)
+                asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t0) : "v"(v.x), "v"(v.y), "v"(v.z));
+                asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(u) : "v"(v.w), "v"(t0));
+                m[i] = __float_as_uint(u);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = umax_dpp<0xB1>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = umax_dpp<0x4E>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = umax_dpp<0x141>(m[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = umax_dpp<0x140>(m[i]);
+            float sc[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const auto r = __builtin_amdgcn_permlane16_swap(m[i], m[i], false, false);
+                const unsigned xm = r[0] > r[1] ? r[0] : r[1];
+                unsigned e = xm >> 23;
+                e = e < 15u ? 15u : e;
+                m[i] = e;
+                sc[i] = __uint_as_float((268u - e) << 23);      // 2^(14 - (e - 127)): the chunk's maximum lands in [2^14, 2^15)
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4& v = set[i];
+                f32x2 xa = f32x2{v.x, v.y} * sc[i], xb = f32x2{v.z, v.w} * sc[i];
+                const f16x2 ha = __builtin_convertvector(xa, f16x2), hb = __builtin_convertvector(xb, f16x2);
+                xa -= __builtin_convertvector(ha, f32x2);
+                xb -= __builtin_convertvector(hb, f32x2);
+                const f16x2 la = __builtin_convertvector(xa, f16x2), lb = __builtin_convertvector(xb, f16x2);
+                const int row = 2 * hw + i / 3, kc = i % 3;
+                const unsigned off = static_cast<unsigned>((kc * 16 + blk) * 256 + ((row ^ (blk & 7)) * 16) + (l32 & 1) * 8);
+                *reinterpret_cast<u32x2*>(pl + off) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+                *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+            }
+            if (l32 == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    *reinterpret_cast<float*>(pl + 2 * kPlane + ((2 * hw + i / 3) * 3 + i % 3) * 4) = __uint_as_float((m[i] - 14u) << 23);
+            }
+        };
+        // residual rows of stage t (requested one iteration before the tile is finished)
+        float4 res[2];
+        auto fetch_res = [&](int t) {
+            if (!RES) return;
+            if (t > T - 1) t = T - 1;
+            if (t < 0) t = 0;
+            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t left = (R - r0) * 512;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ep.residual) + r0 * 128, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                res[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rsrc, static_cast<unsigned>(hw) * 1024u + static_cast<unsigned>(l32) * 16u, j * 512, 0));
+        };
+        // finished tile of stage t: LDS -> (+ residual, LayerNorm) -> HBM.  Thread (hw, l32) owns channels 4 l32 .. of rows
+        // 2 hw, 2 hw + 1; the tile stores a row's slots xor-ed with (row & 7).
+        auto finish = [&](int t) {
+            const bool ok = t >= 0 && t < T;
+            const int tc = ok ? t : 0;
+            const int64_t r0 = (s_lo + tc) * kSR;
+            const int64_t left = R - r0;
+            const int rows = ok ? static_cast<int>(left < kSR ? left : kSR) : 0;      // 0: every store is dropped
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 128, 0, rows * 512, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((LN && ep.pre) ? ep.pre + r0 * 128 : y, 0,
+                                                                               (LN && ep.pre) ? rows * 512 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(LN ? ep.mean + r0 : y, 0, LN ? rows * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(LN ? ep.rstd + r0 : y, 0, LN ? rows * 4 : 0, 0x00020000);
+            const char* ot = smem + kOffOut + (tc & 1) * kOut;
+            float4 gam = f4(0.f), bet = f4(0.f);
+            if (LN) {
+                gam = ld4(tab + 4 * l32);
+                bet = ld4(tab + 128 + 4 * l32);
+            }
+            const unsigned goff = static_cast<unsigned>(hw) * 1024u + static_cast<unsigned>(l32) * 16u;
+            const unsigned soff = l32 == 0 ? static_cast<unsigned>(hw) * 8u : 0x7FFFFFF0u;      // one lane per row writes the statistics
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 2 * hw + j;
+                float4 v = *reinterpret_cast<const float4*>(ot + row * 512 + ((l32 ^ (row & 7)) * 16));
+                if (RES) v += res[j];
+                if (LN) {
+                    if (ep.pre) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, goff, j * 512, 0);
+                    const float mu = half_wave_total((v.x + v.y) + (v.z + v.w), upper) * (1.0f / 128.0f);
+                    const float4 d = v - f4(mu);
+                    const float var = half_wave_total((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w), upper) * (1.0f / 128.0f);
+                    const float rs = rsqrtf(var + ep.eps);
+                    v = fma4(rs * d, gam, bet);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rm, soff, j * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rs), rr, soff, j * 4, 0);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, goff, j * 512, 0);
+            }
+        };
+        fetch(pf[0], 0);
+        fetch(pf[1], 1);
+        fetch(pf[2], 2);
+        split(pf[0], 0);
+        fetch(pf[0], 3);
+        __syncthreads();
+        for (int t = 0; t < TP; t += 3) {
+            // iteration t: the consumers are on stage t; planes of stage t + 1 are written, the tile of stage t - 1 is finished
+            // with the residual rows requested an iteration ago, the residual rows of stage t are requested
+            split(pf[1], t + 1);
+            fetch(pf[1], t + 4);
+            finish(t - 1);
+            fetch_res(t);
+            __syncthreads();
+            split(pf[2], t + 2);
+            fetch(pf[2], t + 5);
+            finish(t);
+            fetch_res(t + 1);
+            __syncthreads();
+            split(pf[0], t + 3);
+            fetch(pf[0], t + 6);
+            finish(t + 1);
+            fetch_res(t + 2);
+            __syncthreads();
+        }
+        finish(TP - 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- consumers
+    const int n = lane & 15, kq = lane >> 4;
+    // weight fragments from the packed operand (32-column slabs x 16-deep k-steps, lane = (column, k half)): channel
+    // 16 w + n, k = 32 ks + 8 kq .. + 7  ->  slab (16 w + n) >> 5, k-step 2 ks + (kq >> 1), lane (kq & 1) * 32 + column
+    f16x8 wf[12][2];
+    {
+        const int ch = 16 * w + n;
+        const int tslab = ch >> 5, col = ch & 31;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[ks][p] = packed[(static_cast<size_t>(tslab * 24 + 2 * ks + (kq >> 1)) * 2 + p) * 64 + (kq & 1) * 32 + col];
+    }
+    const float* inv_cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(4) * 24 * 2 * 64);
+    const float4 cs = ld4(inv_cs + 16 * w + 4 * kq);
+    const float4 bs = ep.bias ? ld4(ep.bias + 16 * w + 4 * kq) : f4(0.f);
+    // activation fragment of lane (row n, quarter kq) in k-step ks of a chunk: block 4 ks + kq, position n ^ ((4 ks + kq) & 7)
+    const unsigned xo_e = static_cast<unsigned>(kq * 256 + ((n ^ kq) * 16));            // even k-steps
+    const unsigned xo_o = static_cast<unsigned>(kq * 256 + ((n ^ (4 + kq)) * 16));      // odd k-steps
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // weight fragments, scales and bias are in registers
+    __syncthreads();                         // stage 0 is in planes[0], gamma / beta are written
+    for (int t = 0; t < TP; ++t) {
+        if (t < T) {
+            const char* pl = smem + (t & 1) * kStage;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                // three accumulation chains per chunk (lo.hi, hi.lo, hi.hi): two independent MFMAs between dependent ones
+                f32x4 p0, p1, p2;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const char* q0 = pl + kc * 4096 + ks * 1024 + ((ks & 1) ? xo_o : xo_e);
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(q0);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(q0 + kPlane);
+                    const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][1];
+                    if (ks == 0) {
+                        mfma16_first(p0, wl, xh);
+                        mfma16_first(p1, wh, xl);
+                        mfma16_first(p2, wh, xh);
+                    } else {
+                        mfma16(p0, wl, xh);
+                        mfma16(p1, wh, xl);
+                        mfma16(p2, wh, xh);
+                    }
+                }
+                const float rs = *reinterpret_cast<const float*>(pl + 2 * kPlane + (n * 3 + kc) * 4);
+                mfma_results_ready();
+                acc[0] = fmaf((p0[0] + p1[0]) + p2[0], rs * cs.x, acc[0]);
+                acc[1] = fmaf((p0[1] + p1[1]) + p2[1], rs * cs.y, acc[1]);
+                acc[2] = fmaf((p0[2] + p1[2]) + p2[2], rs * cs.z, acc[2]);
+                acc[3] = fmaf((p0[3] + p1[3]) + p2[3], rs * cs.w, acc[3]);
+            }
+            float4 v = make_float4(acc[0] + bs.x, acc[1] + bs.y, acc[2] + bs.z, acc[3] + bs.w);
+            if (ep.relu) v = max4(v, f4(0.f));
+            char* ot = smem + kOffOut + (t & 1) * kOut;
+            *reinterpret_cast<float4*>(ot + n * 512 + (((4 * w + kq) ^ (n & 7)) * 16)) = v;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+                         const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
+                         float* pre_ln, float eps, hipStream_t stream) {
+    const int64_t stages = (R + kSR - 1) / kSR;
+    const int blocks = static_cast<int>(stages < 256 ? stages : 256);
+    EpiK ep{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
+#define DG_K384_LAUNCH(RES_, LN_)                                                                                  \
+    {                                                                                                              \
+        DG_OPT_IN_LDS((&row_gemm_k384_kernel<RES_, LN_>), kLds);                                                   \
+        hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_>), dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a, \
+                           static_cast<const f16x8*>(packed), y, R, ep);                                          \
+    }
+    if (residual && gamma) DG_K384_LAUNCH(true, true)
+    else if (residual) DG_K384_LAUNCH(true, false)
+    else if (gamma) DG_K384_LAUNCH(false, true)
+    else DG_K384_LAUNCH(false, false)
+#undef DG_K384_LAUNCH
+    return 0;
+}
+
+}  // namespace dg

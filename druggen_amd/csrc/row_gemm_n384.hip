@@ -49,6 +49,17 @@ __device__ __forceinline__ unsigned umax_dpp(unsigned x) {
     return x > moved ? x : moved;
 }
 
+// acc += A . B on v_mfma_f32_16x16x32_f16, ALWAYS in place, and the fence in front of the first vector read of a result:
+// see row_gemm_k384.hip (hipcc's renamed destinations one slot behind the producing MFMA read partly written accumulators).
+__device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// first MFMA of a chain: accumulator input = the constant 0 (no vector write of the accumulator in front of the chain)
+__device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 struct Epi {
     const float* bias;            // [384] or null
     const unsigned* mask_bits;    // [stages][8][64] words written by a launch with relu_bits of the SAME geometry, or null
@@ -231,10 +242,6 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             const unsigned bits = *reinterpret_cast<const unsigned*>(smem + kOffBitsIn + (t & 1) * 2048 + (w * 64 + lane) * 4);
             f32x4 acc[2][3];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 3; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f16x8 xh[2], xl[2];
 #pragma unroll
@@ -249,10 +256,12 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                        for (int cb = 0; cb < 3; ++cb)
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb][ks][term == 0 ? 1 : 0],
-                                                                                term == 1 ? xl[rb] : xh[rb], acc[rb][cb], 0, 0, 0);
+                        for (int cb = 0; cb < 3; ++cb) {
+                            if (ks == 0 && term == 0) mfma16_first(acc[rb][cb], wf[cb][ks][1], xh[rb]);
+                            else mfma16(acc[rb][cb], wf[cb][ks][term == 0 ? 1 : 0], term == 1 ? xl[rb] : xh[rb]);
+                        }
             }
+            mfma_results_ready();
             // epilogue: lane (row n of block rb, channel group kq) holds channels 48 w + 16 cb + 4 kq + i of its row
             char* ot = smem + kOffOut + (t & 1) * kOut;
             unsigned newbits = 0;
