@@ -49,6 +49,8 @@ SIGNATURES = {
     "dg_row_gemm_sum3": (c_int, [_P] * 5 + [c_int64, _P, c_int, _P]),
     "dg_linear_wgrad_batch_begin": (c_int, []),
     "dg_linear_wgrad_batch_end": (c_int, [_P]),
+    "dg_launch_pair_begin": (c_int, []),
+    "dg_launch_pair_end": (c_int, [_P]),
     "dg_skinny_linear_fwd": (c_int, [_P] * 4 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_dgrad": (c_int, [_P] * 3 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_wgrad": (c_int, [_P] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, _P]),

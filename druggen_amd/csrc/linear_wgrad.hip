@@ -727,6 +727,8 @@ extern "C" int dg_linear_wgrad_batch_end(dg_stream_t stream_) {
     const int n = g_batch_n;
     g_batch_on = false;
     g_batch_n = 0;
+    // (a weight gradient still waiting for a carrier -- pair.h -- must be on the stream before its partial sums are reduced)
+    if (int st = flush_wgrad_stream(static_cast<hipStream_t>(stream_))) return st;
     if (n == 0) return 0;
     int maxb = 0;
     for (int i = 0; i < n; ++i) maxb = g_batch.e[i].blocks > maxb ? g_batch.e[i].blocks : maxb;
@@ -817,7 +819,8 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     }();
     const bool use_stream = !bf && split == 2 && stream_kernel && !dy_mask_ && wgrad_stream_supported(N, K);
     int tpb;
-    const int S = use_stream ? wgrad_stream_blocks(R, N, K)
+    const bool may_wait = g_batch_on && g_batch_n < 8;      // (a launch may only wait for a carrier when its reduce is deferred too)
+    const int S = use_stream ? wgrad_stream_blocks(R, N, K, may_wait)
                              : wgrad_blocks(R, p, &tpb, !bf && split != 0 && p.nt + p.kt == 16 && p.tr % 16 == 0);
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
@@ -825,7 +828,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     ProfScope prof(wgrad_prof_key(R, N, K), stream);
     if (use_stream) {
         if (int st = launch_wgrad_stream(static_cast<const float*>(dy_), static_cast<const float*>(x_), part_w, part_b, R, N,
-                                         K, S, stream))
+                                         K, S, stream, nullptr, nullptr, may_wait))
             return st;
     } else {
 #define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \
@@ -895,13 +898,14 @@ extern "C" int dg_linear_wgrad3(const void* dy0, const void* dy1, const void* dy
     constexpr int N = 384, K = 128;
     if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K)) return fail(DG_E_WORKSPACE, "dg_linear_wgrad3: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int S = wgrad_stream_blocks(R, N, K);
+    const bool may_wait = g_batch_on && g_batch_n < 8;
+    const int S = wgrad_stream_blocks(R, N, K, may_wait);
     float* part_w = static_cast<float*>(workspace);
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     {
         ProfScope prof(wgrad_prof_key(R, N, K), stream);
         if (int st = launch_wgrad_stream(static_cast<const float*>(dy0), static_cast<const float*>(x), part_w, part_b, R, N, K, S,
-                                         stream, static_cast<const float*>(dy1), static_cast<const float*>(dy2)))
+                                         stream, static_cast<const float*>(dy1), static_cast<const float*>(dy2), may_wait))
             return st;
     }
     const int64_t n4 = static_cast<int64_t>(N) * K / 4;

@@ -10,5 +10,7 @@ namespace dg {
 int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
                          float* pre_ln, float eps, hipStream_t stream);
+// launches a problem that is still waiting for its carrier (pair.h)
+int flush_row_gemm_k384(hipStream_t stream);
 
 }  // namespace dg

@@ -20,7 +20,11 @@
 //   one s_barrier per stage; planes and output tile double-buffered.
 #include "common.h"
 #include "row_gemm_k384.h"
+#include "pair.h"
 
+#ifndef K3_DBG
+#define K3_DBG 0      // ablation builds (scripts/build_variant.sh): 1 no MFMAs, 2 raw LDS writes instead of the split, 4 no tile
+#endif                // finishing (residual, LayerNorm, stores), 8 no global fetch of A, 16 no fragment reads
 namespace dg {
 namespace {
 
@@ -89,18 +93,34 @@ struct EpiK {
     int relu;
 };
 
+// One problem of a launch; workgroups [0, nb0) run problem 0, the others problem 1 (a node-level GEMM riding in the
+// edge-level launch of the same kernel: pair.h, row_gemm_n384.hip).
+struct ProbK {
+    const float* a;
+    const f16x8* packed;
+    float* y;
+    int64_t R;
+    EpiK ep;
+};
+
 template <bool RES, bool LN>
-__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const float* __restrict__ a,
-                                                                           const f16x8* __restrict__ packed,
-                                                                           float* __restrict__ y, int64_t R, EpiK ep) {
+__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const ProbK p0, const ProbK p1, const int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
+    const float* __restrict__ const a = second ? p1.a : p0.a;
+    const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
+    float* __restrict__ const y = second ? p1.y : p0.y;
+    const int64_t R = second ? p1.R : p0.R;
+    const EpiK ep = second ? p1.ep : p0.ep;
+    const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
+    const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
     const int64_t total = (R + kSR - 1) / kSR;
-    const int64_t q = total / gridDim.x, rem = total % gridDim.x;
-    const int64_t s_lo = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
-    const int T = static_cast<int>(q + (blockIdx.x < rem ? 1 : 0));      // >= 1
+    const int64_t q = total / nblk, rem = total % nblk;
+    const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
+    const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1
     const int TP = (T + kDepth - 1) / kDepth * kDepth;
 
     if (w >= kCons) {
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             const int64_t left = (R - r0) * 1536;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+            if (K3_DBG & 8) return;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * 512, 0));
@@ -131,6 +152,17 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         const int blk = l32 >> 1;
         auto split = [&](float4 (&set)[6], int t) {      // stage t -> planes[t & 1]
             char* const pl = smem + (t & 1) * kStage;
+            if (K3_DBG & 2) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int row = 2 * hw + i / 3, kc = i % 3;
+                    const unsigned off = static_cast<unsigned>((kc * 16 + blk) * 256 + ((row ^ (blk & 7)) * 16) + (l32 & 1) * 8);
+                    asm volatile("" : "+v"(set[i].x), "+v"(set[i].y), "+v"(set[i].z), "+v"(set[i].w));
+                    *reinterpret_cast<u32x2*>(pl + off) = u32x2{__float_as_uint(set[i].x), __float_as_uint(set[i].y)};
+                    *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__float_as_uint(set[i].z), __float_as_uint(set[i].w)};
+                }
+                return;
+            }
             unsigned m[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         // residual rows of stage t (requested one iteration before the tile is finished)
         float4 res[2];
         auto fetch_res = [&](int t) {
-            if (!RES) return;
+            if (!RES || (K3_DBG & 4)) return;
             if (t > T - 1) t = T - 1;
             if (t < 0) t = 0;
             const int64_t r0 = (s_lo + t) * kSR;
@@ -196,6 +228,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         // finished tile of stage t: LDS -> (+ residual, LayerNorm) -> HBM.  Thread (hw, l32) owns channels 4 l32 .. of rows
         // 2 hw, 2 hw + 1; the tile stores a row's slots xor-ed with (row & 7).
         auto finish = [&](int t) {
+            if (K3_DBG & 4) return;
             const bool ok = t >= 0 && t < T;
             const int tc = ok ? t : 0;
             const int64_t r0 = (s_lo + tc) * kSR;
@@ -294,10 +327,20 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const char* q0 = pl + kc * 4096 + ks * 1024 + ((ks & 1) ? xo_o : xo_e);
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(q0);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(q0 + kPlane);
+                    f16x8 xh, xl;
+                    if (K3_DBG & 16) {
+                        xh = wf[ks][0];
+                        xl = wf[ks][1];
+                    } else {
+                        xh = *reinterpret_cast<const f16x8*>(q0);
+                        xl = *reinterpret_cast<const f16x8*>(q0 + kPlane);
+                    }
                     const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][1];
-                    if (ks == 0) {
+                    if (K3_DBG & 1) {
+                        if (ks == 0) p0 = p1 = p2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        p0[0] += static_cast<float>(xh[0]) * static_cast<float>(wl[0]);
+                        p1[0] += static_cast<float>(xl[0]) * static_cast<float>(wh[0]);
+                    } else if (ks == 0) {
                         mfma16_first(p0, wl, xh);
                         mfma16_first(p1, wh, xl);
                         mfma16_first(p2, wh, xh);
@@ -325,24 +368,59 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
 
 }  // namespace
 
-int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
-                         const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
-                         float* pre_ln, float eps, hipStream_t stream) {
-    const int64_t stages = (R + kSR - 1) / kSR;
-    const int blocks = static_cast<int>(stages < 256 ? stages : 256);
-    EpiK ep{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
+namespace {
+struct Pending {
+    bool valid = false;
+    ProbK p;
+};
+thread_local Pending g_rider;
+
+// the kernel variant a problem needs: residual and LayerNorm epilogues are template parameters
+int variant(const ProbK& p) { return (p.ep.residual ? 1 : 0) + (p.ep.gamma ? 2 : 0); }
+
+int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
+    const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
+    int nb0, nb1;
+    pair_split(st0, st1, 256, &nb0, &nb1);
+    const ProbK& q1 = p1 ? *p1 : p0;
 #define DG_K384_LAUNCH(RES_, LN_)                                                                                  \
     {                                                                                                              \
         DG_OPT_IN_LDS((&row_gemm_k384_kernel<RES_, LN_>), kLds);                                                   \
-        hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_>), dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a, \
-                           static_cast<const f16x8*>(packed), y, R, ep);                                          \
+        hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
+                           q1, nb0);                                                                               \
     }
-    if (residual && gamma) DG_K384_LAUNCH(true, true)
-    else if (residual) DG_K384_LAUNCH(true, false)
-    else if (gamma) DG_K384_LAUNCH(false, true)
-    else DG_K384_LAUNCH(false, false)
+    switch (variant(p0)) {
+        case 3: DG_K384_LAUNCH(true, true) break;
+        case 1: DG_K384_LAUNCH(true, false) break;
+        case 2: DG_K384_LAUNCH(false, true) break;
+        default: DG_K384_LAUNCH(false, false) break;
+    }
 #undef DG_K384_LAUNCH
     return 0;
+}
+}  // namespace
+
+int flush_row_gemm_k384(hipStream_t stream) {
+    if (!g_rider.valid) return 0;
+    g_rider.valid = false;
+    return launch(g_rider.p, nullptr, stream);
+}
+
+int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+                         const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
+                         float* pre_ln, float eps, hipStream_t stream) {
+    const ProbK p{a, static_cast<const f16x8*>(packed), y, R, EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu}};
+    if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
+        g_rider.valid = true;
+        g_rider.p = p;
+        return 0;
+    }
+    if (g_rider.valid) {
+        g_rider.valid = false;
+        if (variant(g_rider.p) == variant(p)) return launch(p, &g_rider.p, stream);
+        if (int st = launch(g_rider.p, nullptr, stream)) return st;      // another epilogue: on its own, first
+    }
+    return launch(p, nullptr, stream);
 }
 
 }  // namespace dg

@@ -10,5 +10,7 @@ size_t row_gemm_n384_mask_words(int64_t R);
 // y [R,384] = epi(a [R,128] . B): bias, ReLU (+ bit mask out), bit mask in; `packed` from dg_row_gemm_pack (fp16 hi + lo)
 int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream);
+// launches a problem that is still waiting for its carrier (pair.h)
+int flush_row_gemm_n384(hipStream_t stream);
 
 }  // namespace dg

@@ -21,6 +21,7 @@
 //   one s_barrier per stage; planes and output tile double-buffered.
 #include "common.h"
 #include "row_gemm_n384.h"
+#include "pair.h"
 
 namespace dg {
 namespace {
@@ -67,17 +68,33 @@ struct Epi {
     int relu;
 };
 
-__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const float* __restrict__ a,
-                                                                           const f16x8* __restrict__ packed,
-                                                                           float* __restrict__ y, int64_t R, Epi ep) {
+// One problem of a launch.  A launch carries one or two: workgroups [0, nb0) run problem 0, the others problem 1 -- a
+// node-level GEMM (R = B N rows) riding in the edge-level launch (R = B N^2) of the same kernel (pair.h).
+struct Prob {
+    const float* a;
+    const f16x8* packed;
+    float* y;
+    int64_t R;
+    Epi ep;
+};
+
+__global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
+    const float* __restrict__ const a = second ? p1.a : p0.a;
+    const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
+    float* __restrict__ const y = second ? p1.y : p0.y;
+    const int64_t R = second ? p1.R : p0.R;
+    const Epi ep = second ? p1.ep : p0.ep;
+    const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
+    const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
     const int64_t total = (R + kSR - 1) / kSR;
-    const int64_t q = total / gridDim.x, rem = total % gridDim.x;
-    const int64_t s_lo = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
-    const int T = static_cast<int>(q + (blockIdx.x < rem ? 1 : 0));      // >= 1
+    const int64_t q = total / nblk, rem = total % nblk;
+    const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
+    const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1
     const int TP = (T + kDepth - 1) / kDepth * kDepth;
 
     if (w >= kCons) {
@@ -296,15 +313,42 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
 
 size_t row_gemm_n384_mask_words(int64_t R) { return static_cast<size_t>((R + kSR - 1) / kSR) * kCons * 64; }
 
+namespace {
+struct Pending {
+    bool valid = false;
+    Prob p;
+};
+thread_local Pending g_rider;
+
+int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
+    const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
+    int nb0, nb1;
+    pair_split(st0, st1, 256, &nb0, &nb1);
+    DG_OPT_IN_LDS((&row_gemm_n384_kernel), kLds);
+    hipLaunchKernelGGL(row_gemm_n384_kernel, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
+    return 0;
+}
+}  // namespace
+
+int flush_row_gemm_n384(hipStream_t stream) {
+    if (!g_rider.valid) return 0;
+    g_rider.valid = false;
+    return launch(g_rider.p, nullptr, stream);
+}
+
 int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream) {
-    const int64_t stages = (R + kSR - 1) / kSR;
-    const int blocks = static_cast<int>(stages < 256 ? stages : 256);
-    Epi ep{bias, mask_bits, relu_bits, relu};
-    DG_OPT_IN_LDS((&row_gemm_n384_kernel), kLds);
-    hipLaunchKernelGGL(row_gemm_n384_kernel, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a,
-                       static_cast<const f16x8*>(packed), y, R, ep);
-    return 0;
+    const Prob p{a, static_cast<const f16x8*>(packed), y, R, Epi{bias, mask_bits, relu_bits, relu}};
+    if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
+        g_rider.valid = true;
+        g_rider.p = p;
+        return 0;
+    }
+    if (g_rider.valid) {
+        g_rider.valid = false;
+        return launch(p, &g_rider.p, stream);
+    }
+    return launch(p, nullptr, stream);
 }
 
 }  // namespace dg

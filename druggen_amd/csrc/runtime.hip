@@ -1,5 +1,9 @@
 // Error reporting and the opt-in event profiler of libdruggen_hip.so.
 #include "common.h"
+#include "pair.h"
+#include "row_gemm_k384.h"
+#include "row_gemm_n384.h"
+#include "wgrad_stream.h"
 
 #include <mutex>
 #include <vector>
@@ -78,9 +82,27 @@ ProfScope::~ProfScope() {
     if (idx < g_spans.size()) (void)hipEventRecord(g_spans[idx].stop, stream);
 }
 
+static thread_local bool g_pair_mode = false;
+bool pair_mode() { return g_pair_mode; }
+
 }  // namespace dg
 
 extern "C" {
+
+int dg_launch_pair_begin(void) {
+    dg::g_pair_mode = true;
+    return 0;
+}
+
+int dg_launch_pair_end(dg_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    dg::g_pair_mode = false;
+    int st = dg::flush_row_gemm_n384(stream);
+    const int st2 = dg::flush_row_gemm_k384(stream);
+    const int st3 = dg::flush_wgrad_stream(stream);
+    st = st ? st : (st2 ? st2 : st3);
+    return st ? st : dg::check_launch("dg_launch_pair_end");
+}
 
 int dg_version(void) { return DG_VERSION; }
 

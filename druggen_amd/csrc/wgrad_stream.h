@@ -6,11 +6,15 @@
 namespace dg {
 
 bool wgrad_stream_supported(int N, int K);
-// workgroups (= split-K partials) the launch uses for R rows
-int wgrad_stream_blocks(int64_t R, int N, int K);
+// workgroups (= split-K partials) the launch uses for R rows.  may_wait: the caller's reduce is deferred
+// (dg_linear_wgrad_batch), so inside dg_launch_pair_begin / _end a node-level launch may wait for a carrier (pair.h) --
+// the SAME value must be passed to launch_wgrad_stream
+int wgrad_stream_blocks(int64_t R, int N, int K, bool may_wait = false);
 // part_w [blocks][N][K], part_b [blocks][N] (nullable): partial sums, reduced by the caller in a fixed order
 // dy1 / dy2 (N = 384, K = 128 only): dy's three 128-column blocks given as three [R,128] matrices
 int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream, const float* dy1 = nullptr, const float* dy2 = nullptr);
+                        hipStream_t stream, const float* dy1 = nullptr, const float* dy2 = nullptr, bool may_wait = false);
+// launches a problem that is still waiting for its carrier (pair.h)
+int flush_wgrad_stream(hipStream_t stream);
 
 }  // namespace dg

@@ -24,6 +24,7 @@
 // the exact power-of-two ratio and re-enter.
 #include "bf16.h"
 #include "wgrad_stream.h"
+#include "pair.h"
 
 // Developer builds only (-DWS_DBG=<bits>, loaded through DG_LIB; scripts/build_variant.sh): ablations that time the
 // kernel with a phase removed -- 1: no MFMAs, 2: raw stores instead of the hi / lo split, 4: no LDS writes, 8: no
@@ -72,13 +73,30 @@ constexpr int kConsumers = 8, kProducers = 4, kDepth = 3;
 constexpr int kStageBytes = 32768;                 // one stage of planes: SR rows x (N + K) columns x (hi + lo)
 constexpr int kHdr = 2 * kStageBytes;              // tags [2][4] u32, then ratios [2][N + K], then final inverse scales [N + K]
 
+// One problem of a launch; workgroups [0, nb0) run problem 0, the others problem 1 (a node-level weight gradient riding
+// in the edge-level launch of the same shape: pair.h).  Each problem has its own partial sums.
+struct ProbW {
+    const float* dy;
+    const float* dy1;
+    const float* dy2;
+    const float* x;
+    float* part_w;
+    float* part_b;
+    int64_t R;
+};
+
 template <int NT, int KT, int CN, int CK>
-__global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_kernel(const float* __restrict__ dy,
-                                                                                     const float* __restrict__ dy1,
-                                                                                     const float* __restrict__ dy2,
-                                                                                     const float* __restrict__ x,
-                                                                                     float* __restrict__ part_w,
-                                                                                     float* __restrict__ part_b, int64_t R) {
+__global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_kernel(const ProbW p0, const ProbW p1, const int nb0) {
+    const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
+    const float* __restrict__ const dy = second ? p1.dy : p0.dy;
+    const float* __restrict__ const dy1 = second ? p1.dy1 : p0.dy1;
+    const float* __restrict__ const dy2 = second ? p1.dy2 : p0.dy2;
+    const float* __restrict__ const x = second ? p1.x : p0.x;
+    float* __restrict__ const part_w = second ? p1.part_w : p0.part_w;
+    float* __restrict__ const part_b = second ? p1.part_b : p0.part_b;
+    const int64_t R = second ? p1.R : p0.R;
+    const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
+    const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
     constexpr int N = NT * 32, K = KT * 32, COLS = N + K, NTILES = NT + KT;
     constexpr int TN = NT / CN, TK = KT / CK;
     constexpr int CW = COLS / kProducers;          // columns per producer
@@ -95,9 +113,9 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
 
     // stages of this workgroup: a contiguous range, as even as possible
     const int64_t total = (R + SR - 1) / SR;
-    const int64_t q = total / gridDim.x, rem = total % gridDim.x;
-    const int64_t s_lo = blockIdx.x * q + (blockIdx.x < rem ? blockIdx.x : rem);
-    const int T = static_cast<int>(q + (blockIdx.x < rem ? 1 : 0));      // >= 1 (gridDim.x <= total)
+    const int64_t q = total / nblk, rem = total % nblk;
+    const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
+    const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1 (workgroups of a problem <= its stages)
     const int TP = (T + kDepth - 1) / kDepth * kDepth;                    // iterations incl. padding (whole groups of kDepth)
 
     if (w >= kConsumers) {
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                 bsum.z = xor_step<false>(bsum.z, 16);
                 bsum.w = xor_step<false>(bsum.w, 16);
             }
-            if (rg == 0) st4(part_b + static_cast<size_t>(blockIdx.x) * N + p * CW + 4 * cq, bsum);
+            if (rg == 0) st4(part_b + static_cast<size_t>(bidx) * N + p * CW + 4 * cq, bsum);
         }
         return;
     }
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         }
     }
     __syncthreads();      // final inverse scales are in LDS
-    float* pw = part_w + static_cast<size_t>(blockIdx.x) * N * K;
+    float* pw = part_w + static_cast<size_t>(bidx) * N * K;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -380,24 +398,23 @@ bool wgrad_stream_supported(int N, int K) {
 // rows per stage of the shape (16 for the 512-column shapes, 32 for 128 x 128)
 static int stage_rows(int N, int K) { return 32768 / ((N + K) * 4); }
 
-int wgrad_stream_blocks(int64_t R, int N, int K) {
-    const int64_t stages = (R + stage_rows(N, K) - 1) / stage_rows(N, K);
-    // every workgroup writes an [N, K] partial: short launches use fewer workgroups (>= 4 stages each)
-    int64_t blocks = stages / 4;
-    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-    return static_cast<int>(blocks);
-}
 
-int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream, const float* dy1, const float* dy2) {
-    if ((dy1 || dy2) && (!dy1 || !dy2 || N != 384 || K != 128))
-        return fail(DG_E_ARG, "wgrad_stream: three dy matrices need N = 384, K = 128");
+namespace {
+struct Pending {
+    bool valid = false;
+    ProbW p;
+    int N = 0, K = 0, blocks = 0;
+};
+thread_local Pending g_rider;
+
+int launch(const ProbW& p0, int nb0, const ProbW* p1, int nb1, int N, int K, hipStream_t stream) {
     const int lds = kHdr + 64 + 3 * (N + K) * 4;
+    const ProbW& q1 = p1 ? *p1 : p0;
 #define DG_WS_LAUNCH(NT_, KT_, CN_, CK_)                                                                          \
     {                                                                                                            \
         DG_OPT_IN_LDS((&wgrad_stream_kernel<NT_, KT_, CN_, CK_>), lds);                                           \
-        hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_>), dim3(blocks), dim3(64 * (kConsumers + kProducers)), \
-                           lds, stream, dy, dy1, dy2, x, part_w, part_b, R);                                    \
+        hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_>), dim3(nb0 + nb1), dim3(64 * (kConsumers + kProducers)), \
+                           lds, stream, p0, q1, nb0);                                                            \
     }
     if (N == 128 && K == 128) DG_WS_LAUNCH(4, 4, 4, 2)
     else if (N == 384 && K == 128) DG_WS_LAUNCH(12, 4, 4, 2)
@@ -405,6 +422,53 @@ int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* p
     else return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
 #undef DG_WS_LAUNCH
     return 0;
+}
+}  // namespace
+
+// Workgroups (= partial sums) of a launch, fixed when the call is made: the caller lays out the workspace and records the
+// reduce with this count.  A launch that will wait for a carrier (pair.h) gets its share of a full grid next to an
+// edge-level problem -- one workgroup per ~2 000 rows; the carrier then takes the rest of the 256.
+int wgrad_stream_blocks(int64_t R, int N, int K, bool may_wait) {
+    const int64_t stages = (R + stage_rows(N, K) - 1) / stage_rows(N, K);
+    if (may_wait && pair_mode() && R <= kRiderMaxRows && !g_rider.valid) {
+        int64_t b = (R + 1023) / 2048;
+        b = b < 1 ? 1 : (b > 32 ? 32 : b);
+        return static_cast<int>(b > stages ? stages : b);
+    }
+    // every workgroup writes an [N, K] partial: short launches use fewer workgroups (>= 4 stages each)
+    int64_t blocks = stages / 4;
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    if (g_rider.valid && g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks > 256) blocks = 256 - g_rider.blocks;
+    return static_cast<int>(blocks);
+}
+
+int flush_wgrad_stream(hipStream_t stream) {
+    if (!g_rider.valid) return 0;
+    g_rider.valid = false;
+    return launch(g_rider.p, g_rider.blocks, nullptr, 0, g_rider.N, g_rider.K, stream);
+}
+
+int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
+                        hipStream_t stream, const float* dy1, const float* dy2, bool may_wait) {
+    if ((dy1 || dy2) && (!dy1 || !dy2 || N != 384 || K != 128))
+        return fail(DG_E_ARG, "wgrad_stream: three dy matrices need N = 384, K = 128");
+    if (!wgrad_stream_supported(N, K)) return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
+    const ProbW p{dy, dy1, dy2, x, part_w, part_b, R};
+    if (may_wait && pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this shape
+        g_rider.valid = true;
+        g_rider.p = p;
+        g_rider.N = N;
+        g_rider.K = K;
+        g_rider.blocks = blocks;
+        return 0;
+    }
+    if (g_rider.valid) {
+        g_rider.valid = false;
+        if (g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks <= 256)
+            return launch(p, blocks, &g_rider.p, g_rider.blocks, N, K, stream);
+        if (int st = launch(g_rider.p, g_rider.blocks, nullptr, 0, g_rider.N, g_rider.K, stream)) return st;
+    }
+    return launch(p, blocks, nullptr, 0, N, K, stream);
 }
 
 }  // namespace dg

@@ -364,6 +364,23 @@ def _reduce_batch(ref, on=True):
             _lib.check(lib.dg_linear_wgrad_batch_end(_lib.stream_of(ref)), "dg_linear_wgrad_batch_end")
 
 
+@contextlib.contextmanager
+def _pair_launches(ref, on=True):
+    """dg_launch_pair_begin / _end: node-level launches of the 384-wide row GEMMs and of the producer / consumer weight
+    gradients issued inside wait for -- and ride in -- the next launch of the same kernel (include/druggen_hip.h).  The
+    caller issues node, edge, node, edge ... and reads no waiting result before its carrier was called."""
+    if not (on and ref.is_cuda):
+        yield False
+        return
+    lib = _lib.load()
+    with _dev(ref):
+        _lib.check(lib.dg_launch_pair_begin(), "dg_launch_pair_begin")
+        try:
+            yield True
+        finally:
+            _lib.check(lib.dg_launch_pair_end(_lib.stream_of(ref)), "dg_launch_pair_end")
+
+
 def _wgrad_many(items, open_batch=True):
     """[(dy2, x2, want_bias), ...] -> [(dW, db), ...]: the split-K kernels of up to 8 weight gradients run back to back
     into separate workspaces and ONE launch reduces them all (dg_linear_wgrad_batch_begin / _end) -- the six projections
@@ -1092,6 +1109,201 @@ class _FFNLNBwd(Function):
         # node (second output of _FFNLN), which runs ONE backward pass for both gradient sources.
         # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff
         return None, gw1, None, gw2, None, gbar, None, None, None, zbar, None, dybar.view_as(t_dx), None, None, None, None
+
+
+
+def _ffn_pair_enabled() -> bool:
+    """DG_FFN_PAIR=off: the node and the edge feed-forward of a block as two autograd nodes (A/B measurements)."""
+    return os.environ.get("DG_FFN_PAIR", "on") != "off"
+
+
+class _FFNLNPair(Function):
+    """The two feed-forward halves of an Encoder_Block -- ``x = ln5(x + mlp(x))`` over the B N node rows and
+    ``y = ln6(y + mlp2(y))`` over the B N^2 edge rows (reference layers.py:191-192) -- as ONE autograd node: each of
+    its launches over the node rows rides in the launch of the same kernel over the edge rows (``_pair_launches``).
+    Per branch exactly ``_FFNLN``: same kernels, same saved tensors, same extra outputs (pre-LayerNorm sum, row statistics)."""
+
+    @staticmethod
+    def forward(ctx, eps_n, eps_e, *args):      # args = (x, w1, b1, w2, b2, gamma, beta) of the node branch, then of the edge branch
+        lib = _lib.load()
+        keep = any(ctx.needs_input_grad)
+        probs = []
+        for inp, w1, b1, w2, b2, gamma, beta in (args[0:7], args[7:14]):
+            H, C = w1.shape
+            x2 = _c(inp).reshape(-1, C)
+            R = x2.shape[0]
+            dev, adt = x2.device, x2.dtype
+            code = _lib.dt(x2)
+            probs.append(dict(
+                inp=inp, x2=x2, R=R, C=C, H=H, code=code, w1=w1, b1=b1, w2=w2, b2=b2, gamma=gamma, beta=beta,
+                y=torch.empty(R, C, dtype=adt, device=dev), h=torch.empty(R, H, dtype=adt, device=dev),
+                pre=torch.empty(R, C, dtype=adt, device=dev) if keep else None,
+                mean=torch.empty(R, dtype=torch.float32, device=dev), rstd=torch.empty(R, dtype=torch.float32, device=dev),
+                bits=torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev) if keep else None))
+        ref = probs[0]["x2"]
+        with _pair_launches(ref):
+            st = _lib.stream_of(ref)
+            for p in probs:      # h = relu(x W1^T + b1) (+ the ReLU bit mask)
+                _lib.check(lib.dg_row_gemm(_lib.ptr(p["x2"]), packed_weight(p["w1"], 0, ref.dtype).data_ptr(), _lib.ptr(p["h"]),
+                                           p["R"], p["C"], p["H"], _lib.fptr(_c(p["b1"])), 1,
+                                           None if p["bits"] is None else p["bits"].data_ptr(), None, None, None, None, None,
+                                           None, None, 0.0, p["code"], st), "dg_row_gemm")
+            for p, eps in zip(probs, (eps_n, eps_e)):      # y = LN(x + h W2^T + b2)
+                _lib.check(lib.dg_row_gemm(_lib.ptr(p["h"]), packed_weight(p["w2"], 0, ref.dtype).data_ptr(), _lib.ptr(p["y"]),
+                                           p["R"], p["H"], p["C"], _lib.fptr(_c(p["b2"])), 0, None, None, _lib.ptr(p["x2"]),
+                                           _lib.fptr(_c(p["gamma"])), _lib.fptr(_c(p["beta"])), _lib.ptr(p["mean"]),
+                                           _lib.ptr(p["rstd"]), _lib.ptr(p["pre"]), float(eps), p["code"], st), "dg_row_gemm")
+        es = ref.element_size()
+        for p in probs:
+            R, C, H = p["R"], p["C"], p["H"]
+            _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+            _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H)
+        pn, pe = probs
+        outs = (pn["y"].view(pn["inp"].shape), pn["pre"], pn["mean"], pn["rstd"],
+                pe["y"].view(pe["inp"].shape), pe["pre"], pe["mean"], pe["rstd"])
+        ctx.mark_non_differentiable(pn["mean"], pn["rstd"], pe["mean"], pe["rstd"])
+        if not keep:
+            return outs
+        ctx.save_for_backward(*args[0:7], pn["h"], pn["mean"], pn["rstd"], pn["pre"], pn["bits"],
+                              *args[7:14], pe["h"], pe["mean"], pe["rstd"], pe["pre"], pe["bits"])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dyn, dpren, _dmn, _drn, dye, dpree, _dme=None, _dre=None):
+        sv = ctx.saved_tensors
+        call = []
+        for base, off, dy, dpre in ((0, 2, dyn, dpren), (12, 9, dye, dpree)):
+            x, w1, b1, w2, b2, gamma, beta, h, mean, rstd, pre, bits = sv[base:base + 12]
+            want_w = ctx.needs_input_grad[off + 1] and not _inputs_only()
+            want_aff = (ctx.needs_input_grad[off + 5] or ctx.needs_input_grad[off + 6]) and not _inputs_only()
+            if dy is None and (dpre is None or torch.is_grad_enabled()):
+                dy = torch.zeros_like(pre)
+            call += [x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dpre, ctx.needs_input_grad[off], want_w, want_aff]
+        o = _FFNLNPairBwd.apply(*call)
+        return (None, None, *o[0:7], *o[7:14])
+
+
+class _FFNLNPairBwd(Function):
+    """Backward of ``_FFNLNPair`` as a differentiable node: per branch the sequence of ``_FFNLNBwd`` (LayerNorm backward,
+    dh = (dz W2) * m, dx = dz + dh W1, the two weight gradients), node-level launches riding in the edge-level ones; its own
+    backward (second order of the gradient penalty) pairs the same way."""
+
+    @staticmethod
+    def forward(ctx, *args):      # per branch: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff
+        lib = _lib.load()
+        probs = []
+        for x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff in (args[0:16], args[16:32]):
+            H, C = w1.shape
+            R = pre.shape[0]
+            adt = pre.dtype
+            p = dict(x=x, x2=_c(x).reshape(-1, C), w1=w1, w2=w2, gamma=gamma, h=h, mean=mean, rstd=rstd, pre=pre, bits=bits,
+                     R=R, C=C, H=H, want_x=want_x, want_w=want_w, want_aff=want_aff, had_add=dz_add is not None,
+                     dgamma=None, dbeta=None)
+            if dy is None:      # dz_add IS the LayerNorm input gradient (made by dg_row_gemm_ln_bwd in the consumer of y)
+                p["dy2"] = None
+                p["dz"] = p["dz_add"] = _c(dz_add if dz_add.dtype == adt else dz_add.to(adt)).reshape(-1, C)
+            else:
+                p["dy2"] = _c(dy if dy.dtype == adt else dy.to(adt)).reshape(-1, C)
+                p["dz_add"] = None if dz_add is None else _c(dz_add if dz_add.dtype == adt else dz_add.to(adt)).reshape(-1, C)
+                p["dz"] = None
+            probs.append(p)
+        ref = probs[0]["pre"]
+        adt = ref.dtype
+        pw = lambda w_, m_: packed_weight(w_, m_, adt)
+        any_w = any(p["want_w"] or (p["want_aff"] and p["dy2"] is not None) for p in probs)
+        with _reduce_batch(ref, on=any_w) as inb, _pair_launches(ref):
+            for i, p in enumerate(probs):
+                if p["dy2"] is not None:
+                    p["dz"], p["dgamma"], p["dbeta"] = _ln_bwd_rows(p["pre"], p["gamma"], p["mean"], p["rstd"], p["dy2"],
+                                                                     p["dz_add"], want_affine=p["want_aff"],
+                                                                     batch_slot=i if inb else None)
+            for p in probs:      # dh = (dz W2) masked by the forward's ReLU bits
+                p["dh"] = row_gemm(p["dz"], pw(p["w2"], 1), p["C"], p["H"], mask_bits=p["bits"])
+            for p in probs:      # dx = dz + dh W1
+                p["dx"] = row_gemm(p["dh"], pw(p["w1"], 1), p["H"], p["C"], residual=p["dz"]) if p["want_x"] else None
+            items = [(p["dz"], p["h"], True) for p in probs if p["want_w"]] + [(p["dh"], p["x2"], True) for p in probs if p["want_w"]]
+            res = iter(_wgrad_many(items, open_batch=not inb)) if items else iter(())
+            for p in probs:
+                p["dw2"], p["db2"] = next(res) if p["want_w"] else (None, None)
+            for p in probs:
+                p["dw1"], p["db1"] = next(res) if p["want_w"] else (None, None)
+        saved, outs = [], []
+        for p in probs:
+            saved += [p["x"], p["w1"], p["w2"], p["gamma"], p["h"], p["mean"], p["rstd"], p["pre"], p["bits"], p["dy2"], p["dz"], p["dh"]]
+            outs += [None if p["dx"] is None else p["dx"].view(p["x"].shape), p["dw1"], p["db1"], p["dw2"], p["db2"],
+                     p["dgamma"], p["dbeta"]]
+        ctx.save_for_backward(*saved)
+        ctx.had_add = tuple(p["had_add"] for p in probs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *t):
+        for k in (0, 7):
+            if any(g is not None for g in t[k + 1:k + 7]):
+                raise RuntimeError("ffn_ln: second-order terms through parameter gradients are not implemented")
+        sv = ctx.saved_tensors
+        probs = []
+        for i, k in enumerate((0, 7)):
+            if t[k] is None:
+                probs.append(None)
+                continue
+            if ctx.had_add[i]:
+                raise RuntimeError("ffn_ln: third-order differentiation is not implemented")
+            x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh = sv[12 * i:12 * i + 12]
+            H, C = w1.shape
+            adt = pre.dtype
+            probs.append(dict(w1=w1, w2=w2, gamma=gamma, mean=mean, rstd=rstd, pre=pre, bits=bits, dy2=dy2, dz=dz, dh=dh, C=C, H=H,
+                              t_dx=t[k], t=_c(t[k] if t[k].dtype == adt else t[k].to(adt)).reshape(-1, C)))
+        live = [p for p in probs if p is not None]
+        if not live:
+            return (None,) * 32
+        ref = live[0]["pre"]
+        pw = lambda w_, m_: packed_weight(w_, m_, ref.dtype)
+        with _pair_launches(ref):
+            for p in live:
+                p["vbar"] = row_gemm(p["t"], pw(p["w1"], 0), p["C"], p["H"], mask_bits=p["bits"])              # (t W1^T) * m
+            for p in live:
+                p["ubar"] = row_gemm(p["vbar"], pw(p["w2"], 0), p["H"], p["C"], residual=p["t"])             # t + vbar W2^T
+        for p in live:
+            p["zbar"], p["dybar"], p["gbar"] = _ln_bwd2_rows(p["pre"], p["gamma"], p["mean"], p["rstd"], p["dy2"], p["ubar"])
+            p["gw1"] = p["gw2"] = None
+        if not _inputs_only():
+            with _pair_launches(ref):
+                res = _wgrad_many([(p["dh"], p["t"], False) for p in live] +          # ((u W2)*m)^T t
+                                  [(p["dz"], p["vbar"], False) for p in live])        # u^T ((t W1^T)*m)
+            for p, r in zip(live, res[:len(live)]):
+                p["gw1"] = r[0]
+            for p, r in zip(live, res[len(live):]):
+                p["gw2"] = r[0]
+        out = []
+        for p in probs:
+            if p is None:
+                out += [None] * 16
+            else:
+                # inputs: x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dz_add, want_x, want_w, want_aff
+                out += [None, p["gw1"], None, p["gw2"], None, p["gbar"], None, None, None, p["zbar"], None,
+                        p["dybar"].view_as(p["t_dx"]), None, None, None, None]
+        return tuple(out)
+
+
+def ffn_ln_pair(x, node, y, edge):
+    """``(ffn_ln(x, *node), ffn_ln(y, *edge, want_handle=True))`` -- node = (w1, b1, w2, b2, gamma, beta, eps) of mlp / ln5,
+    edge the same of mlp2 / ln6 -- as one autograd node whose node-level launches ride in the edge-level ones
+    (``_FFNLNPair``; float32 activations, dim 128, hidden 384).  Returns (x_out, y_out, LNHandle of ln6 or None)."""
+    def ok(t, w1, b1, w2, b2):
+        H, C = w1.shape
+        return (t.is_cuda and t.dtype == torch.float32 and C == 128 and H == 384 and tuple(w2.shape) == (C, H)
+                and b1 is not None and b2 is not None)
+    if not (_ffn_pair_enabled() and ok(x, *node[:4]) and ok(y, *edge[:4]) and x.device == y.device):
+        xo = ffn_ln(x, *node)
+        yo, handle = ffn_ln(y, *edge, want_handle=True)
+        return xo, yo, handle
+    xo, _pn, _mn, _rn, yo, pre, mean, rstd = _FFNLNPair.apply(float(node[6]), float(edge[6]), x, *node[:6], y, *edge[:6])
+    handle = LNHandle(pre, mean, rstd, edge[4], edge[5]) if (pre is not None and pre.requires_grad) else None
+    return xo, yo, handle
 
 
 _ffn_pack_cache = {}

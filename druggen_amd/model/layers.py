@@ -32,6 +32,9 @@ class MLP(nn.Module):
         h = dgf.linear_relu(x, self.fc1.weight, self.fc1.bias)
         return self.droprateout(dgf.linear(h, self.fc2.weight, self.fc2.bias))
 
+    def ffn_ln_args(self, ln):
+        return (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, ln.weight, ln.bias, ln.eps)
+
     def forward_residual_ln(self, x, ln, want_handle=False):
         """ln(x + self(x)) -- Encoder_Block lines 191-192 of the reference -- with fc2, the
         residual add and the LayerNorm in one kernel when dropout is inactive.  ``want_handle``: also returns
@@ -105,9 +108,14 @@ class Encoder_Block(nn.Module):
         x1 = self._ln(self.ln1, x)
         # q/k/v/e projections, attention core, out_n/out_e + residual + ln3/ln4: one autograd node
         x2, y2 = dgf.attn_block(x1, y, self.attn, self.ln3, self.ln4, need_edge, y_ln=y_ln)
-        x = self.mlp.forward_residual_ln(x2, self.ln5)
         if not need_edge:
+            x = self.mlp.forward_residual_ln(x2, self.ln5)
             return (x, None, None) if want_ln else (x, None)
+        if not (self.training and (self.mlp.droprateout.p > 0.0 or self.mlp2.droprateout.p > 0.0)):
+            # both feed-forward halves as one node: the node-level launches ride in the edge-level ones
+            x, y, handle = dgf.ffn_ln_pair(x2, self.mlp.ffn_ln_args(self.ln5), y2, self.mlp2.ffn_ln_args(self.ln6))
+            return (x, y, handle) if want_ln else (x, y)
+        x = self.mlp.forward_residual_ln(x2, self.ln5)
         y, handle = self.mlp2.forward_residual_ln(y2, self.ln6, want_handle=True)
         return (x, y, handle) if want_ln else (x, y)
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 216            /* 0.2.2: + three Linears per launch (dg_row_gemm_lin3 / _sum3 / _pack3, dg_linear_wgrad3) */
+#define DG_VERSION 217            /* 0.2.3: + riding launches (dg_launch_pair_begin / _end) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -182,6 +182,18 @@ int dg_linear_wgrad3(const void* dy0, const void* dy1, const void* dy2, const vo
  * their partial sums (the workspace) must then stay untouched until _batch_end().                                  */
 int dg_linear_wgrad_batch_begin(void);
 int dg_linear_wgrad_batch_end(dg_stream_t stream);
+
+/* Riding launches: the node branch of an Encoder_Block (mlp / ln5, reference layers.py:191) runs the same kernels as its edge
+ * branch (mlp2 / ln6, :192) over N times fewer rows -- launches of 10-25 us that are all prologue and tail.  Between
+ * _pair_begin() and _pair_end() a float32 dg_row_gemm with (K,N) = (128,384) or (384,128), or a float32 dg_linear_wgrad
+ * / dg_linear_wgrad3 on the producer / consumer kernel, over at most 65 536 rows is NOT launched when it is called: it
+ * waits (one per kernel) and runs as a second problem inside the NEXT launch of the same kernel (same epilogue class for
+ * the 384 -> 128 GEMM, same shape for the weight gradient), whose workgroups are split between the two in proportion to
+ * their rows.  Results are those of separate launches (weight gradients: a different, still fixed, number of partial
+ * sums).  The CALLER guarantees that no other launch reads a waiting problem's output before its carrier was called:
+ * issue node, edge, node, edge ...  _pair_end() launches whatever still waits on `stream`.  Per host thread.         */
+int dg_launch_pair_begin(void);
+int dg_launch_pair_end(dg_stream_t stream);
 
 /* ---- fp32-MFMA row GEMM with fused epilogues ------------------------------------
  * The dense layers applied to every edge / node row: MHA projections

@@ -203,6 +203,95 @@ def test_three_linears_per_launch_match_three_launches(R):
     assert _rel(dgf.lin3(x, ws, bs)[2], x.double().cpu() @ ws[2].double().cpu().t() + bs[2].double().cpu()) < TOL
 
 
+@pytest.mark.parametrize("Rn,Re", [(45, 2025), (360, 16200), (11520, 518400), (23040, 40000)])
+def test_riding_launches_equal_separate_launches(Rn, Re):
+    """dg_launch_pair_begin / _end: a node-level launch of a 384-wide row GEMM or of a producer / consumer weight
+    gradient waits and runs as the second problem of the next launch of the same kernel (workgroups split by rows).
+    Row GEMMs are row-local: bit-identical to separate launches, ReLU bit masks included; weight gradients use another
+    (fixed) number of partial sums: equal to rounding, and reproducible.  A problem nobody carries leaves at _pair_end."""
+    from druggen_amd import functional as dgf
+    w1 = [(_gen((384, 128), 100 + i) * 0.1).float().cuda() for i in range(2)]
+    b1 = [_gen((384,), 110 + i).float().cuda() for i in range(2)]
+    w2 = [(_gen((128, 384), 120 + i) * 0.1).float().cuda() for i in range(2)]
+    b2 = [_gen((128,), 130 + i).float().cuda() for i in range(2)]
+    g = [(_gen((128,), 140 + i) * 0.1 + 1).float().cuda() for i in range(2)]
+    be = [_gen((128,), 150 + i).float().cuda() for i in range(2)]
+    xs = [_gen((R, 128), 160 + i).float().cuda() for i, R in enumerate((Rn, Re))]
+
+    def chain(paired):
+        out = []
+        with dgf._pair_launches(xs[0], on=paired):
+            hs = [dgf.row_gemm(x, dgf.packed_weight(w1[i], 0), 128, 384, bias=b1[i], relu=True, want_relu_bits=True)
+                  for i, x in enumerate(xs)]
+            ys = [dgf.row_gemm(h, dgf.packed_weight(w2[i], 0), 384, 128, bias=b2[i], residual=xs[i], ln=(g[i], be[i], 1e-5),
+                               want_pre=True) for i, (h, _) in enumerate(hs)]
+            dh = [dgf.row_gemm(y[0], dgf.packed_weight(w2[i], 1), 128, 384, mask_bits=hs[i][1]) for i, y in enumerate(ys)]
+            dx = [dgf.row_gemm(d, dgf.packed_weight(w1[i], 1), 384, 128, residual=ys[i][0]) for i, d in enumerate(dh)]
+            wg = dgf._wgrad_many([(ys[0][0], hs[0][0], True), (ys[1][0], hs[1][0], True), (dh[0], xs[0], True), (dh[1], xs[1], True)])
+        for i in range(2):      # (the mask buffer is sized for every 128 -> 384 kernel; this one writes 512 words per 32 rows)
+            out.append([hs[i][0], hs[i][1][:(xs[i].shape[0] + 31) // 32 * 512], *ys[i], dh[i], dx[i]])
+        return out, wg
+
+    sep, wsep = chain(False)
+    par, wpar = chain(True)
+    for a, b in zip(sep, par):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    for (dw, db), (ew, eb) in zip(wsep, wpar):
+        assert _rel(ew, dw.double().cpu()) < 2e-6 and _rel(eb, db.double().cpu()) < 2e-6
+    assert _rel(wpar[0][0], sep[0][2].double().cpu().t() @ sep[0][0].double().cpu()) < TOL
+    assert _rel(wpar[3][0], sep[1][6].double().cpu().t() @ xs[1].double().cpu()) < TOL
+    again, wagain = chain(True)
+    for (dw, db), (ew, eb) in zip(wpar, wagain):
+        assert torch.equal(dw, ew) and torch.equal(db, eb)
+    # a rider nobody carries: launched by _pair_end
+    with dgf._pair_launches(xs[0]):
+        lone = dgf.row_gemm(xs[0], dgf.packed_weight(w1[0], 0), 128, 384, bias=b1[0])
+    assert torch.equal(lone, dgf.row_gemm(xs[0], dgf.packed_weight(w1[0], 0), 128, 384, bias=b1[0]))
+    # a rider whose 384 -> 128 epilogue differs from the next launch's: on its own, in order
+    with dgf._pair_launches(xs[0]):
+        plain = dgf.row_gemm(sep[0][0], dgf.packed_weight(w2[0], 0), 384, 128)
+        withres = dgf.row_gemm(sep[1][0], dgf.packed_weight(w2[1], 0), 384, 128, residual=xs[1])
+    assert torch.equal(plain, dgf.row_gemm(sep[0][0], dgf.packed_weight(w2[0], 0), 384, 128))
+    assert torch.equal(withres, dgf.row_gemm(sep[1][0], dgf.packed_weight(w2[1], 0), 384, 128, residual=xs[1]))
+
+
+@pytest.mark.parametrize("B,N", [(2, 9), (8, 45)])
+def test_paired_feed_forward_nodes_match_the_two_single_nodes(B, N, monkeypatch):
+    """ffn_ln_pair (mlp / ln5 over the node rows + mlp2 / ln6 over the edge rows of an Encoder_Block, reference
+    layers.py:191-192, as one autograd node) against the two ffn_ln nodes: forward and input gradients bit-identical,
+    parameter gradients to rounding, and the same through a double backward (gradient-penalty pattern, loss.py:28-39)."""
+    from druggen_amd import functional as dgf
+    C, H = 128, 384
+    mk = lambda s, shape, scale=1.0: (_gen(shape, s) * scale).float().cuda().requires_grad_(True)
+    params = [[mk(200 + 10 * i, (H, C), 0.1), mk(201 + 10 * i, (H,)), mk(202 + 10 * i, (C, H), 0.1), mk(203 + 10 * i, (C,)),
+               mk(204 + 10 * i, (C,)), mk(205 + 10 * i, (C,))] for i in range(2)]
+    x0, y0 = mk(230, (B, N, C)), mk(231, (B, N, N, C))
+    gx, gy = _gen((B, N, C), 232).float().cuda(), _gen((B, N, N, C), 233).float().cuda()
+
+    def run(mode, second):
+        monkeypatch.setenv("DG_FFN_PAIR", mode)
+        x, y = x0.detach().clone().requires_grad_(True), y0.detach().clone().requires_grad_(True)
+        xo, yo, _ = dgf.ffn_ln_pair(x, (*params[0], 1e-5), y, (*params[1], 1e-5))
+        flat = [x, y] + params[0] + params[1]
+        if not second:
+            return [xo, yo] + list(torch.autograd.grad([xo, yo], flat, [gx, gy]))
+        with dgf.inputs_only_backward():
+            dx, dy = torch.autograd.grad([xo, yo], [x, y], [gx, gy], create_graph=True)
+        pen = (dx.square().sum() + dy.square().sum()) * 0.5
+        return [dx, dy] + list(torch.autograd.grad(pen, flat, allow_unused=True))      # (biases / beta: no second-order term)
+
+    for second in (False, True):
+        one, two = run("off", second), run("on", second)
+        for i, (a, b) in enumerate(zip(one, two)):
+            if a is None or b is None:
+                assert a is None and b is None, i
+            elif i < 4:
+                assert torch.equal(a, b), i
+            else:
+                assert _rel(b, a.double().cpu()) < 5e-6, i
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
