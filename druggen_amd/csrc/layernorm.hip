@@ -175,8 +175,20 @@ __global__ __launch_bounds__(1024) void ln_finish_kernel(const float* __restrict
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     const int g = threadIdx.x >> 5;
     float s = 0.f;
-    if (c < C)
-        for (int b = g; b < nblocks; b += 32) s += part[(static_cast<size_t>(b) * K + k) * C + c];
+    if (c < C) {
+        // eight independent loads in flight per thread (the launch is all latency: 1 024 partials = 32 per thread), summed in
+        // a fixed order
+        const float* src = part + static_cast<size_t>(k) * C + c;
+        const size_t step = static_cast<size_t>(K) * C;
+        int b = g;
+        for (; b + 7 * 32 < nblocks; b += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(b + 32 * u) * step];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; b < nblocks; b += 32) s += src[static_cast<size_t>(b) * step];
+    }
     red[g][threadIdx.x & 31] = s;
     __syncthreads();
     if (g == 0 && c < C) {

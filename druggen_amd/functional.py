@@ -381,14 +381,16 @@ def _pair_launches(ref, on=True):
             _lib.check(lib.dg_launch_pair_end(_lib.stream_of(ref)), "dg_launch_pair_end")
 
 
-def _wgrad_many(items, open_batch=True):
+def _wgrad_many(items, open_batch=True, pair_from=None):
     """[(dy2, x2, want_bias), ...] -> [(dW, db), ...]: the split-K kernels of up to 8 weight gradients run back to back
     into separate workspaces and ONE launch reduces them all (dg_linear_wgrad_batch_begin / _end) -- the six projections
-    of an attention block used to cost six reduce launches.  Shapes outside the MFMA kernel take their usual path."""
+    of an attention block used to cost six reduce launches.  Shapes outside the MFMA kernel take their usual path.
+    ``pair_from``: items[pair_from:] are issued inside ``_pair_launches`` (a node-level item there rides in the next item
+    of its shape; items before it launch at once -- a waiting launch nobody carries is slow, few workgroups)."""
     lib = _lib.load()
     ref = items[0][0]
     if any(isinstance(dy, tuple) for dy, _, _ in items):      # a (dq, dk, dv) triple: one stacked [384,128] gradient
-        return _wgrad_many_mixed(items, open_batch)
+        return _wgrad_many_mixed(items, open_batch, pair_from)
     ok = (ref.is_cuda and len(items) <= 8 and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
           and all(dy.dtype == x.dtype and dy.shape[1] > 16 and x.shape[1] > 16 for dy, x, _ in items))
     needs = [int(lib.dg_linear_wgrad_workspace_bytes(dy.shape[0], dy.shape[1], x.shape[1])) for dy, x, _ in items] if ok else []
@@ -409,13 +411,15 @@ def _wgrad_many(items, open_batch=True):
     out = []
     with _dev(ref):
         ws = _scratch(ref, total, "wgrad_batch")
-        with _reduce_batch(ref, on=open_batch):
-            for (dy, x, b), off, n in zip(items, offs, needs):
+        with _reduce_batch(ref, on=open_batch), contextlib.ExitStack() as pairing:
+            for i, ((dy, x, b), off, n) in enumerate(zip(items, offs, needs)):
+                if i == pair_from:
+                    pairing.enter_context(_pair_launches(ref))
                 out.append(_wgrad(dy, x, b, ws=ws[off:off + n]))
     return out
 
 
-def _wgrad_many_mixed(items, open_batch=True):
+def _wgrad_many_mixed(items, open_batch=True, pair_from=None):
     """``_wgrad_many`` when an item's dy is a 3-tuple of [R,128] float32 matrices sharing x (``_wgrad3``).  Same batching:
     private workspaces, one reduce launch."""
     lib = _lib.load()
@@ -430,8 +434,10 @@ def _wgrad_many_mixed(items, open_batch=True):
     with _dev(ref):
         ws = _scratch(ref, total, "wgrad_batch")
         batch = open_batch and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
-        with _reduce_batch(ref, on=batch):
-            for (dy, x, b), off, n in zip(items, offs, needs):
+        with _reduce_batch(ref, on=batch), contextlib.ExitStack() as pairing:
+            for i, ((dy, x, b), off, n) in enumerate(zip(items, offs, needs)):
+                if i == pair_from:
+                    pairing.enter_context(_pair_launches(ref))
                 out.append(_wgrad3(dy, x, b, ws=ws[off:off + n]) if isinstance(dy, tuple) else _wgrad(dy, x, b, ws=ws[off:off + n]))
     return out
 
@@ -1693,7 +1699,8 @@ class _AttnBlockBwd(Function):
             items = qkv_items + [(def_, yf, True), (dz3, o, True)]
             if need_edge:
                 items.append((dz4, s, True))
-            res = _wgrad_many(items, open_batch=not inb)
+            # (out_n's weight gradient over the node rows rides in out_e's over the edge rows)
+            res = _wgrad_many(items, open_batch=not inb, pair_from=len(items) - 2 if need_edge else None)
             if use3:      # rows 0..127 / 128..255 / 256..383 of the stacked gradient
                 (w3, b3), res = res[0], res[1:]
                 gw[0:6] = [w3[0:128], b3[0:128], w3[128:256], b3[128:256], w3[256:384], b3[256:384]]
@@ -1754,7 +1761,7 @@ class _AttnBlockBwd(Function):
             items = qkv_items + [(def_, tyf, False), (dz3, gwo.view(-1, C), False)]
             if need_edge:
                 items.append((dz4, gws.view(-1, C), False))
-            res = _wgrad_many(items)
+            res = _wgrad_many(items, pair_from=len(items) - 2 if need_edge else None)
             if use3:
                 w3, res = res[0][0], res[1:]
                 gW[0], gW[2], gW[4] = w3[0:128], w3[128:256], w3[256:384]
