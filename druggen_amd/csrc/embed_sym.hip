@@ -308,7 +308,9 @@ struct BwdPart {
     static constexpr int kW2 = 0, kB2 = kC * kHid, kW1 = kB2 + kC, kB1 = kW1 + kHid * kMaxE, kTotal = kB1 + kHid;
 };
 
-template <typename T, int EP, int ACT>
+// DA: the input gradient is wanted (a template parameter: with a run-time `if (da)` hipcc allocated the whole tile loop for
+// the input-gradient stage -- 255 VGPRs and 84 B of scratch (620 B for EP = 16) against 165-173 VGPRs and none without it)
+template <typename T, int EP, int ACT, bool DA>
 __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2p, const float* __restrict__ w2d, const float* __restrict__ b2,
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
     float4* w1p = reinterpret_cast<float4*>(&ij[kPairs][0]);   // W1 permuted: w1p[u * 4 + eg] = { W1[u][eg + 4 q] }_q
     float* gst = d1;   // symmetrised upstream gradient of the tile [32 pairs][128]: dead before d1 is written
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (da) {   // visible after the first barrier of the tile loop
+    if (DA) {   // visible after the first barrier of the tile loop
         const int u = tid >> 2, eg = tid & 3;
         float v[4];
 #pragma unroll
@@ -432,10 +434,10 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd_kernel(
             }
 #pragma unroll
             for (int e = 0; e < EP; ++e) aw1[e] = fmaf(p, av[e], aw1[e]);
-            if (da) d1[row * kD1Pitch + u] = p;
+            if (DA) d1[row * kD1Pitch + u] = p;
         }
         ESTAMP(5)
-        if (da) {
+        if (DA) {
             __syncthreads();
             // da[row][e] = sum_u dpre1[row][u] W1[u][e]: thread = (tile row, e mod 4); the two halves of a diagonal pair
             // (rows pr and 32 + pr = lanes pr and 32 + pr of the wave) are summed across the wave
@@ -849,11 +851,15 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kD1Pitch + 64 * kMaxE + kHid * 16) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
+#define BWD_D(T, EP_, ACT_, DA_)                                                                                  \
+    {                                                                                                             \
+        DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_, ACT_, DA_>), lds_bytes);                                      \
+        hipLaunchKernelGGL((embed_sym_bwd_kernel<T, EP_, ACT_, DA_>), dim3(grid), dim3(256), lds_bytes, stream, a, \
+                           w1, b1, w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), da, part, B, N, E, tpm); \
+    }
 #define BWD_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                             \
-        DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_, ACT_>), lds_bytes);                                           \
-        hipLaunchKernelGGL((embed_sym_bwd_kernel<T, EP_, ACT_>), dim3(grid), dim3(256), lds_bytes, stream, a, w1,  \
-                           b1, w2_packed, w2_dgrad_packed, b2, static_cast<const T*>(g), da, part, B, N, E, tpm); \
+        if (da) BWD_D(T, EP_, ACT_, true) else BWD_D(T, EP_, ACT_, false)                                         \
     }
 #define BWD(T, EP_)                                                                                               \
     switch (act) {                                                                                                \
@@ -868,6 +874,7 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
         if (E <= 8) BWD(float, 8) else BWD(float, 16)
     }
 #undef BWD_A
+#undef BWD_D
 #undef BWD
     hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
                        BwdPart::kTotal, red);
