@@ -443,6 +443,22 @@ def main():
             "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
         }
         if world == 1 and args.config == "c2" and act_dtype == "f32" and not args.no_extra and not args.graph:
+            # the same step replayed from a captured hipGraph (trainer.GraphedGANStep; single GPU): reported beside the eager
+            # headline, never as it -- the N > 1 lines of this benchmark run eagerly (the all-reduce is not captured)
+            try:
+                graphed = GraphedGANStep(stepper, disc_edge, disc_node, gen_edge, gen_node, warmup=1)
+                graphed.step()
+                torch.cuda.synchronize(dev)
+                tg = time.perf_counter()
+                for _ in range(args.steps):
+                    graphed.step()
+                torch.cuda.synchronize(dev)
+                tg = time.perf_counter() - tg
+                out["hip_graph_replay_same_step"] = {"value": B * args.steps / tg, "unit": "molecules/s",
+                                                     "ms_per_step": 1e3 * tg / args.steps, "steps": args.steps}
+                del graphed
+            except Exception as exc:      # a failed capture must not cost the headline line
+                out["hip_graph_replay_same_step"] = {"error": repr(exc)[:200]}
             out["bf16_configs2"] = secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_batch, args.cpu_threads)

@@ -24,6 +24,7 @@
 //     once at the end through LDS in a fixed order.
 //   * narrow models (C < 32) use fewer quads per slice (LQS) and more phases.
 #include "bf16.h"
+#include "traversal.h"
 
 #include <type_traits>
 
@@ -61,7 +62,7 @@ template <typename T, int LQS, int JPL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, const T* __restrict__ e,
                                                       T* __restrict__ s, T* __restrict__ o, int N, int C,
-                                                      float alpha, int RG, int B) {
+                                                      float alpha, int RG, int B, int reverse) {
     constexpr int QS = 1 << LQS;
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.y * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +72,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
     // so the molecule's k, v rows are fetched from HBM once instead of once per XCD (PMC: reads 1.30x -> ~1.0x
     // of the algorithmic bytes).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / RG) * 8 + xcd, rg = slot % RG;
+    // (reverse, traversal.h: molecules in descending order -- b -> 8 ceil(B / 8) - 1 - b keeps a molecule's workgroups on one XCD)
+    int b = (slot / RG) * 8 + xcd;
+    const int rg = slot % RG;
+    if (reverse) b = (B + 7) / 8 * 8 - 1 - b;
     if (b >= B) return;
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
     const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo, const T* __restrict__ add_e,
     T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, T* __restrict__ de, int N, int C,
-    float alpha, int SL, int B) {
+    float alpha, int SL, int B, int reverse) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // k_j, v_j in the lane layout, shared by the RW waves: kv[2][JPL][64]; then the reduction area
@@ -151,7 +155,9 @@ __global__ __launch_bounds__(RW * 64, (JPL <= 6 ? 2 : 1)) void attn_bwd_kernel(
     // consecutive ids on ONE XCD, so they run at the same time behind the same L2.  With bf16 rows a slice covers
     // 64 of the 128 bytes of a cache line: the other half is then an L2 hit instead of a second HBM fetch.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / SL) * 8 + xcd, slice = slot % SL;
+    int b = (slot / SL) * 8 + xcd;
+    const int slice = slot % SL;
+    if (reverse) b = (B + 7) / 8 * 8 - 1 - b;      // molecules in descending order (traversal.h)
     if (b >= B) return;   // block-uniform
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
     const T* __restrict__ e, const T* __restrict__ ws, const T* __restrict__ wo,
     const T* __restrict__ tq, const T* __restrict__ tk, const T* __restrict__ tv,
     const T* __restrict__ te, T* __restrict__ gq, T* __restrict__ gk, T* __restrict__ gv,
-    T* __restrict__ ge, T* __restrict__ gws, T* __restrict__ gwo, int N, int C, float alpha, int SL, int B) {
+    T* __restrict__ ge, T* __restrict__ gws, T* __restrict__ gwo, int N, int C, float alpha, int SL, int B, int reverse) {
     constexpr int QS = 1 << LQS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // per-neighbour operands live in LDS (read-only, shared by the RW waves):
@@ -299,7 +305,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd2_kernel(
     // consecutive ids on ONE XCD, so they run at the same time behind the same L2.  With bf16 rows a slice covers
     // 64 of the 128 bytes of a cache line: the other half is then an L2 hit instead of a second HBM fetch.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / SL) * 8 + xcd, slice = slot % SL;
+    int b = (slot / SL) * 8 + xcd;
+    const int slice = slot % SL;
+    if (reverse) b = (B + 7) / 8 * 8 - 1 - b;      // molecules in descending order (traversal.h)
     if (b >= B) return;   // block-uniform
     const Lane<LQS, JPL> L(lane, slice, N, C);
     const size_t NC = static_cast<size_t>(N) * C;
@@ -517,10 +525,11 @@ extern "C" int dg_attn_core_fwd(const void* q_, const void* k_, const void* v_, 
     if (RG > N) RG = N;
     dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
     ProfScope prof(DG_K_ATTN_FWD, stream);
+    const int reverse = take_direction(static_cast<int64_t>(B) * N * N);      // per-molecule results: any order
 #define LAUNCH_T(T, LQS, JPL)                                                                                     \
     hipLaunchKernelGGL((attn_fwd_kernel<T, LQS, JPL>), grid, block, 0, stream, static_cast<const T*>(q_),         \
                        static_cast<const T*>(k_), static_cast<const T*>(v_), static_cast<const T*>(e_),          \
-                       static_cast<T*>(s_), static_cast<T*>(o_), N, C, alpha, RG, B);
+                       static_cast<T*>(s_), static_cast<T*>(o_), N, C, alpha, RG, B, reverse);
 #define LAUNCH(LQS, JPL)                                       \
     if (g.lqs == LQS && g.jpl == JPL) {                        \
         if (dtype == DG_DTYPE_BF16) { LAUNCH_T(bf16_t, LQS, JPL) } \
@@ -553,6 +562,7 @@ extern "C" int dg_attn_core_bwd_add(const void* q_, const void* k_, const void* 
     const bool rw8 = rw_env == 8 && g.jpl <= 6;
     dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * g.slices), block(64 * (rw8 ? 8 : kRW));
     ProfScope prof(DG_K_ATTN_BWD, stream);
+    const int reverse = take_direction(static_cast<int64_t>(B) * N * N);      // per-molecule results: any order
 #define LAUNCH_T(T, LQS, JPL, RW_)                                                                              \
     {                                                                                                           \
         constexpr int lds = (2 * JPL + (RW_ - 1) * 2 * JPL + RW_ * JPL) * 64 * 16;   /* + the add_e stash */    \
@@ -562,14 +572,14 @@ extern "C" int dg_attn_core_bwd_add(const void* q_, const void* k_, const void* 
                                static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_), \
                                static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_), \
                                static_cast<const T*>(add_e_), static_cast<T*>(dq_), static_cast<T*>(dk_),       \
-                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B);           \
+                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B, reverse);           \
         } else {                                                                                                \
             DG_OPT_IN_LDS((&attn_bwd_kernel<T, LQS, JPL, RW_>), lds);                                            \
             hipLaunchKernelGGL((attn_bwd_kernel<T, LQS, JPL, RW_>), grid, block, lds, stream,                    \
                                static_cast<const T*>(q_), static_cast<const T*>(k_), static_cast<const T*>(v_), \
                                static_cast<const T*>(e_), static_cast<const T*>(ws_), static_cast<const T*>(wo_), \
                                static_cast<const T*>(nullptr), static_cast<T*>(dq_), static_cast<T*>(dk_),      \
-                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B);           \
+                               static_cast<T*>(dv_), static_cast<T*>(de_), N, C, alpha, g.slices, B, reverse);           \
         }                                                                                                       \
     }
 #define LAUNCH_RW(LQS, JPL, RW_)                                        \
@@ -602,6 +612,7 @@ extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * g.slices), block(64 * kRW);
     ProfScope prof(DG_K_ATTN_BWD2, stream);
+    const int reverse = take_direction(static_cast<int64_t>(B) * N * N);      // per-molecule results: any order
 #define LAUNCH_T(T, LQS, JPL)                                                                                     \
     {                                                                                                             \
         constexpr int lds = (4 * JPL + (kRW - 1) * 2 * JPL) * 64 * 16;                                            \
@@ -612,7 +623,7 @@ extern "C" int dg_attn_core_bwd2(const void* q_, const void* k_, const void* v_,
                            static_cast<const T*>(tq_), static_cast<const T*>(tk_), static_cast<const T*>(tv_),    \
                            static_cast<const T*>(te_), static_cast<T*>(gq_), static_cast<T*>(gk_),                \
                            static_cast<T*>(gv_), static_cast<T*>(ge_), static_cast<T*>(gws_), static_cast<T*>(gwo_), \
-                           N, C, alpha, g.slices, B);                                                             \
+                           N, C, alpha, g.slices, B, reverse);                                                             \
     }
 #define LAUNCH(LQS, JPL)                                   \
     if (g.lqs == LQS && g.jpl == JPL) {                    \

@@ -13,6 +13,7 @@
 // fragments resident in VGPRs; the hidden tile lives in LDS (XOR-swizzled, conflict-free b128
 // fragment reads).  Nothing but the inputs is saved: the backward recomputes both layers.
 #include "bf16.h"
+#include "traversal.h"
 
 namespace dg {
 namespace {
@@ -813,6 +814,7 @@ extern "C" int dg_embed_sym_fwd(const float* a, const float* w1, const float* b1
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     ProfScope prof(DG_K_EMBED_SYM, stream);
+    note_forward(static_cast<int64_t>(B) * N * N);
 #define FWD_A(T, EP_, ACT_)                                                                                      \
     hipLaunchKernelGGL((embed_sym_fwd_kernel<T, EP_, ACT_>), dim3(embed_grid(B * tpm, 8)), dim3(256), 0, stream, a, w1, \
                        b1, w2_packed, b2, static_cast<T*>(out), B, N, E, tpm);
@@ -851,6 +853,7 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kD1Pitch + 64 * kMaxE + kHid * 16) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
+    note_forward(static_cast<int64_t>(B) * N * N);
 #define BWD_D(T, EP_, ACT_, DA_)                                                                                  \
     {                                                                                                             \
         DG_OPT_IN_LDS((&embed_sym_bwd_kernel<T, EP_, ACT_, DA_>), lds_bytes);                                      \
@@ -903,6 +906,7 @@ extern "C" int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b
     float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kHid + 2 * 64 * kMaxE + kPairs * kC) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
+    note_forward(static_cast<int64_t>(B) * N * N);
 #define BWD2_A(T, EP_, ACT_)                                                                                       \
     {                                                                                                              \
         DG_OPT_IN_LDS((&embed_sym_bwd2_kernel<T, EP_, ACT_>), lds_bytes);                                           \
@@ -941,6 +945,7 @@ extern "C" int dg_onehot_embed_fwd(const int* labels, const float* table, void* 
     const int64_t rows = static_cast<int64_t>(B) * N * N;
     const int grid = static_cast<int>(rows / 8 + 1 < 4096 ? rows / 8 + 1 : 4096);
     ProfScope prof(DG_K_EMBED_SYM, stream);
+    note_forward(static_cast<int64_t>(B) * N * N);
     if (dtype == DG_DTYPE_BF16)
         hipLaunchKernelGGL((onehot_embed_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, labels, table,
                            static_cast<bf16_t*>(out), rows, N, E);
@@ -962,6 +967,7 @@ extern "C" int dg_onehot_embed_bwd(const int* labels, const void* g, float* dtab
     const int grid = static_cast<int>(rows / 8 + 1 < kOneHotBlocks ? rows / 8 + 1 : kOneHotBlocks);
     float* part = static_cast<float*>(workspace);
     ProfScope prof(DG_K_EMBED_SYM, stream);
+    note_forward(static_cast<int64_t>(B) * N * N);
 #define BWD(T, EP_)                                                                                         \
     hipLaunchKernelGGL((onehot_embed_bwd_kernel<T, EP_>), dim3(grid), dim3(256), 0, stream, labels,          \
                        static_cast<const T*>(g), part, rows, N, E);

@@ -8,6 +8,7 @@
 // reduced in a fixed order (per-block partials in the workspace, then one
 // finishing kernel), so results are bit-reproducible.
 #include "bf16.h"
+#include "traversal.h"
 
 namespace dg {
 namespace {
@@ -339,6 +340,7 @@ extern "C" int dg_ln_residual_fwd(const void* a, const void* r, const float* gam
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int grid = ln_grid(R, g.G);
     ProfScope prof(DG_K_LN_FWD, stream);
+    note_forward(R);
 #define LAUNCH_T(T, GG, QQ)                                                                                      \
     hipLaunchKernelGGL((ln_fwd_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
                        static_cast<const T*>(r), gamma, beta, static_cast<T*>(y), mean, rstd, R, C, eps);
@@ -380,6 +382,7 @@ extern "C" int dg_ln_residual_bwd_add(const void* a, const void* r, const float*
     const int grid = ln_grid(R, g.G);
     float* part = static_cast<float*>(workspace);
     ProfScope prof(DG_K_LN_BWD, stream);
+    note_forward(R);
 #define LAUNCH_T(T, GG, QQ)                                                                                      \
     hipLaunchKernelGGL((ln_bwd_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
                        static_cast<const T*>(r), gamma, mean, rstd, static_cast<const T*>(dy), static_cast<T*>(dz), \
@@ -413,6 +416,7 @@ extern "C" int dg_ln_residual_bwd2(const void* a, const void* r, const float* ga
     const int grid = ln_grid(R, g.G);
     float* part = static_cast<float*>(workspace);
     ProfScope prof(DG_K_LN_BWD2, stream);
+    note_forward(R);
 #define LAUNCH_T(T, GG, QQ)                                                                                       \
     hipLaunchKernelGGL((ln_bwd2_kernel<T, GG, QQ>), dim3(grid), dim3(kBlock), 0, stream, static_cast<const T*>(a), \
                        static_cast<const T*>(r), gamma, mean, rstd, static_cast<const T*>(dy),                    \

@@ -15,6 +15,7 @@
 // feeds MFMA operands with conflict-free ds_read_b32 (lane&31 walks a row).
 // Split-K partials are reduced by a second kernel in a fixed order.
 #include "bf16.h"
+#include "traversal.h"
 #include "wgrad_stream.h"
 
 #include <cstring>
@@ -826,6 +827,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     const bool big_tiles = (p.nt == 4 && p.kt == 4) ? p.tr == 64 : p.tr == 32;
     ProfScope prof(wgrad_prof_key(R, N, K), stream);
+    note_forward(R);
     if (use_stream) {
         if (int st = launch_wgrad_stream(static_cast<const float*>(dy_), static_cast<const float*>(x_), part_w, part_b, R, N,
                                          K, S, stream, nullptr, nullptr, may_wait))
@@ -904,6 +906,7 @@ extern "C" int dg_linear_wgrad3(const void* dy0, const void* dy1, const void* dy
     float* part_b = db ? part_w + static_cast<size_t>(S) * N * K : nullptr;
     {
         ProfScope prof(wgrad_prof_key(R, N, K), stream);
+        note_forward(R);
         if (int st = launch_wgrad_stream(static_cast<const float*>(dy0), static_cast<const float*>(x), part_w, part_b, R, N, K, S,
                                          stream, static_cast<const float*>(dy1), static_cast<const float*>(dy2), may_wait))
             return st;

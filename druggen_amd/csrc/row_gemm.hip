@@ -24,6 +24,7 @@
 #include "common.h"
 #include "row_gemm_n384.h"
 #include "row_gemm_k384.h"
+#include "traversal.h"
 
 #include <cstring>
 #include <type_traits>
@@ -101,6 +102,7 @@ struct Epilogue {
     float* y_alt[2] = {nullptr, nullptr};
     const float* bias_alt[2] = {nullptr, nullptr};
     const float* a_alt[2] = {nullptr, nullptr};
+    int reverse = 0;      // 128 -> 128 kernels without LayerNorm-backward stages: tiles in descending order (traversal.h)
 };
 
 // Sum over the 32 lanes of a half-wave, result in every lane.  DPP adds inside each 16-lane row
@@ -693,7 +695,12 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     // moment a third of the CUs streams each group's B fragments from L2 instead of all CUs the same 96 KiB.
     const int rot = static_cast<int>(blockIdx.x % 3);
     const int64_t padded = (nchunks + DEPTH - 1) / DEPTH * DEPTH;      // the producers run whole groups of DEPTH iterations
-    auto tile_of = [&](int64_t chunk) { return blockIdx.x + (chunk / KC) * gridDim.x; };
+    // tiles round-robin over the workgroups, ascending or (ep.reverse, traversal.h) descending
+    auto tile_at = [&](int64_t ti) {
+        const int64_t t = blockIdx.x + ti * gridDim.x;
+        return ep.reverse ? tiles - 1 - t : t;
+    };
+    auto tile_of = [&](int64_t chunk) { return tile_at(chunk / KC); };
 
     if (w >= NC) {
         // ------------------------------------------------------------------ producers
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
         const int kc = pos_kc, kcv = KC > 1 ? (pos_kc + rot) % KC : 0;
         const int g = NG > 1 ? (pos_g + rot) % NG : 0;
         const int64_t chunk = ti * KC + pos_kc;
-        const int64_t tix = blockIdx.x + ti * gridDim.x;
+        const int64_t tix = tile_at(ti);
         const int64_t r0 = tix * kTR;
         if (UPT > 1) load_b(bset[1], g, kcv, 1);
         // ReLU mask words of this unit's slabs, requested before the MFMA phase and unconditionally (a null mask reads a
@@ -1699,9 +1706,14 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
             hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs), dim3(512), lds6, stream, a,
                                reinterpret_cast<const f16x8*>(packed), y, R, ep);
         } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
-        else if (K == 128 && exch) LAUNCH6(1, 1, true)
-        else if (K == 128 && !(mask_bits || relu_bits_out) && getenv("DG_GEMM_PLAIN_EXCH")) LAUNCH6(1, 1, true)
-        else if (K == 128) LAUNCH6(1, 1, false)
+        else if (K == 128 && exch) {
+            ep.reverse = take_direction(R);
+            LAUNCH6(1, 1, true)
+        } else if (K == 128 && !(mask_bits || relu_bits_out) && getenv("DG_GEMM_PLAIN_EXCH")) LAUNCH6(1, 1, true)
+        else if (K == 128) {
+            ep.reverse = take_direction(R);
+            LAUNCH6(1, 1, false)
+        }
         else {
             constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;
             DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<true>), lds384);
@@ -1768,6 +1780,7 @@ int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t 
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
     {
         ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        note_forward(R);      // (dgamma / dbeta partial sums: the order of the rows matters)
         DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, true, 4, true>), kH3Lds);
         hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, true, 4, true>), dim3(seqs), dim3(512), kH3Lds, stream, a,
                            reinterpret_cast<const f16x8*>(packed), dz, R, ep);
@@ -1798,6 +1811,7 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
     {
         ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        note_forward(R);      // (dgamma / dbeta partial sums: the order of the rows matters)
         constexpr int lds = kH3Lds + 4 * 32 * 32 * 4;
         DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 4, false, true>), lds);
         hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 4, false, true>), dim3(seqs), dim3(512), lds, stream, dy,

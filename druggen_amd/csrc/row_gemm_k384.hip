@@ -21,6 +21,7 @@
 #include "common.h"
 #include "row_gemm_k384.h"
 #include "pair.h"
+#include "traversal.h"
 
 #ifndef K3_DBG
 #define K3_DBG 0      // ablation builds (scripts/build_variant.sh): 1 no MFMAs, 2 raw LDS writes instead of the split, 4 no tile
@@ -91,6 +92,7 @@ struct EpiK {
     float* pre;               // optional [R,128]: the pre-LayerNorm sum
     float eps;
     int relu;
+    int reverse;              // stages in descending order (traversal.h)
 };
 
 // One problem of a launch; workgroups [0, nb0) run problem 0, the others problem 1 (a node-level GEMM riding in the
@@ -117,10 +119,14 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
     const EpiK ep = second ? p1.ep : p0.ep;
     const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
     const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
+    // stages round-robin over the problem's workgroups, ascending or (ep.reverse) descending: at any time the launch works on
+    // one window of consecutive rows that moves through the matrix like the windows of its neighbours in the stream
     const int64_t total = (R + kSR - 1) / kSR;
-    const int64_t q = total / nblk, rem = total % nblk;
-    const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
-    const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1
+    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk);      // >= 1
+    auto stage_of = [&](int t) {
+        const int64_t st = bidx + static_cast<int64_t>(t) * nblk;
+        return ep.reverse ? total - 1 - st : st;
+    };
     const int TP = (T + kDepth - 1) / kDepth * kDepth;
 
     if (w >= kCons) {
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         const unsigned voff = static_cast<unsigned>(hw) * 3072u + static_cast<unsigned>(l32) * 16u;
         auto fetch = [&](float4 (&set)[6], int t) {
             if (t > T - 1) t = T - 1;
-            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t r0 = stage_of(t) * kSR;
             const int64_t left = (R - r0) * 1536;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             if (!RES || (K3_DBG & 4)) return;
             if (t > T - 1) t = T - 1;
             if (t < 0) t = 0;
-            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t r0 = stage_of(t) * kSR;
             const int64_t left = (R - r0) * 512;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(ep.residual) + r0 * 128, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             if (K3_DBG & 4) return;
             const bool ok = t >= 0 && t < T;
             const int tc = ok ? t : 0;
-            const int64_t r0 = (s_lo + tc) * kSR;
+            const int64_t r0 = stage_of(tc) * kSR;
             const int64_t left = R - r0;
             const int rows = ok ? static_cast<int>(left < kSR ? left : kSR) : 0;      // 0: every store is dropped
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 128, 0, rows * 512, 0x00020000);
@@ -409,7 +415,7 @@ int flush_row_gemm_k384(hipStream_t stream) {
 int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
                          float* pre_ln, float eps, hipStream_t stream) {
-    const ProbK p{a, static_cast<const f16x8*>(packed), y, R, EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu}};
+    const ProbK p{a, static_cast<const f16x8*>(packed), y, R, EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;
         g_rider.p = p;

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "row_gemm_n384.h"
 #include "pair.h"
+#include "traversal.h"
 
 namespace dg {
 namespace {
@@ -66,6 +67,7 @@ struct Epi {
     const unsigned* mask_bits;    // [stages][8][64] words written by a launch with relu_bits of the SAME geometry, or null
     unsigned* relu_bits;          // optional output, same layout: bit (rb * 3 + cb) * 4 + i = (v > 0)
     int relu;
+    int reverse;                  // stages in descending order (traversal.h)
 };
 
 // One problem of a launch.  A launch carries one or two: workgroups [0, nb0) run problem 0, the others problem 1 -- a
@@ -91,10 +93,14 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
     const Epi ep = second ? p1.ep : p0.ep;
     const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
     const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
+    // stages round-robin over the problem's workgroups, ascending or (ep.reverse) descending: at any time the launch works on
+    // one window of consecutive rows that moves through the matrix like the windows of its neighbours in the stream
     const int64_t total = (R + kSR - 1) / kSR;
-    const int64_t q = total / nblk, rem = total % nblk;
-    const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
-    const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1
+    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk);      // >= 1
+    auto stage_of = [&](int t) {
+        const int64_t st = bidx + static_cast<int64_t>(t) * nblk;
+        return ep.reverse ? total - 1 - st : st;
+    };
     const int TP = (T + kDepth - 1) / kDepth * kDepth;
 
     if (w >= kCons) {
@@ -117,10 +123,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             if (t > T - 1) t = T - 1;
             // (a null mask: a zero-sized range, every word reads as 0 and is replaced by all-ones in split())
             const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned*>(ep.mask_bits ? ep.mask_bits + (s_lo + t) * 512 : reinterpret_cast<const unsigned*>(a)), 0,
+                const_cast<unsigned*>(ep.mask_bits ? ep.mask_bits + stage_of(t) * 512 : reinterpret_cast<const unsigned*>(a)), 0,
                 ep.mask_bits ? 2048 : 0, 0x00020000);
             mword = __builtin_amdgcn_raw_buffer_load_b64(rmask, static_cast<unsigned>(pt) * 8u, 0, 0);
-            const int64_t r0 = (s_lo + t) * kSR;
+            const int64_t r0 = stage_of(t) * kSR;
             const int64_t left = (R - r0) * 512;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a) + r0 * 128, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
         auto store_out = [&](int t) {
             const bool ok = t >= 0 && t < T;
             const int tc = ok ? t : 0;
-            const int64_t r0 = (s_lo + tc) * kSR;
+            const int64_t r0 = stage_of(tc) * kSR;
             const int64_t left = (R - r0) * 1536;
             const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 384, 0, bytes, 0x00020000);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             }
             // the stage's ReLU bit words (written by the consumers next to the tile)
             const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(
-                ep.relu_bits ? ep.relu_bits + (s_lo + tc) * 512 : reinterpret_cast<unsigned*>(y), 0, (ok && ep.relu_bits) ? 2048 : 0,
+                ep.relu_bits ? ep.relu_bits + stage_of(tc) * 512 : reinterpret_cast<unsigned*>(y), 0, (ok && ep.relu_bits) ? 2048 : 0,
                 0x00020000);
             const u32x2 bw = *reinterpret_cast<const u32x2*>(smem + kOffBitsOut + (tc & 1) * 2048 + pt * 8);
             __builtin_amdgcn_raw_buffer_store_b64(bw, rbits, static_cast<unsigned>(pt) * 8u, 0, 0);
@@ -338,7 +344,7 @@ int flush_row_gemm_n384(hipStream_t stream) {
 
 int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream) {
-    const Prob p{a, static_cast<const f16x8*>(packed), y, R, Epi{bias, mask_bits, relu_bits, relu}};
+    const Prob p{a, static_cast<const f16x8*>(packed), y, R, Epi{bias, mask_bits, relu_bits, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;
         g_rider.p = p;

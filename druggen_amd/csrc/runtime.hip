@@ -1,10 +1,12 @@
 // Error reporting and the opt-in event profiler of libdruggen_hip.so.
 #include "common.h"
 #include "pair.h"
+#include "traversal.h"
 #include "row_gemm_k384.h"
 #include "row_gemm_n384.h"
 #include "wgrad_stream.h"
 
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -84,6 +86,20 @@ ProfScope::~ProfScope() {
 
 static thread_local bool g_pair_mode = false;
 bool pair_mode() { return g_pair_mode; }
+
+static thread_local int g_last_dir = 1;      // (the first edge-level launch ascends)
+static bool alternate_traversal() {
+    static const bool on = !(getenv("DG_TRAVERSAL") && strcmp(getenv("DG_TRAVERSAL"), "forward") == 0);
+    return on;
+}
+int take_direction(int64_t R) {
+    if (R < DG_EDGE_ROWS || !alternate_traversal()) return 0;
+    g_last_dir = !g_last_dir;
+    return g_last_dir;
+}
+void note_forward(int64_t R) {
+    if (R >= DG_EDGE_ROWS) g_last_dir = 0;
+}
 
 }  // namespace dg
 
