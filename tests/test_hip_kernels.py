@@ -292,6 +292,37 @@ def test_paired_feed_forward_nodes_match_the_two_single_nodes(B, N, monkeypatch)
                 assert _rel(b, a.double().cpu()) < 5e-6, i
 
 
+@pytest.mark.parametrize("R", [65536, 70001, 131083])
+def test_alternating_traversal_is_invisible_in_the_results(R):
+    """Edge-level row GEMMs and attention launches walk the rows opposite to their predecessor (csrc/traversal.h: start in
+    what the memory-side cache still holds).  Their results are functions of the row / molecule alone: four launches in a
+    row (ascending, descending, ...) are bit-identical, ragged last tiles included, and equal the fp64 contraction."""
+    from druggen_amd import functional as dgf
+    x = _gen((R, 128), 300).float().cuda()
+    res = _gen((R, 128), 301).float().cuda()
+    w1, w2, w3 = (_gen((384, 128), 302) * 0.1).float().cuda(), (_gen((128, 384), 303) * 0.1).float().cuda(), (_gen((128, 128), 304) * 0.1).float().cuda()
+    b1, g, be = _gen((384,), 305).float().cuda(), (_gen((128,), 306) * 0.1 + 1).float().cuda(), _gen((128,), 307).float().cuda()
+    runs = []
+    for _ in range(4):
+        h, bits = dgf.row_gemm(x, dgf.packed_weight(w1, 0), 128, 384, bias=b1, relu=True, want_relu_bits=True)
+        y, mean, rstd, pre = dgf.row_gemm(h, dgf.packed_weight(w2, 0), 384, 128, residual=res, ln=(g, be, 1e-5), want_pre=True)
+        z = dgf.row_gemm(y, dgf.packed_weight(w3, 0), 128, 128, residual=x)
+        dh = dgf.row_gemm(z, dgf.packed_weight(w2, 1), 128, 384, mask_bits=bits)
+        runs.append([h, bits[:(R + 31) // 32 * 512], y, mean, rstd, pre, z, dh])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+    hd = torch.relu(x.double().cpu() @ w1.double().cpu().t() + b1.double().cpu())
+    assert _rel(runs[0][0], hd) < TOL
+    assert _rel(runs[0][5], hd @ w2.double().cpu().t() + res.double().cpu()) < TOL
+    B, N, C = (R + 44) // 45 // 45, 45, 128      # attention core: molecules in ascending / descending order
+    f = lambda shape, s_: _gen(shape, s_).float().cuda()
+    q, k, v, e = f((B, N, C), 310), f((B, N, C), 311), f((B, N, C), 312), f((B, N, N, C), 313)
+    outs = [dgf.attn_core(q, k, v, e, 0.25) for _ in range(4)]
+    for s_, o in outs[1:]:
+        assert torch.equal(s_, outs[0][0]) and torch.equal(o, outs[0][1])
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
