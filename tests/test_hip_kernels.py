@@ -228,8 +228,8 @@ def test_riding_launches_equal_separate_launches(Rn, Re):
             dh = [dgf.row_gemm(y[0], dgf.packed_weight(w2[i], 1), 128, 384, mask_bits=hs[i][1]) for i, y in enumerate(ys)]
             dx = [dgf.row_gemm(d, dgf.packed_weight(w1[i], 1), 384, 128, residual=ys[i][0]) for i, d in enumerate(dh)]
             wg = dgf._wgrad_many([(ys[0][0], hs[0][0], True), (ys[1][0], hs[1][0], True), (dh[0], xs[0], True), (dh[1], xs[1], True)])
-        for i in range(2):      # (the mask buffer is sized for every 128 -> 384 kernel; this one writes 512 words per 32 rows)
-            out.append([hs[i][0], hs[i][1][:(xs[i].shape[0] + 31) // 32 * 512], *ys[i], dh[i], dx[i]])
+        for i in range(2):      # (the ReLU bit words are compared through dh: their buffer is sized for every 128 -> 384 kernel)
+            out.append([hs[i][0], *ys[i], dh[i], dx[i]])
         return out, wg
 
     sep, wsep = chain(False)
@@ -239,8 +239,8 @@ def test_riding_launches_equal_separate_launches(Rn, Re):
             assert torch.equal(u, v)
     for (dw, db), (ew, eb) in zip(wsep, wpar):
         assert _rel(ew, dw.double().cpu()) < 2e-6 and _rel(eb, db.double().cpu()) < 2e-6
-    assert _rel(wpar[0][0], sep[0][2].double().cpu().t() @ sep[0][0].double().cpu()) < TOL
-    assert _rel(wpar[3][0], sep[1][6].double().cpu().t() @ xs[1].double().cpu()) < TOL
+    assert _rel(wpar[0][0], sep[0][1].double().cpu().t() @ sep[0][0].double().cpu()) < TOL
+    assert _rel(wpar[3][0], sep[1][5].double().cpu().t() @ xs[1].double().cpu()) < TOL
     again, wagain = chain(True)
     for (dw, db), (ew, eb) in zip(wpar, wagain):
         assert torch.equal(dw, ew) and torch.equal(db, eb)
@@ -308,13 +308,13 @@ def test_alternating_traversal_is_invisible_in_the_results(R):
         y, mean, rstd, pre = dgf.row_gemm(h, dgf.packed_weight(w2, 0), 384, 128, residual=res, ln=(g, be, 1e-5), want_pre=True)
         z = dgf.row_gemm(y, dgf.packed_weight(w3, 0), 128, 128, residual=x)
         dh = dgf.row_gemm(z, dgf.packed_weight(w2, 1), 128, 384, mask_bits=bits)
-        runs.append([h, bits[:(R + 31) // 32 * 512], y, mean, rstd, pre, z, dh])
+        runs.append([h, y, mean, rstd, pre, z, dh])
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
     hd = torch.relu(x.double().cpu() @ w1.double().cpu().t() + b1.double().cpu())
     assert _rel(runs[0][0], hd) < TOL
-    assert _rel(runs[0][5], hd @ w2.double().cpu().t() + res.double().cpu()) < TOL
+    assert _rel(runs[0][4], hd @ w2.double().cpu().t() + res.double().cpu()) < TOL
     B, N, C = (R + 44) // 45 // 45, 45, 128      # attention core: molecules in ascending / descending order
     f = lambda shape, s_: _gen(shape, s_).float().cuda()
     q, k, v, e = f((B, N, C), 310), f((B, N, C), 311), f((B, N, C), 312), f((B, N, N, C), 313)
