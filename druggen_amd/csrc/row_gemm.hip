@@ -698,7 +698,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_kernel(const float* __rest
     // tiles round-robin over the workgroups, ascending or (ep.reverse, traversal.h) descending
     auto tile_at = [&](int64_t ti) {
         const int64_t t = blockIdx.x + ti * gridDim.x;
-        return ep.reverse ? tiles - 1 - t : t;
+        if constexpr (LNB || LNA || S3 || NC != 4) return t;      // (partial sums per workgroup / node-level kernels: always ascending)
+        else return ep.reverse ? tiles - 1 - t : t;
     };
     auto tile_of = [&](int64_t chunk) { return tile_at(chunk / KC); };
 
