@@ -84,8 +84,8 @@ ProfScope::~ProfScope() {
     if (idx < g_spans.size()) (void)hipEventRecord(g_spans[idx].stop, stream);
 }
 
-static thread_local bool g_pair_mode = false;
-bool pair_mode() { return g_pair_mode; }
+static thread_local int g_pair_depth = 0;      // dg_launch_pair_begin / _end nest: launches wait while the depth is > 0
+bool pair_mode() { return g_pair_depth > 0; }
 
 static thread_local int g_last_dir = 1;      // (the first edge-level launch ascends)
 static bool alternate_traversal() {
@@ -106,13 +106,14 @@ void note_forward(int64_t R) {
 extern "C" {
 
 int dg_launch_pair_begin(void) {
-    dg::g_pair_mode = true;
+    ++dg::g_pair_depth;
     return 0;
 }
 
 int dg_launch_pair_end(dg_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    dg::g_pair_mode = false;
+    if (dg::g_pair_depth > 0) --dg::g_pair_depth;
+    if (dg::g_pair_depth > 0) return 0;      // an enclosing region is still open: its _end launches what waits
     int st = dg::flush_row_gemm_n384(stream);
     const int st2 = dg::flush_row_gemm_k384(stream);
     const int st3 = dg::flush_wgrad_stream(stream);

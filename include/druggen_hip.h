@@ -191,7 +191,8 @@ int dg_linear_wgrad_batch_end(dg_stream_t stream);
  * the 384 -> 128 GEMM, same shape for the weight gradient), whose workgroups are split between the two in proportion to
  * their rows.  Results are those of separate launches (weight gradients: a different, still fixed, number of partial
  * sums).  The CALLER guarantees that no other launch reads a waiting problem's output before its carrier was called:
- * issue node, edge, node, edge ...  _pair_end() launches whatever still waits on `stream`.  Per host thread.         */
+ * issue node, edge, node, edge ...  _pair_end() launches whatever still waits on `stream`.  Regions nest (the outermost
+ * _pair_end() launches); per host thread.                                                                             */
 int dg_launch_pair_begin(void);
 int dg_launch_pair_end(dg_stream_t stream);
 

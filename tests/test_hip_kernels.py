@@ -244,6 +244,14 @@ def test_riding_launches_equal_separate_launches(Rn, Re):
     again, wagain = chain(True)
     for (dw, db), (ew, eb) in zip(wpar, wagain):
         assert torch.equal(dw, ew) and torch.equal(db, eb)
+    # regions nest: the inner end leaves the waiting launch to the outer region
+    with dgf._pair_launches(xs[0]):
+        hn = dgf.row_gemm(xs[0], dgf.packed_weight(w1[0], 0), 128, 384, bias=b1[0])
+        with dgf._pair_launches(xs[0]):
+            pass
+        he = dgf.row_gemm(xs[1], dgf.packed_weight(w1[1], 0), 128, 384, bias=b1[1])
+    assert torch.equal(hn, dgf.row_gemm(xs[0], dgf.packed_weight(w1[0], 0), 128, 384, bias=b1[0]))
+    assert torch.equal(he, dgf.row_gemm(xs[1], dgf.packed_weight(w1[1], 0), 128, 384, bias=b1[1]))
     # a rider nobody carries: launched by _pair_end
     with dgf._pair_launches(xs[0]):
         lone = dgf.row_gemm(xs[0], dgf.packed_weight(w1[0], 0), 128, 384, bias=b1[0])
