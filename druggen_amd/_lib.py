@@ -19,6 +19,21 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DG_LIB") or os.path.join(_PKG, "lib", "libdruggen_hip.so")   # DG_LIB: developer A/B builds
 
 _P = c_void_p
+
+
+class FFNFwdArgs(ctypes.Structure):
+    """dg_ffn_fwd_args of include/druggen_hip.h."""
+    _fields_ = [(n, _P) for n in ("x", "w1_packed", "b1", "w2_packed", "b2", "gamma", "beta", "y", "h", "relu_bits", "pre_ln",
+                                  "mean", "rstd")] + [("R", c_int64), ("eps", c_float)]
+
+
+class FFNBwdArgs(ctypes.Structure):
+    """dg_ffn_bwd_args of include/druggen_hip.h."""
+    _fields_ = [(n, _P) for n in ("x", "h", "relu_bits", "pre_ln", "mean", "rstd", "gamma", "w1_dgrad_packed", "w2_dgrad_packed",
+                                  "dy", "dz_add", "dz", "dh", "dx", "dgamma", "dbeta", "dw1", "db1", "dw2", "db2", "workspace")] + [
+        ("workspace_bytes", c_size_t), ("R", c_int64)]
+
+
 # name -> (restype, argtypes); mirrors include/druggen_hip.h one to one
 SIGNATURES = {
     "dg_version": (c_int, []),
@@ -61,6 +76,8 @@ SIGNATURES = {
     "dg_edge_ffn_ln_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "dg_edge_ffn_ln_fwd": (c_int, [_P] * 13 + [c_int64, c_int, c_int, c_float, c_int, _P]),
     "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_edge_ffn_ln_fwd_pair": (c_int, [ctypes.POINTER(FFNFwdArgs), ctypes.POINTER(FFNFwdArgs), c_int, c_int, c_int, _P]),
+    "dg_edge_ffn_ln_bwd_pair": (c_int, [ctypes.POINTER(FFNBwdArgs), ctypes.POINTER(FFNBwdArgs), c_int, c_int, c_int, _P]),
     "dg_ffn_bf16_padded_rows": (c_int64, [c_int64]),
     "dg_ffn_bf16_packed_bytes": (c_size_t, []),
     "dg_ffn_bf16_pack": (c_int, [_P, _P, _P, _P]),
@@ -163,7 +180,14 @@ def fptr(t):
     return ptr(t)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t) -> int:
+    """The caller's current HIP stream on t's device as a raw handle (asked for at every launch: a step issues ~600 of them,
+    so the raw-handle query is used where this torch has it -- no Stream object per call)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

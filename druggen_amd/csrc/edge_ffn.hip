@@ -95,3 +95,85 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
     }
     return 0;
 }
+
+// ---- node + edge feed-forward of a block in one call (riding launches, pair.h) ---------------------------------------
+namespace {
+
+int ffn_fwd_check(const dg_ffn_fwd_args* a, const char* who) {
+    if (!a || !a->x || !a->w1_packed || !a->b1 || !a->w2_packed || !a->b2 || !a->gamma || !a->beta || !a->y || !a->h ||
+        !a->mean || !a->rstd)
+        return fail(DG_E_ARG, "dg_edge_ffn_ln_fwd_pair: null pointer (%s)", who);
+    return 0;
+}
+
+// one step of dg_edge_ffn_ln_bwd's sequence for one problem; the workspace is laid out as in that function
+int ffn_bwd_phase(const dg_ffn_bwd_args& a, int phase, int C, int H, int dtype, dg_stream_t stream) {
+    const int64_t R = a.R;
+    const size_t lnb = (dg_ln_workspace_bytes(R, C) + 255) / 256 * 256;
+    const size_t w2b = (dg_linear_wgrad_workspace_bytes(R, C, H) + 255) / 256 * 256;
+    char* ws = static_cast<char*>(a.workspace);
+    switch (phase) {
+        case 0:      // dz = LN'(dy) (+ dz_add); dy == NULL: dz already holds it
+            if (!a.dy) return 0;
+            return dg_ln_residual_bwd_add(a.pre_ln, nullptr, a.gamma, a.mean, a.rstd, a.dy, a.dz_add, a.dz, a.dgamma, a.dbeta, ws,
+                                          lnb, R, C, dtype, stream);
+        case 1:      // dh = (dz W2) masked by the forward's ReLU bits
+            return dg_row_gemm(a.dz, a.w2_dgrad_packed, a.dh, R, C, H, nullptr, 0, nullptr, a.relu_bits, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, 0.f, dtype, stream);
+        case 2:      // dx = dz + dh W1
+            if (!a.dx) return 0;
+            return dg_row_gemm(a.dh, a.w1_dgrad_packed, a.dx, R, H, C, nullptr, 0, nullptr, nullptr, a.dz, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, 0.f, dtype, stream);
+        case 3:      // dW2, db2 = dz^T h, sum dz
+            if (!a.dw2) return 0;
+            return dg_linear_wgrad(a.dz, nullptr, a.h, a.dw2, a.db2, ws + lnb, w2b, R, C, H, dtype, stream);
+        default:     // dW1, db1 = dh^T x, sum dh
+            if (!a.dw1) return 0;
+            return dg_linear_wgrad(a.dh, nullptr, a.x, a.dw1, a.db1, ws + lnb + w2b, a.workspace_bytes - lnb - w2b, R, H, C, dtype,
+                                   stream);
+    }
+}
+
+}  // namespace
+
+extern "C" int dg_edge_ffn_ln_fwd_pair(const dg_ffn_fwd_args* node, const dg_ffn_fwd_args* edge, int C, int H, int dtype,
+                                       dg_stream_t stream) {
+    if (int st = ffn_fwd_check(node, "node")) return st;
+    if (int st = ffn_fwd_check(edge, "edge")) return st;
+    if (C != 128 || H != 384) return fail(DG_E_SHAPE, "dg_edge_ffn_ln_fwd_pair: needs dim 128, hidden 384 (got %d, %d)", C, H);
+    const dg_ffn_fwd_args* ps[2] = {node, edge};
+    dg_launch_pair_begin();
+    int st = 0;
+    for (int i = 0; i < 2 && !st; ++i)      // h = relu(x W1^T + b1)
+        st = dg_row_gemm(ps[i]->x, ps[i]->w1_packed, ps[i]->h, ps[i]->R, C, H, ps[i]->b1, 1, ps[i]->relu_bits, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, dtype, stream);
+    for (int i = 0; i < 2 && !st; ++i)      // y = LN(x + h W2^T + b2)
+        st = dg_row_gemm(ps[i]->h, ps[i]->w2_packed, ps[i]->y, ps[i]->R, H, C, ps[i]->b2, 0, nullptr, nullptr, ps[i]->x,
+                         ps[i]->gamma, ps[i]->beta, ps[i]->mean, ps[i]->rstd, ps[i]->pre_ln, ps[i]->eps, dtype, stream);
+    const int st2 = dg_launch_pair_end(stream);
+    return st ? st : st2;
+}
+
+extern "C" int dg_edge_ffn_ln_bwd_pair(const dg_ffn_bwd_args* node, const dg_ffn_bwd_args* edge, int C, int H, int dtype,
+                                       dg_stream_t stream) {
+    const dg_ffn_bwd_args* ps[2] = {node, edge};
+    for (const dg_ffn_bwd_args* a : ps) {
+        if (!a || !a->x || !a->h || !a->relu_bits || !a->pre_ln || !a->mean || !a->rstd || !a->gamma || !a->w1_dgrad_packed ||
+            !a->w2_dgrad_packed || !a->dz || !a->dh || !a->workspace)
+            return fail(DG_E_ARG, "dg_edge_ffn_ln_bwd_pair: null pointer");
+        if (!a->dy && a->dz_add != a->dz)
+            return fail(DG_E_ARG, "dg_edge_ffn_ln_bwd_pair: dy == NULL means dz already holds the LayerNorm input gradient (pass it as dz_add too)");
+        if (a->workspace_bytes < dg_edge_ffn_ln_workspace_bytes(a->R, C, H))
+            return fail(DG_E_WORKSPACE, "dg_edge_ffn_ln_bwd_pair: workspace too small");
+    }
+    if (C != 128 || H != 384) return fail(DG_E_SHAPE, "dg_edge_ffn_ln_bwd_pair: needs dim 128, hidden 384 (got %d, %d)", C, H);
+    // every reduction of the call (LayerNorm dgamma / dbeta of up to two problems, up to four weight gradients) in one launch
+    dg_linear_wgrad_batch_begin();
+    dg_launch_pair_begin();
+    int st = 0;
+    for (int phase = 0; phase < 5 && !st; ++phase)
+        for (int i = 0; i < 2 && !st; ++i) st = ffn_bwd_phase(*ps[i], phase, C, H, dtype, stream);
+    const int st2 = dg_launch_pair_end(stream);
+    const int st3 = dg_linear_wgrad_batch_end(stream);
+    return st ? st : (st2 ? st2 : st3);
+}

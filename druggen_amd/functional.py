@@ -179,7 +179,7 @@ def _scratch(ref, need, tag="ln"):
     """Per (device, stream, thread, tag) scratch buffer owned by the caller side (PyTorch).  The thread is part of the key
     because nn.DataParallel replicas are threads: two of them on ONE device and stream (device_ids=[0, 0]) would
     otherwise interleave a kernel of one call with the reduction of another over the same workspace."""
-    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream, threading.get_ident(), tag)
+    key = (ref.device, _lib.stream_of(ref), threading.get_ident(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         if len(_ws_cache) > 256:      # nn.DataParallel starts fresh replica threads per forward: drop dead threads' buffers
@@ -1147,18 +1147,16 @@ class _FFNLNPair(Function):
                 mean=torch.empty(R, dtype=torch.float32, device=dev), rstd=torch.empty(R, dtype=torch.float32, device=dev),
                 bits=torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev) if keep else None))
         ref = probs[0]["x2"]
-        with _pair_launches(ref):
-            st = _lib.stream_of(ref)
-            for p in probs:      # h = relu(x W1^T + b1) (+ the ReLU bit mask)
-                _lib.check(lib.dg_row_gemm(_lib.ptr(p["x2"]), packed_weight(p["w1"], 0, ref.dtype).data_ptr(), _lib.ptr(p["h"]),
-                                           p["R"], p["C"], p["H"], _lib.fptr(_c(p["b1"])), 1,
-                                           None if p["bits"] is None else p["bits"].data_ptr(), None, None, None, None, None,
-                                           None, None, 0.0, p["code"], st), "dg_row_gemm")
-            for p, eps in zip(probs, (eps_n, eps_e)):      # y = LN(x + h W2^T + b2)
-                _lib.check(lib.dg_row_gemm(_lib.ptr(p["h"]), packed_weight(p["w2"], 0, ref.dtype).data_ptr(), _lib.ptr(p["y"]),
-                                           p["R"], p["H"], p["C"], _lib.fptr(_c(p["b2"])), 0, None, None, _lib.ptr(p["x2"]),
-                                           _lib.fptr(_c(p["gamma"])), _lib.fptr(_c(p["beta"])), _lib.ptr(p["mean"]),
-                                           _lib.ptr(p["rstd"]), _lib.ptr(p["pre"]), float(eps), p["code"], st), "dg_row_gemm")
+        cargs = []
+        for p, eps in zip(probs, (eps_n, eps_e)):      # dg_ffn_fwd_args: h = relu(x W1^T + b1), y = LN(x + h W2^T + b2)
+            cargs.append(_lib.FFNFwdArgs(
+                _lib.ptr(p["x2"]), packed_weight(p["w1"], 0, ref.dtype).data_ptr(), _lib.fptr(_c(p["b1"])),
+                packed_weight(p["w2"], 0, ref.dtype).data_ptr(), _lib.fptr(_c(p["b2"])), _lib.fptr(_c(p["gamma"])),
+                _lib.fptr(_c(p["beta"])), _lib.ptr(p["y"]), _lib.ptr(p["h"]), None if p["bits"] is None else p["bits"].data_ptr(),
+                _lib.ptr(p["pre"]), _lib.ptr(p["mean"]), _lib.ptr(p["rstd"]), p["R"], float(eps)))
+        with _dev(ref):      # one call: node, edge, node, edge inside dg_launch_pair_begin / _end
+            _lib.check(lib.dg_edge_ffn_ln_fwd_pair(ctypes.byref(cargs[0]), ctypes.byref(cargs[1]), probs[0]["C"], probs[0]["H"],
+                                                   probs[0]["code"], _lib.stream_of(ref)), "dg_edge_ffn_ln_fwd_pair")
         es = ref.element_size()
         for p in probs:
             R, C, H = p["R"], p["C"], p["H"]
@@ -1215,25 +1213,43 @@ class _FFNLNPairBwd(Function):
                 p["dz"] = None
             probs.append(p)
         ref = probs[0]["pre"]
-        adt = ref.dtype
-        pw = lambda w_, m_: packed_weight(w_, m_, adt)
-        any_w = any(p["want_w"] or (p["want_aff"] and p["dy2"] is not None) for p in probs)
-        with _reduce_batch(ref, on=any_w) as inb, _pair_launches(ref):
-            for i, p in enumerate(probs):
+        adt, dev, es = ref.dtype, ref.device, ref.element_size()
+        cargs = []
+        with _dev(ref):
+            for i, p in enumerate(probs):      # dg_ffn_bwd_args: outputs and a workspace of its own per branch
+                R, C, H = p["R"], p["C"], p["H"]
                 if p["dy2"] is not None:
-                    p["dz"], p["dgamma"], p["dbeta"] = _ln_bwd_rows(p["pre"], p["gamma"], p["mean"], p["rstd"], p["dy2"],
-                                                                     p["dz_add"], want_affine=p["want_aff"],
-                                                                     batch_slot=i if inb else None)
-            for p in probs:      # dh = (dz W2) masked by the forward's ReLU bits
-                p["dh"] = row_gemm(p["dz"], pw(p["w2"], 1), p["C"], p["H"], mask_bits=p["bits"])
-            for p in probs:      # dx = dz + dh W1
-                p["dx"] = row_gemm(p["dh"], pw(p["w1"], 1), p["H"], p["C"], residual=p["dz"]) if p["want_x"] else None
-            items = [(p["dz"], p["h"], True) for p in probs if p["want_w"]] + [(p["dh"], p["x2"], True) for p in probs if p["want_w"]]
-            res = iter(_wgrad_many(items, open_batch=not inb)) if items else iter(())
-            for p in probs:
-                p["dw2"], p["db2"] = next(res) if p["want_w"] else (None, None)
-            for p in probs:
-                p["dw1"], p["db1"] = next(res) if p["want_w"] else (None, None)
+                    p["dz"] = torch.empty(R, C, dtype=adt, device=dev)
+                    if p["want_aff"]:      # adjacent in memory: their reduction joins the call's single reduce launch
+                        p["dgamma"], p["dbeta"] = torch.empty(2, p["gamma"].numel(), dtype=p["gamma"].dtype, device=dev).unbind(0)
+                p["dh"] = torch.empty(R, H, dtype=adt, device=dev)
+                p["dx"] = torch.empty(R, C, dtype=adt, device=dev) if p["want_x"] else None
+                p["dw1"] = p["db1"] = p["dw2"] = p["db2"] = None
+                if p["want_w"]:
+                    p["dw1"], p["dw2"] = torch.empty_like(p["w1"]), torch.empty_like(p["w2"])
+                    p["db1"] = torch.empty(H, dtype=torch.float32, device=dev)
+                    p["db2"] = torch.empty(C, dtype=torch.float32, device=dev)
+                ws = _scratch(ref, int(lib.dg_edge_ffn_ln_workspace_bytes(R, C, H)), f"ffn_pair{i}")
+                cargs.append(_lib.FFNBwdArgs(
+                    _lib.ptr(p["x2"]), _lib.ptr(p["h"]), p["bits"].data_ptr(), _lib.ptr(p["pre"]), _lib.ptr(p["mean"]),
+                    _lib.ptr(p["rstd"]), _lib.fptr(_c(p["gamma"])), packed_weight(p["w1"], 1, adt).data_ptr(),
+                    packed_weight(p["w2"], 1, adt).data_ptr(), _lib.ptr(p["dy2"]), _lib.ptr(p["dz_add"]), _lib.ptr(p["dz"]),
+                    _lib.ptr(p["dh"]), _lib.ptr(p["dx"]), _lib.ptr(p["dgamma"]), _lib.ptr(p["dbeta"]), _lib.ptr(p["dw1"]),
+                    _lib.ptr(p["db1"]), _lib.ptr(p["dw2"]), _lib.ptr(p["db2"]), ws.data_ptr(), ws.numel(), R))
+            # one call: LayerNorm backward, dh = (dz W2) * m, dx = dz + dh W1, dW2 = dz^T h, dW1 = dh^T x -- node, edge, node, edge
+            # inside dg_launch_pair_begin / _end, one reduce launch for everything
+            _lib.check(lib.dg_edge_ffn_ln_bwd_pair(ctypes.byref(cargs[0]), ctypes.byref(cargs[1]), probs[0]["C"], probs[0]["H"],
+                                                   _lib.dt(ref), _lib.stream_of(ref)), "dg_edge_ffn_ln_bwd_pair")
+        for p in probs:
+            R, C, H = p["R"], p["C"], p["H"]
+            if p["dy2"] is not None:
+                _account("ln_bwd", es * R * C * (4 if p["dz_add"] is not None else 3))
+            _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+            if p["dx"] is not None:
+                _account(_gemm_key(R, H, C), es * R * (H + 2 * C), 2 * R * C * H)
+            if p["want_w"]:
+                _account(_wgrad_key(R, C, H), es * R * (C + H), 2 * R * C * H)
+                _account(_wgrad_key(R, H, C), es * R * (C + H), 2 * R * C * H)
         saved, outs = [], []
         for p in probs:
             saved += [p["x"], p["w1"], p["w2"], p["gamma"], p["h"], p["mean"], p["rstd"], p["pre"], p["bits"], p["dy2"], p["dz"], p["dh"]]

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 217            /* 0.2.3: + riding launches (dg_launch_pair_begin / _end) */
+#define DG_VERSION 218            /* 0.2.4: + riding launches (dg_launch_pair_begin / _end), paired feed-forward entries */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -296,6 +296,29 @@ int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* relu_bits, 
                        float* dw1, float* db1, float* dw2, float* db2,
                        void* workspace, size_t workspace_bytes, int64_t R, int C, int H, int dtype,
                        dg_stream_t stream);
+
+/* The two feed-forward halves of an Encoder_Block -- mlp / ln5 over the B N node rows, mlp2 / ln6 over the B N^2 edge rows
+ * (layers.py:191-192) -- in ONE call per direction: exactly dg_edge_ffn_ln_fwd / _bwd for `node` and for `edge` (same
+ * arguments, as structs; each with its own workspace of dg_edge_ffn_ln_workspace_bytes(R, C, H)), issued node, edge, node,
+ * edge ... inside dg_launch_pair_begin / _end, so that every node-level launch rides in the edge-level launch of the same
+ * kernel; the backward's reductions (LayerNorm dgamma / dbeta, four weight gradients) share one launch.  float32 rows on the
+ * producer / consumer kernels ride; other dtypes / kernels simply run one after the other.                                  */
+typedef struct dg_ffn_fwd_args {
+    const void* x; const void* w1_packed; const float* b1; const void* w2_packed; const float* b2;
+    const float* gamma; const float* beta;
+    void* y; void* h; unsigned* relu_bits; void* pre_ln; float* mean; float* rstd;
+    int64_t R; float eps;
+} dg_ffn_fwd_args;
+typedef struct dg_ffn_bwd_args {
+    const void* x; const void* h; const unsigned* relu_bits; const void* pre_ln; const float* mean; const float* rstd;
+    const float* gamma; const void* w1_dgrad_packed; const void* w2_dgrad_packed; const void* dy; const void* dz_add;
+    void* dz; void* dh; void* dx; float* dgamma; float* dbeta; float* dw1; float* db1; float* dw2; float* db2;
+    void* workspace; size_t workspace_bytes; int64_t R;
+} dg_ffn_bwd_args;
+int dg_edge_ffn_ln_fwd_pair(const dg_ffn_fwd_args* node, const dg_ffn_fwd_args* edge, int C, int H, int dtype,
+                            dg_stream_t stream);
+int dg_edge_ffn_ln_bwd_pair(const dg_ffn_bwd_args* node, const dg_ffn_bwd_args* edge, int C, int H, int dtype,
+                            dg_stream_t stream);
 
 /* ---- the same feed-forward half as FUSED kernels, bf16 configuration only (csrc/ffn_bf16.hip) ----
  *   y = LayerNorm(x + fc2(relu(fc1(x)))) * gamma + beta,  C = 128, H = 384, all activations bf16.
