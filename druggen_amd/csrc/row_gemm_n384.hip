@@ -24,6 +24,9 @@
 #include "pair.h"
 #include "traversal.h"
 
+#ifndef N3_DBG
+#define N3_DBG 0      // ablation builds (scripts/build_variant.sh, scripts/n384_variants.sh): 1 no MFMAs, 2 no epilogue arithmetic
+#endif                // (raw accumulators to the tile), 4 no output stores, 8 no global fetch of A
 namespace dg {
 namespace {
 
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             const int64_t left = (R - r0) * 512;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a) + r0 * 128, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+            if (N3_DBG & 8) return;
 #pragma unroll
             for (int i = 0; i < 4; ++i)      // rows hw + 8 i
                 set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * 4096, 0));
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
         const unsigned ooff = static_cast<unsigned>(hw) * 1536u + static_cast<unsigned>(l32) * 16u;
         const unsigned goff = static_cast<unsigned>(hw) * 1536u + static_cast<unsigned>(l32 ^ hw) * 16u;
         auto store_out = [&](int t) {
+            if (N3_DBG & 4) return;
             const bool ok = t >= 0 && t < T;
             const int tc = ok ? t : 0;
             const int64_t r0 = stage_of(tc) * kSR;
@@ -280,7 +285,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int cb = 0; cb < 3; ++cb) {
-                            if (ks == 0 && term == 0) mfma16_first(acc[rb][cb], wf[cb][ks][1], xh[rb]);
+                            if (N3_DBG & 1) {
+                                if (ks == 0 && term == 0) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                acc[rb][cb][0] += static_cast<float>(xh[rb][0]) * static_cast<float>(wf[cb][ks][0][0]);
+                            } else if (ks == 0 && term == 0) mfma16_first(acc[rb][cb], wf[cb][ks][1], xh[rb]);
                             else mfma16(acc[rb][cb], wf[cb][ks][term == 0 ? 1 : 0], term == 1 ? xl[rb] : xh[rb]);
                         }
             }
@@ -296,6 +304,12 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                 for (int cb = 0; cb < 3; ++cb) {
                     const int c0 = 48 * w + 16 * cb + 4 * kq;
                     const float4 cs = ld4(tab + c0), bs = ld4(tab + 384 + c0);
+                    if (N3_DBG & 2) {
+                        const int slot = (c0 >> 2) ^ (row & 7);
+                        *reinterpret_cast<float4*>(ot + row * 1536 + slot * 16) =
+                            make_float4(acc[rb][cb][0], acc[rb][cb][1], acc[rb][cb][2], acc[rb][cb][3]);
+                        continue;
+                    }
                     float v[4] = {fmaf(acc[rb][cb][0], rs * cs.x, bs.x), fmaf(acc[rb][cb][1], rs * cs.y, bs.y),
                                   fmaf(acc[rb][cb][2], rs * cs.z, bs.z), fmaf(acc[rb][cb][3], rs * cs.w, bs.w)};
 #pragma unroll
