@@ -1515,6 +1515,13 @@ def _composite_attn_block(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, 
     return x2, linear_ln(s, woe, boe, y, g4, b4, eps4)
 
 
+def attn_half_f32_supported(yf, N: int, C: int) -> bool:
+    """dg_attn_half_f32_fwd (e projection + attention core + out_e + residual + ln4 as one float32 launch) serves C = 128 and
+    row groups of at most 48 neighbours; DG_ATTN_HALF_F32=off keeps the three launches (A/B measurements)."""
+    return (yf.is_cuda and yf.dtype == torch.float32 and C == 128 and N <= 48 and _h3_row_gemm()
+            and os.environ.get("DG_ATTN_HALF_F32", "fused") != "off")
+
+
 class _AttnBlock(Function):
     """x2 = LN3(x1 + out_n(o)), y2 = LN4(y + out_e(s)) with (s, o) = attention(q(x1), k(x1), v(x1), e(y))
     -- reference layers.py:111-135 + 186-190 -- as ONE autograd node: every projection is a row-GEMM
@@ -1537,26 +1544,48 @@ class _AttnBlock(Function):
             q = row_gemm(x1f, pw(wq, 0), C, C, bias=bq)
             k = row_gemm(x1f, pw(wk, 0), C, C, bias=bk)
             v = row_gemm(x1f, pw(wv, 0), C, C, bias=bv)
-        e = row_gemm(yf, pw(we, 0), C, C, bias=be)
         lib = _lib.load()
-        s = torch.empty_like(e) if need_edge else None
-        o = torch.empty_like(q)
-        with _dev(q):
-            _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
-                                            _lib.ptr(o), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_fwd")
-        _account("attn_fwd", q.element_size() * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
         # no input needs a gradient (the Generator's forward inside the D step): the pre-LayerNorm sums are not written
         keep = any(ctx.needs_input_grad)
+        o = torch.empty_like(q)
+        fused_edge = need_edge and attn_half_f32_supported(yf, N, C)
+        if fused_edge:
+            # e projection, scores, softmax / node output, out_e, residual, ln4: one launch (dg_attn_half_f32_fwd); e, s and
+            # the pre-LayerNorm sum are written for the backward only
+            R = yf.shape[0]
+            dev = yf.device
+            e = torch.empty(R, C, dtype=adt, device=dev) if keep else None
+            s = torch.empty(R, C, dtype=adt, device=dev) if keep else None
+            y2 = torch.empty(R, C, dtype=adt, device=dev)
+            pre4 = torch.empty(R, C, dtype=adt, device=dev) if keep else None
+            mean4 = torch.empty(R, dtype=torch.float32, device=dev)
+            rstd4 = torch.empty(R, dtype=torch.float32, device=dev)
+            with _dev(q):
+                _lib.check(lib.dg_attn_half_f32_fwd(_lib.ptr(yf), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), pw(we, 0).data_ptr(),
+                                                    _lib.fptr(_c(be)), pw(woe, 0).data_ptr(), _lib.fptr(_c(boe)), _lib.fptr(_c(g4)),
+                                                    _lib.fptr(_c(b4)), _lib.ptr(e), _lib.ptr(s), _lib.ptr(o), _lib.ptr(y2),
+                                                    _lib.ptr(pre4), _lib.ptr(mean4), _lib.ptr(rstd4), B, N, C, alpha, eps4,
+                                                    _lib.stream_of(q)), "dg_attn_half_f32_fwd")
+            _account("attn_half_fwd", 4 * (R * C * (5 if keep else 2) + 4 * B * N * C), 4 * R * C * C)
+        else:
+            e = row_gemm(yf, pw(we, 0), C, C, bias=be)
+            s = torch.empty_like(e) if need_edge else None
+            with _dev(q):
+                _lib.check(lib.dg_attn_core_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(e), _lib.ptr(s),
+                                                _lib.ptr(o), B, N, C, alpha, _lib.dt(q), _lib.stream_of(q)), "dg_attn_core_fwd")
+            _account("attn_fwd", q.element_size() * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
         r3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3), want_pre=keep)
         x2, mean3, rstd3, pre3 = r3 if keep else (*r3, None)
         outs = [x2.view(B, N, C)]
         saved = [x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3]
-        pre4 = None
         if need_edge:
-            r4 = row_gemm(s, pw(woe, 0), C, C, bias=boe, residual=yf, ln=(_c(g4), _c(b4), eps4), want_pre=keep)
-            y2, mean4, rstd4, pre4 = r4 if keep else (*r4, None)
+            if not fused_edge:
+                r4 = row_gemm(s, pw(woe, 0), C, C, bias=boe, residual=yf, ln=(_c(g4), _c(b4), eps4), want_pre=keep)
+                y2, mean4, rstd4, pre4 = r4 if keep else (*r4, None)
             outs.append(y2.view(B, N, N, C))
             saved += [mean4, rstd4, pre4]
+        else:
+            pre4 = None
         ctx.has_prev = ppre is not None
         if ctx.has_prev:
             saved += [ppre, pmean, prstd, pgamma]

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 218            /* 0.2.4: + riding launches (dg_launch_pair_begin / _end), paired feed-forward entries */
+#define DG_VERSION 219            /* 0.2.5: + riding launches, paired feed-forward entries, float32 fused attention-half forward */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -100,6 +100,20 @@ int dg_attn_half_fwd(const void* y, const void* q, const void* k, const void* v,
                      const float* be, const float* boe, const float* gamma4, const float* beta4,
                      void* o, void* y2, void* pre4, float* mean4, float* rstd4,
                      int B, int N, int C, float alpha, float eps, int dtype, dg_stream_t stream);
+
+/* The same attention half, FORWARD, for float32 rows (csrc/attn_half_f32.hip): e projection, scores, softmax and node
+ * output, out_e, residual, ln4 in ONE producer / consumer kernel per call,
+ *   e = y We^T + be;  sc = alpha q_i k_j (e + 1) e;  o_i = sum_j softmax_j(sc) v_j;  y2 = LN(y + sc Woe^T + boe),
+ * with everything the float32 backward reads written on the way: e, sc (`s`), the pre-LayerNorm sum (`pre_ln`), mean / rstd
+ * -- e, s and pre_ln may be NULL when no backward will follow (their stores are then skipped).  we_packed / woe_packed:
+ * dg_row_gemm_pack(e.weight / out_e.weight, 128, 128, mode 0) (fp16 hi + lo arithmetic of dg_row_gemm); C == 128, N <= 48
+ * (others DG_E_SHAPE: the caller takes dg_row_gemm + dg_attn_core_fwd + dg_row_gemm).  HBM traffic: read y once, write e,
+ * s, y2, pre_ln -- 5 x 4 R C bytes against 8 for the three launches.  Results are those of the unfused launches up to the
+ * rounding of a different accumulation order.                                                                            */
+int dg_attn_half_f32_fwd(const float* y, const float* q, const float* k, const float* v, const void* we_packed,
+                         const float* be, const void* woe_packed, const float* boe, const float* gamma4,
+                         const float* beta4, float* e, float* s, float* o, float* y2, float* pre_ln, float* mean4,
+                         float* rstd4, int B, int N, int C, float alpha, float eps, dg_stream_t stream);
 
 /* Backward of dg_attn_half_fwd given dz4 = d loss / d (y + s Woe^T + boe) -- the ln4 backward (dg_ln_residual_bwd on
  * pre4, mean4, rstd4) runs first and also yields dgamma4 / dbeta4 -- and d_o = d loss / d o.  e, s, p are recomputed

@@ -331,6 +331,66 @@ def test_alternating_traversal_is_invisible_in_the_results(R):
         assert torch.equal(s_, outs[0][0]) and torch.equal(o, outs[0][1])
 
 
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45)])
+def test_fused_float32_attention_half_forward(B, N):
+    """dg_attn_half_f32_fwd -- e = y We^T + be, sc = alpha q_i k_j (e + 1) e, o_i = sum_j softmax_j(sc) v_j,
+    y2 = LN(y + sc Woe^T + boe) (reference layers.py:114-135, 186-188) as ONE launch -- against the fp64 closed form and
+    against the three launches it replaces; with and without the outputs only a backward reads; repeated launches
+    (ascending / descending traversal) bit-identical."""
+    from druggen_amd import functional as dgf
+    lib = _lib().load()
+    C, alpha, eps = 128, 0.25, 1e-5
+    y = _gen((B, N, N, C), 400).float().cuda()
+    q, k, v = (_gen((B, N, C), 401 + i).float().cuda() for i in range(3))
+    we, woe = (_gen((C, C), 404) * 0.1).float().cuda(), (_gen((C, C), 405) * 0.1).float().cuda()
+    be, boe = (_gen((C,), 406) * 0.1).float().cuda(), (_gen((C,), 407) * 0.1).float().cuda()
+    g4, b4 = (_gen((C,), 408) * 0.1 + 1).float().cuda(), (_gen((C,), 409) * 0.1).float().cuda()
+    R = B * N * N
+    pe, po = dgf.packed_weight(we, 0), dgf.packed_weight(woe, 0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(keep):
+        e, s, pre = ((torch.full((R, C), float("nan"), device="cuda") for _ in range(3)) if keep else (None, None, None))
+        y2, o = torch.empty(R, C, device="cuda"), torch.empty(B, N, C, device="cuda")
+        mean, rstd = torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib().check(lib.dg_attn_half_f32_fwd(y.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), pe.data_ptr(), be.data_ptr(),
+                                              po.data_ptr(), boe.data_ptr(), g4.data_ptr(), b4.data_ptr(), p(e), p(s), o.data_ptr(),
+                                              y2.data_ptr(), p(pre), mean.data_ptr(), rstd.data_ptr(), B, N, C, alpha, eps, st),
+                     "dg_attn_half_f32_fwd")
+        return e, s, o, y2, pre, mean, rstd
+
+    e, s, o, y2, pre, mean, rstd = run(True)
+    yd = y.double().cpu().reshape(R, C)
+    ed = yd @ we.double().cpu().t() + be.double().cpu()
+    e4 = ed.view(B, N, N, C)
+    sc = alpha * q.double().cpu()[:, :, None, :] * k.double().cpu()[:, None, :, :] * (e4 * e4 + e4)
+    od = (torch.softmax(sc, dim=2) * v.double().cpu()[:, None, :, :]).sum(2)
+    pred = yd + sc.reshape(R, C) @ woe.double().cpu().t() + boe.double().cpu()
+    mu, var = pred.mean(1, keepdim=True), pred.var(1, unbiased=False, keepdim=True)
+    y2d = (pred - mu) / torch.sqrt(var + eps) * g4.double().cpu() + b4.double().cpu()
+    for got, want in ((e, ed), (s, sc.reshape(R, C)), (o, od), (pre, pred), (y2, y2d), (mean, mu.squeeze(1)),
+                      (rstd, 1 / torch.sqrt(var.squeeze(1) + eps))):
+        assert _rel(got, want) < TOL
+    # the three launches it replaces
+    e3 = dgf.row_gemm(y.view(R, C), pe, C, C, bias=be)
+    s3, o3 = torch.empty_like(e3), torch.empty(B, N, C, device="cuda")
+    _lib().check(lib.dg_attn_core_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), e3.data_ptr(), s3.data_ptr(), o3.data_ptr(), B, N, C,
+                                      alpha, 0, st), "dg_attn_core_fwd")
+    y3, _, _, p3 = dgf.row_gemm(s3, po, C, C, bias=boe, residual=y.view(R, C), ln=(g4, b4, eps), want_pre=True)
+    for got, want in ((e, e3), (s, s3), (o, o3), (pre, p3), (y2, y3)):
+        assert _rel(got, want.double().cpu()) < 5e-6
+    # outputs only a backward reads may be skipped; launches are bit-reproducible in either traversal direction
+    for keep in (False, True, True):
+        again = run(keep)
+        for a_, b_ in zip((e, s, o, y2, pre, mean, rstd), again):
+            if b_ is not None:
+                assert torch.equal(a_, b_)
+    assert lib.dg_attn_half_f32_fwd(y.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), pe.data_ptr(), be.data_ptr(),
+                                    po.data_ptr(), boe.data_ptr(), g4.data_ptr(), b4.data_ptr(), None, None, o.data_ptr(),
+                                    y2.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), B, 49, C, alpha, eps, st) != 0
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
