@@ -21,6 +21,9 @@
 #include "common.h"
 #include "traversal.h"
 
+#ifndef AH_DBG
+#define AH_DBG 0      // ablation builds (scripts/build_variant.sh): 1 no MFMAs, 2 no score / softmax arithmetic, 4 no score tile
+#endif                // -> HBM / planes, 8 no finish (residual, LayerNorm, stores), 16 no q / k / v loads, 32 no y split
 namespace dg {
 namespace {
 
@@ -109,6 +112,7 @@ struct HalfArgs {
     int B, N;
     float alpha, eps;
     int reverse;
+    int cs, spl;          // row groups per chunk, chunks per molecule (a workgroup keeps k, v of a chunk's molecule)
 };
 
 __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel(const HalfArgs a) {
@@ -117,17 +121,52 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N;
-    // row groups round-robin over the workgroups, ascending or (a.reverse, traversal.h) descending
-    const int64_t total = static_cast<int64_t>(a.B) * N;
+    // Work units are chunks of a.cs consecutive row groups (b, i0 .. i0 + cs) of ONE molecule -- round-robin over the workgroups,
+    // ascending or (a.reverse, traversal.h) descending -- so that k_j, v_j of the molecule are fetched once per chunk, not once per
+    // row group (they were 56 KB of L2 traffic per 115 KB of HBM traffic).  Stages past the molecule's last row group (the
+    // last chunk of a molecule may be short) and past the last chunk run empty.
+    const int64_t total = static_cast<int64_t>(a.B) * a.spl;      // chunks
     const int bidx = blockIdx.x, nblk = gridDim.x;
-    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk);      // >= 1
+    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk) * a.cs;      // >= cs
     const int TP = (T + 2) / 3 * 3;
-    auto group_of = [&](int t) {
-        if (t > T - 1) t = T - 1;
-        if (t < 0) t = 0;
-        const int64_t g = bidx + static_cast<int64_t>(t) * nblk;
-        return a.reverse ? total - 1 - g : g;
+    struct Where {
+        int64_t g;      // row group b N + i (clamped to a valid one)
+        int b;
+        bool live, first;
     };
+    // stage cursor: steps through the workgroup's stages with adds and compares only (one 32-bit division per chunk: three
+    // 64-bit divisions per stage cost the consumer waves ~300 scalar instructions of the ~1 100 they issued per stage)
+    struct Cursor {
+        int t, ii, j, b, i0;
+        int T, cs, spl, bidx, nblk, N, reverse, total;
+        __device__ __forceinline__ void chunk() {
+            int cid = bidx + j * nblk;
+            if (cid > total - 1) cid = total - 1;      // (stages past the last chunk run empty on a valid one)
+            if (reverse) cid = total - 1 - cid;
+            b = cid / spl;
+            i0 = (cid - b * spl) * cs;
+        }
+        __device__ __forceinline__ void start() {
+            t = ii = j = 0;
+            chunk();
+        }
+        __device__ __forceinline__ void advance() {
+            ++t;
+            if (++ii == cs) {
+                ii = 0;
+                ++j;
+                chunk();
+            }
+        }
+        __device__ __forceinline__ Where here() const {
+            int i = i0 + ii;
+            const bool live = t < T && i < N;
+            if (i > N - 1) i = N - 1;
+            return Where{static_cast<int64_t>(b) * N + i, b, live, ii == 0};
+        }
+    };
+    Cursor cur{0, 0, 0, 0, 0, T, a.cs, a.spl, bidx, nblk, N, a.reverse, static_cast<int>(total)};
+    cur.start();
 
     if (w >= kCons) {
         // ------------------------------------------------------------------------------------------ producers
@@ -151,8 +190,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         const unsigned voff = static_cast<unsigned>(hw) * 512u + static_cast<unsigned>(l32) * 16u;
         const int rowbytes = N * 512;
         float4 ys[3][6];
-        auto fetch = [&](float4 (&set)[6], int t) {
-            const int64_t g = group_of(t);
+        auto fetch = [&](float4 (&set)[6], const Where& wh) {
+            const int64_t g = wh.g;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + g * N * 128, 0, rowbytes,
                                                                                   0x00020000);      // rows >= N read as zeros
 #pragma unroll
@@ -163,6 +202,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         const int blk = l32 >> 1;
         const unsigned wbase = static_cast<unsigned>(blk * (kNP * 16) + (l32 & 1) * 8);
         auto split = [&](const float4 (&set)[6], char* pl, bool fence) {      // six rows -> hi / lo planes + inverse row scales
+            if ((AH_DBG & 32) && fence) return;
             unsigned m[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -213,32 +253,41 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                     *reinterpret_cast<float*>(pl + 2 * kPlane + (hw + 8 * i) * 4) = __uint_as_float((m[i] - 14u) << 23);
             }
         };
-        // score tile (and e tile) of stage t -> HBM and -> planes (A operand of out_e); the node output o_i
-        auto scores_out = [&](int t) {
-            const bool ok = t < T;
-            const int64_t g = group_of(t);
+        // score tile of stage t -> planes (A operand of out_e): the only work between the two barriers the consumers wait at
+        float4 sv[6];
+        auto scores_split = [&]() {
+            if (AH_DBG & 4) return;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int row = hw + 8 * i;
+                sv[i] = *reinterpret_cast<const float4*>(smem + kOffTs + row * 512 + ((l32 ^ (row & 7)) * 16));
+            }
+            split(sv, smem + kOffPs, false);
+        };
+        // ... and, while the consumers run out_e, the scores (still in registers), the e tile and the node output o_i -> HBM
+        auto scores_store = [&](const Where& wh) {
+            if (AH_DBG & 4) return;
+            const bool ok = wh.live;
+            const int64_t g = wh.g;
             const int bytes = ok ? rowbytes : 0;      // 0: every store is dropped
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.s ? a.s + g * N * 128 : a.y2, 0, a.s ? bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(a.e ? a.e + g * N * 128 : a.y2, 0, a.e ? bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(a.o + g * 128, 0, ok ? 512 : 0, 0x00020000);
-            float4 sv[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int row = hw + 8 * i;
-                const unsigned lo = static_cast<unsigned>(row * 512 + ((l32 ^ (row & 7)) * 16));
-                sv[i] = *reinterpret_cast<const float4*>(smem + kOffTs + lo);
-                const float4 ev = *reinterpret_cast<const float4*>(smem + kOffTe + lo);
+                const float4 ev = *reinterpret_cast<const float4*>(smem + kOffTe + row * 512 + ((l32 ^ (row & 7)) * 16));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[i]), rs_, voff, i * 4096, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), re_, voff, i * 4096, 0);
             }
             const float4 ov = *reinterpret_cast<const float4*>(smem + kOffO + (pt & 31) * 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), ro_, pt < 32 ? static_cast<unsigned>(pt) * 16u : 0x7FFFFFF0u, 0, 0);
-            split(sv, smem + kOffPs, false);
         };
         // out_e tile of stage t + residual (the y rows still in registers) -> LayerNorm -> HBM
-        auto finish = [&](const float4 (&res)[6], int t) {
-            const bool ok = t >= 0 && t < T;
-            const int64_t g = group_of(t);
+        auto finish = [&](const float4 (&res)[6], const Where& wh) {
+            if (AH_DBG & 8) return;
+            const bool ok = wh.live;
+            const int64_t g = wh.g;
             const int bytes = ok ? rowbytes : 0;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y2 + g * N * 128, 0, bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.pre ? a.pre + g * N * 128 : a.y2, 0, a.pre ? bytes : 0, 0x00020000);
@@ -262,39 +311,60 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, voff, i * 4096, 0);
             }
         };
-        fetch(ys[0], 0);
-        fetch(ys[1], 1);
+        // stages t - 1 (finish), t (stores), t + 1, t + 2 (fetch) of the iteration
+        Where wq[4];
+        wq[0] = Where{0, 0, false, false};
+        wq[1] = cur.here();
+        cur.advance();
+        wq[2] = cur.here();
+        cur.advance();
+        wq[3] = cur.here();
+        auto next_stage = [&]() {
+            wq[0] = wq[1];
+            wq[1] = wq[2];
+            wq[2] = wq[3];
+            cur.advance();
+            wq[3] = cur.here();
+        };
+        fetch(ys[0], wq[1]);
+        fetch(ys[1], wq[2]);
         split(ys[0], smem + kOffPy, true);
         __syncthreads();
         // stage t: | consumers: e projection + scores (t)      producers: finish (t - 1), fetch (t + 2)
-        //          | producers: score tile (t) -> HBM, planes   consumers wait
-        //          | consumers: out_e (t)                       producers: y planes of stage t + 1
+        //          | producers: score tile (t) -> planes         consumers wait
+        //          | consumers: out_e (t)                        producers: scores, e, o_i (t) -> HBM; y planes of stage t + 1
         for (int t = 0; t < TP; t += 3) {
-            finish(ys[2], t - 1);
-            fetch(ys[2], t + 2);
+            finish(ys[2], wq[0]);
+            fetch(ys[2], wq[3]);
             __syncthreads();
-            scores_out(t);
+            scores_split();
             __syncthreads();
+            scores_store(wq[1]);
             split(ys[1], smem + kOffPy, true);
+            next_stage();
             __syncthreads();
 
-            finish(ys[0], t);
-            fetch(ys[0], t + 3);
+            finish(ys[0], wq[0]);
+            fetch(ys[0], wq[3]);
             __syncthreads();
-            scores_out(t + 1);
+            scores_split();
             __syncthreads();
+            scores_store(wq[1]);
             split(ys[2], smem + kOffPy, true);
+            next_stage();
             __syncthreads();
 
-            finish(ys[1], t + 1);
-            fetch(ys[1], t + 4);
+            finish(ys[1], wq[0]);
+            fetch(ys[1], wq[3]);
             __syncthreads();
-            scores_out(t + 2);
+            scores_split();
             __syncthreads();
+            scores_store(wq[1]);
             split(ys[0], smem + kOffPy, true);
+            next_stage();
             __syncthreads();
         }
-        finish(ys[2], TP - 1);
+        finish(ys[2], wq[0]);
         return;
     }
 
@@ -334,7 +404,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int rb = 0; rb < 3; ++rb) {
-                    if (ks == 0 && term == 0) mfma16_first(acc[rb], wf[ks][1], xh[rb]);
+                    if (AH_DBG & 1) {
+                        if (ks == 0 && term == 0) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[rb][0] += static_cast<float>(xh[rb][0]) * static_cast<float>(wf[ks][0][0]);
+                    } else if (ks == 0 && term == 0) mfma16_first(acc[rb], wf[ks][1], xh[rb]);
                     else mfma16(acc[rb], wf[ks][term == 0 ? 1 : 0], term == 1 ? xl[rb] : xh[rb]);
                 }
         }
@@ -343,22 +416,28 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
     __builtin_amdgcn_s_waitcnt(0x0F70);      // weight fragments are in registers
     __syncthreads();                         // stage 0 is in the y planes, the tables are written
     const float4 cse = ld4(tab + c0), bev = ld4(tab + 128 + c0), cso = ld4(tab + 256 + c0), bov = ld4(tab + 384 + c0);
-    for (int t = 0; t < TP; ++t) {
-        const bool live = t < T;
-        const int64_t g = group_of(t);
-        const int64_t b = g / N;
-        // q_i, and k_j / v_j of the lane's three rows (clamped: rows >= N are masked below)
-        float4 qa = f4(0.f), kk[3], vv[3];
-        if (live) {
-            qa = a.alpha * ld4(a.q + g * 128 + c0);
+    // q_i of the stage, and -- once per chunk -- k_j / v_j of the lane's three rows (clamped: rows >= N are masked below),
+    // requested one stage ahead: as soon as stage t's softmax has used its set
+    float4 qa = f4(0.f), kk[3], vv[3];
+    auto request_qkv = [&](const Where& wh) {
+        if (AH_DBG & 16) return;
+        qa = ld4(a.q + wh.g * 128 + c0);
+        if (wh.first) {
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 const int j = 16 * rb + n;
-                const int64_t jr = (b * N + (j < N ? j : 0)) * 128 + c0;
+                const int64_t jr = (wh.b * N + (j < N ? j : 0)) * 128 + c0;
                 kk[rb] = ld4(a.k + jr);
                 vv[rb] = ld4(a.v + jr);
             }
         }
+    };
+    Where wc = cur.here();
+    request_qkv(wc);
+    for (int t = 0; t < TP; ++t) {
+        const bool live = wc.live;
+        cur.advance();
+        wc = cur.here();
         if (live) {
             f32x4 acc[3];
             contract(smem + kOffPy, wfe, acc);
@@ -371,12 +450,13 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                 const float4 ev = make_float4(fmaf(acc[rb][0], rs * cse.x, bev.x), fmaf(acc[rb][1], rs * cse.y, bev.y),
                                               fmaf(acc[rb][2], rs * cse.z, bev.z), fmaf(acc[rb][3], rs * cse.w, bev.w));
                 const bool valid = row < N;
-                sc[rb] = valid ? qa * kk[rb] * fma4(ev, ev, ev) : f4(0.f);
+                sc[rb] = valid ? (a.alpha * qa) * kk[rb] * fma4(ev, ev, ev) : f4(0.f);
                 if (valid) m = max4(m, sc[rb]);
                 const unsigned lo = static_cast<unsigned>(row * 512 + (((4 * w + kq) ^ (row & 7)) * 16));
                 *reinterpret_cast<float4*>(smem + kOffTe + lo) = ev;
                 *reinterpret_cast<float4*>(smem + kOffTs + lo) = sc[rb];
             }
+            if (!(AH_DBG & 2)) {
             m = make_float4(row16_max(m.x), row16_max(m.y), row16_max(m.z), row16_max(m.w));
             float4 l = f4(0.f), av = f4(0.f);
 #pragma unroll
@@ -387,8 +467,13 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             }
             l = make_float4(row16_sum(l.x), row16_sum(l.y), row16_sum(l.z), row16_sum(l.w));
             av = make_float4(row16_sum(av.x), row16_sum(av.y), row16_sum(av.z), row16_sum(av.w));
-            if (n == 0) *reinterpret_cast<float4*>(smem + kOffO + c0 * 4) = av * rcp4(l);
+            if (n == 0)      // (v_rcp_f32: 1 ulp; an IEEE division is a 10-instruction sequence per component)
+                *reinterpret_cast<float4*>(smem + kOffO + c0 * 4) =
+                    make_float4(av.x * __builtin_amdgcn_rcpf(l.x), av.y * __builtin_amdgcn_rcpf(l.y), av.z * __builtin_amdgcn_rcpf(l.z),
+                                av.w * __builtin_amdgcn_rcpf(l.w));
+            }
         }
+        request_qkv(wc);      // the NEXT stage's (also after an empty stage: the next one may open a chunk)
         __syncthreads();      // e / score tiles, o_i written
         __syncthreads();      // score planes written
         if (live) {
@@ -423,11 +508,15 @@ extern "C" int dg_attn_half_f32_fwd(const float* y, const float* q, const float*
         return fail(DG_E_SHAPE, "dg_attn_half_f32_fwd: unsupported shape B=%d N=%d C=%d (C = 128, N <= 48)", B, N, C);
     if (B == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int64_t total = static_cast<int64_t>(B) * N;
-    const int64_t rows = total * N;
+    // chunks of row groups: enough of them to fill the chip, as long as possible (k, v are fetched once per chunk)
+    const int want = (256 + B - 1) / B;                      // chunks per molecule wanted
+    const int cs = (N + want - 1) / want;                    // row groups per chunk (>= 1)
+    const int spl = (N + cs - 1) / cs;                       // chunks per molecule
+    const int64_t chunks = static_cast<int64_t>(B) * spl;
+    const int64_t rows = static_cast<int64_t>(B) * N * N;
     HalfArgs a{y, q, k, v, static_cast<const f16x8*>(we_packed), be, static_cast<const f16x8*>(woe_packed), boe, gamma, beta,
-               e, s, o, y2, pre_ln, mean, rstd, B, N, alpha, eps, take_direction(rows)};
-    const int blocks = static_cast<int>(total < 256 ? total : 256);
+               e, s, o, y2, pre_ln, mean, rstd, B, N, alpha, eps, take_direction(rows), cs, spl};
+    const int blocks = static_cast<int>(chunks < 256 ? chunks : 256);
     ProfScope prof(DG_K_ATTN_HALF_FWD, stream);
     DG_OPT_IN_LDS((&attn_half_f32_fwd_kernel), kLds);
     hipLaunchKernelGGL(attn_half_f32_fwd_kernel, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
