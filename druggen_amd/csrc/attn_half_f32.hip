@@ -72,14 +72,12 @@ __device__ __forceinline__ float row16_max(float x) {
     x = max_dpp<0x141>(x);
     return max_dpp<0x140>(x);
 }
-// sum over the 32 lanes of a half-wave, result in every lane
-__device__ __forceinline__ float half_wave_total(float x, bool upper) {
+// sum over the 32 lanes of a half-wave, result in every lane: the two 16-lane row totals meet through one v_permlane16_swap
+// (four v_readlane + their wait states before)
+__device__ __forceinline__ float half_wave_total(float x) {
     x = row16_sum(x);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
-    return upper ? r2 + r3 : r0 + r1;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // in-place MFMAs and the fence in front of the first vector read of their results: see row_gemm_k384.hip
@@ -173,7 +171,6 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         __builtin_amdgcn_s_setprio(3);
         const int pt = threadIdx.x - 64 * kCons;
         const int hw = pt >> 5, l32 = pt & 31;
-        const bool upper = (lane & 32) != 0;
         {
             const float* cse = reinterpret_cast<const float*>(a.we + 4 * 8 * 2 * 64);
             const float* cso = reinterpret_cast<const float*>(a.woe + 4 * 8 * 2 * 64);
@@ -300,9 +297,9 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                 float4 v = *reinterpret_cast<const float4*>(smem + kOffTo + row * 512 + ((l32 ^ (row & 7)) * 16));
                 v += res[i];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, voff, i * 4096, 0);
-                const float mu = half_wave_total((v.x + v.y) + (v.z + v.w), upper) * (1.0f / 128.0f);
+                const float mu = half_wave_total((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
                 const float4 d = v - f4(mu);
-                const float var = half_wave_total((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w), upper) * (1.0f / 128.0f);
+                const float var = half_wave_total((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 128.0f);
                 const float rsd = rsqrtf(var + a.eps);
                 v = fma4(rsd * d, gam, bet);
                 const unsigned soff = l32 == 0 ? static_cast<unsigned>(row) * 4u : 0x7FFFFFF0u;      // one lane per row
