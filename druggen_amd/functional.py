@@ -1522,6 +1522,15 @@ def attn_half_f32_supported(yf, N: int, C: int) -> bool:
             and os.environ.get("DG_ATTN_HALF_F32", "fused") != "off")
 
 
+def attn_half_f32_bwd1_supported(dy2f, B: int, N: int, C: int) -> bool:
+    """dg_attn_half_f32_bwd1 (ln4 backward + out_e input gradient + attention-core backward as one float32 launch) serves
+    C = 128 and row groups of at most 48 neighbours; its workgroups walk whole molecules, so it needs a batch that fills the
+    chip (B >= 128; DG_ATTN_HALF_F32_BWD=force lifts that for tests, =off keeps the two launches)."""
+    mode = os.environ.get("DG_ATTN_HALF_F32_BWD", "fused")
+    return (dy2f.is_cuda and dy2f.dtype == torch.float32 and C == 128 and N <= 48 and _h3_row_gemm() and mode != "off"
+            and (B >= 128 or mode == "force"))
+
+
 class _AttnBlock(Function):
     """x2 = LN3(x1 + out_n(o)), y2 = LN4(y + out_e(s)) with (s, o) = attention(q(x1), k(x1), v(x1), e(y))
     -- reference layers.py:111-135 + 186-190 -- as ONE autograd node: every projection is a row-GEMM
@@ -1632,7 +1641,8 @@ class _AttnBlock(Function):
                                    q, k, v, e, s, o, mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2,
                                    add3, add4, aq, ak, av, ae,
                                    alpha, need_edge, ctx.needs_input_grad[0], ctx.needs_input_grad[1], wants_w,
-                                   ppre if fuse_prev else None, pmean, prstd, pgamma, want_aff)
+                                   ppre if fuse_prev else None, pmean, prstd, pgamma, want_aff,
+                                   not torch.is_grad_enabled())      # (no graph is being recorded: see _AttnBlockBwd)
         (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4, dzp, dgp, dbp) = outs
         if not (ctx.needs_input_grad[25] and not _inputs_only()):
             dgp = dbp = None
@@ -1688,7 +1698,8 @@ class _AttnBlockBwd(Function):
     @staticmethod
     def _forward(ctx, inb, x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, bon, g3, g4, q, k, v, e, s, o,
                  mean3, rstd3, pre3, mean4, rstd4, pre4, dx2, dy2, add3, add4, aq, ak, av, ae,
-                 alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None, want_aff=None):
+                 alpha, need_edge, want_x, want_y, wants_w, ppre=None, pmean=None, prstd=None, pgamma=None, want_aff=None,
+                 no_graph=False):
         if want_aff is None:
             want_aff = wants_w
         B, N, C = x1.shape
@@ -1702,9 +1713,31 @@ class _AttnBlockBwd(Function):
                                      batch_slot=0 if inb else None)
         do = row_gemm(dz3, pw(won, 1), C, C).view(B, N, C)
         ds = dz4 = dg4 = db4 = dy2f = None
+        qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
+        fused1 = None
         if need_edge:
             dy2f = _c(cast(dy2)).reshape(-1, C)
-            if add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):
+            if (add4 is None and all(t is None for t in (aq, ak, av, ae)) and no_graph
+                    and attn_half_f32_bwd1_supported(dy2f, B, N, C)):
+                # ln4 backward + ds = dz4 Woe + the attention core's backward: one launch, ds never reaches HBM (no graph is being
+                # recorded: the second order would need ds)
+                lib = _lib.load()
+                dev = dy2f.device
+                dz4, de = torch.empty_like(dy2f), torch.empty_like(dy2f)
+                dq, dk, dv = (torch.empty(B, N, C, dtype=adt, device=dev) for _ in range(3))
+                dg4, db4 = (torch.empty(2, C, dtype=torch.float32, device=dev).unbind(0) if want_aff else (None, None))
+                with _dev(dy2f):
+                    ws = _scratch(dy2f, int(lib.dg_attn_half_f32_bwd1_workspace_bytes(B)), "ahb_batch" if inb else "ahb")
+                    _lib.check(lib.dg_attn_half_f32_bwd1(_lib.ptr(dy2f), _lib.ptr(pre4), _lib.ptr(mean4), _lib.ptr(rstd4),
+                                                         _lib.fptr(_c(g4)), pw(woe, 1).data_ptr(), _lib.ptr(ev), _lib.ptr(qv),
+                                                         _lib.ptr(kv), _lib.ptr(vv), _lib.ptr(do), _lib.ptr(dz4), _lib.ptr(de),
+                                                         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dg4), _lib.ptr(db4),
+                                                         ws.data_ptr(), ws.numel(), B, N, C, alpha, _lib.stream_of(dy2f)),
+                               "dg_attn_half_f32_bwd1")
+                _account("attn_half_bwd", 4 * (dy2f.shape[0] * C * 5 + 7 * B * N * C), 2 * dy2f.shape[0] * C * C)
+                de = de.view(B, N, N, C)
+                fused1 = (dq, dk, dv, de)
+            elif add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):
                 # ln4's backward runs in the producer waves of the out_e input-gradient GEMM (edge-level launches only:
                 # at node level the three small launches it replaces are faster)
                 dz4, ds, dg4, db4 = ln_bwd_row_gemm(pre4, g4, mean4, rstd4, dy2f, pw(woe, 1), want_affine=want_aff,
@@ -1714,13 +1747,12 @@ class _AttnBlockBwd(Function):
                 dz4, dg4, db4 = _ln_bwd_rows(pre4, g4, mean4, rstd4, dy2f, cadd(add4), want_affine=want_aff,
                                              batch_slot=1 if inb else None)
                 ds = row_gemm(dz4, pw(woe, 1), C, C).view(B, N, N, C)
-        qv, kv, vv, ev = q.view(B, N, C), k.view(B, N, C), v.view(B, N, C), e.view(B, N, N, C)
         # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
         # variant of that kernel is latency-bound at 2 waves / SIMD and the extra operand set costs more than the add
         # it saves (configs[2], A/B on one box: 217.2 vs 213.7 ms per step): bf16 adds afterwards.
         fold = ae is not None and adt == torch.float32 and os.environ.get("DG_ATTN_ADD", "kernel") != "post"
         aef = _c(cast(ae)).view(B, N, N, C) if fold else None      # joins de inside the kernel
-        dq, dk, dv, de = _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha, add_e=aef)
+        dq, dk, dv, de = fused1 if fused1 is not None else _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha, add_e=aef)
         for got, extra in ((dq, aq), (dk, ak), (dv, av), (de, None if fold else ae)):
             if extra is not None:
                 got.add_(extra.view(got.shape))
@@ -1822,7 +1854,7 @@ class _AttnBlockBwd(Function):
         #         mean3,rstd3,pre3, mean4,rstd4,pre4, dx2, dy2, 6 adds, 5 flags, 4 LNHandle fields, want_aff
         return (None, None, *gW, g3bar, g4bar, gq.view_as(q), gk.view_as(k), gv.view_as(v), ge.view_as(e), None, None,
                 None, None, z3bar, None, None, z4bar, dx2bar.view(dx2_shape),
-                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 16))
+                None if dy2bar is None else dy2bar.view(dy2_shape), *([None] * 17))
 
 
 _half_pack_cache = {}
