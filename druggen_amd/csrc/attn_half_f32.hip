@@ -198,8 +198,16 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         // block b = c >> 1 of float4 column c = l32 (k-step c >> 3, quarter (c >> 1) & 3), half c & 1; row r of a block sits at r ^ (b & 7)
         const int blk = l32 >> 1;
         const unsigned wbase = static_cast<unsigned>(blk * (kNP * 16) + (l32 & 1) * 8);
+        // fp32 tiles: row hw + 8 i sits at tile + i * 4096 + trow (row & 7 = hw for all six rows); planes: row hw + 8 i of block
+        // blk at plane + i * 128 + prow.  ONE lane term each, made opaque per use: hipcc otherwise keeps every (buffer, row)
+        // address of a stage in registers across the whole loop
+        const unsigned trow0 = static_cast<unsigned>(hw * 512 + ((l32 ^ hw) * 16));
+        const unsigned prow0 = wbase + static_cast<unsigned>((hw ^ (blk & 7)) * 16);
         auto split = [&](const float4 (&set)[6], char* pl, bool fence) {      // six rows -> hi / lo planes + inverse row scales
             if ((AH_DBG & 32) && fence) return;
+            unsigned prow = prow0;
+            asm volatile("" : "+v"(prow));
+            char* pw_ = pl + prow;
             unsigned m[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -239,10 +247,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                 xa -= __builtin_convertvector(ha, f32x2);
                 xb -= __builtin_convertvector(hb, f32x2);
                 const f16x2 la = __builtin_convertvector(xa, f16x2), lb = __builtin_convertvector(xb, f16x2);
-                const int row = hw + 8 * i;
-                const unsigned off = wbase + static_cast<unsigned>((row ^ (blk & 7)) * 16);
-                *reinterpret_cast<u32x2*>(pl + off) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-                *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+                *reinterpret_cast<u32x2*>(pw_ + i * 128) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+                *reinterpret_cast<u32x2*>(pw_ + kPlane + i * 128) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
             }
             if (l32 == 0) {
 #pragma unroll
@@ -254,11 +260,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         float4 sv[6];
         auto scores_split = [&]() {
             if (AH_DBG & 4) return;
+            unsigned trow = trow0;
+            asm volatile("" : "+v"(trow));
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int row = hw + 8 * i;
-                sv[i] = *reinterpret_cast<const float4*>(smem + kOffTs + row * 512 + ((l32 ^ (row & 7)) * 16));
-            }
+            for (int i = 0; i < 6; ++i) sv[i] = *reinterpret_cast<const float4*>(smem + kOffTs + trow + i * 4096);
             split(sv, smem + kOffPs, false);
         };
         // ... and, while the consumers run out_e, the scores (still in registers), the e tile and the node output o_i -> HBM
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.s ? a.s + g * N * 128 : a.y2, 0, a.s ? bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(a.e ? a.e + g * N * 128 : a.y2, 0, a.e ? bytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(a.o + g * 128, 0, ok ? 512 : 0, 0x00020000);
+            unsigned trow = trow0;
+            asm volatile("" : "+v"(trow));
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int row = hw + 8 * i;
-                const float4 ev = *reinterpret_cast<const float4*>(smem + kOffTe + row * 512 + ((l32 ^ (row & 7)) * 16));
+                const float4 ev = *reinterpret_cast<const float4*>(smem + kOffTe + trow + i * 4096);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[i]), rs_, voff, i * 4096, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), re_, voff, i * 4096, 0);
             }
@@ -291,10 +297,12 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.mean + g * N, 0, ok ? N * 4 : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.rstd + g * N, 0, ok ? N * 4 : 0, 0x00020000);
             const float4 gam = ld4(tab + 512 + 4 * l32), bet = ld4(tab + 640 + 4 * l32);
+            unsigned trow = trow0;
+            asm volatile("" : "+v"(trow));
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int row = hw + 8 * i;
-                float4 v = *reinterpret_cast<const float4*>(smem + kOffTo + row * 512 + ((l32 ^ (row & 7)) * 16));
+                float4 v = *reinterpret_cast<const float4*>(smem + kOffTo + trow + i * 4096);
                 v += res[i];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, voff, i * 4096, 0);
                 const float mu = half_wave_total((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);

@@ -160,6 +160,11 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
         const unsigned wbase = static_cast<unsigned>(blk * (kNP * 16) + (l32 & 1) * 8);
         const float4 gam = ld4(a.gamma + 4 * l32);
         float4 dgam = f4(0.f), dbet = f4(0.f);
+        // fp32 tiles: row hw + 8 i of a tile sits at tile + i * 4096 + trow (row & 7 = hw for all six rows); planes: row
+        // hw + 8 i of block blk at plane + i * 128 + prow.  ONE lane term each, made opaque per use: hipcc otherwise keeps the
+        // ~18 (buffer, row) addresses of a stage in registers across the whole loop (29 spilled registers)
+        const unsigned trow0 = static_cast<unsigned>(hw * 512 + ((l32 ^ hw) * 16));
+        const unsigned prow0 = wbase + static_cast<unsigned>((hw ^ (blk & 7)) * 16);
         float4 es[6];               // e rows of the same stage: through registers into the LDS tile (an LDS-DMA would have to be
                                     // awaited with vmcnt before the barrier -- together with every store issued since)
         float4 dys[6], prs[6];      // ONE set: the rows of stage t + 2 are requested right after the LayerNorm backward of stage
@@ -185,20 +190,22 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
             st = __uint_as_float(mv | rv);      // (the lane that does not take part read 0)
         };
         auto stage_e = [&](int buf) {      // the prefetched e rows -> LDS tile [buf]
+            unsigned trow = trow0;
+            asm volatile("" : "+v"(trow));
+            char* tb = smem + kOffTe + buf * kTile + trow;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int row = hw + 8 * i;
-                *reinterpret_cast<float4*>(smem + kOffTe + buf * kTile + row * 512 + ((l32 ^ (row & 7)) * 16)) = es[i];
-            }
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(tb + i * 4096) = es[i];
             __builtin_amdgcn_sched_barrier(0);
         };
         auto store_prev = [&](const Where& wh, int buf) {      // de tile and dq_i of a finished stage -> HBM
             const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(a.de + wh.g * N * 128, 0, wh.live ? rowbytes : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rq_ = __builtin_amdgcn_make_buffer_rsrc(a.dq + wh.g * 128, 0, wh.live ? 512 : 0, 0x00020000);
+            unsigned trow = trow0;
+            asm volatile("" : "+v"(trow));
+            const char* tb = smem + kOffTd + buf * kTile + trow;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int row = hw + 8 * i;
-                const u32x4 dv_ = *reinterpret_cast<const u32x4*>(smem + kOffTd + buf * kTile + row * 512 + ((l32 ^ (row & 7)) * 16));
+                const u32x4 dv_ = *reinterpret_cast<const u32x4*>(tb + i * 4096);
                 __builtin_amdgcn_raw_buffer_store_b128(dv_, re_, voff, i * 4096, 0);
             }
             const u32x4 qv = *reinterpret_cast<const u32x4*>(smem + kOffQ + buf * 512 + (pt & 31) * 16);
@@ -209,6 +216,9 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
         auto ln_bwd_split = [&](const float4 (&dyr)[6], float4 (&prr)[6], float st, const Where& wh, int buf) {
             const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(a.dz + wh.g * N * 128, 0, wh.live ? rowbytes : 0, 0x00020000);
             char* pl = smem + kOffPa + buf * kPlanes;
+            unsigned prow = prow0;
+            asm volatile("" : "+v"(prow));
+            char* pw_ = pl + prow;
             const float livef = wh.live ? 1.f : 0.f;
             float4 (&dzr)[6] = prr;      // dz4 takes the place of the pre-LayerNorm rows, row by row
 #pragma unroll
@@ -262,16 +272,15 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
                 xa -= __builtin_convertvector(ha, f32x2);
                 xb -= __builtin_convertvector(hb, f32x2);
                 const f16x2 la = __builtin_convertvector(xa, f16x2), lb = __builtin_convertvector(xb, f16x2);
-                const int row = hw + 8 * i;
-                const unsigned off = wbase + static_cast<unsigned>((row ^ (blk & 7)) * 16);
-                *reinterpret_cast<u32x2*>(pl + off) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-                *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+                *reinterpret_cast<u32x2*>(pw_ + i * 128) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+                *reinterpret_cast<u32x2*>(pw_ + kPlane + i * 128) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
             }
             if (l32 == 0) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     *reinterpret_cast<float*>(pl + 2 * kPlane + (hw + 8 * i) * 4) = __uint_as_float((m[i] - 14u) << 23);
             }
+            __builtin_amdgcn_sched_barrier(0);      // (the next stage's loads are not hoisted above this: they reuse the registers)
         };
         // stages t - 1 (stores), t + 1 (LayerNorm backward, e tile), t + 2 (prefetch) of iteration t
         Where wprev{0, 0, 0, false};
