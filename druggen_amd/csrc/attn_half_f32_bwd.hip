@@ -89,8 +89,7 @@ __device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-// at most the 14 youngest vector-memory operations of the wave may still be in flight (loads return in order: everything a
-// producer issued before its last prefetch -- the LDS-DMA of the e tile above all -- has landed)
+
 struct HalfBwdArgs {
     const float* dy2;     // [B,N,N,128]
     const float* pre;     // pre-LayerNorm sum of ln4
@@ -345,6 +344,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
                 wf[ks][p] = a.woe[(static_cast<size_t>(tslab * 8 + 2 * ks + (kq >> 1)) * 2 + p) * 64 + (kq & 1) * 32 + col];
     }
     const int c0 = 16 * w + 4 * kq;      // this lane's four channels
+    // row 16 rb + n of an fp32 tile, this lane's slot: tile + rb * 8192 + tlane (row & 7 = n & 7 for the three row blocks)
+    const unsigned tlane0 = static_cast<unsigned>(n * 512 + (((4 * w + kq) ^ (n & 7)) * 16));
     const unsigned xo_e = static_cast<unsigned>(kq * (kNP * 16) + ((n ^ kq) * 16));            // even k-steps
     const unsigned xo_o = static_cast<unsigned>(kq * (kNP * 16) + ((n ^ (4 + kq)) * 16));      // odd k-steps
     // q_i, d_o_i of the stage and -- at the first row group of a molecule -- k_j, v_j of the lane's three rows, one stage ahead
@@ -375,8 +376,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
         wc = cur.here();
         if (wh.live) {
             const char* pl = smem + kOffPa + (t & 1) * kPlanes;
-            const char* te = smem + kOffTe + (t & 1) * kTile;
-            char* td = smem + kOffTd + (t & 1) * kTile;
+            unsigned tlane = tlane0;
+            asm volatile("" : "+v"(tlane));      // opaque per stage: the (buffer, row block) addresses are not kept across the loop
+            const char* te = smem + kOffTe + (t & 1) * kTile + tlane;
+            char* td = smem + kOffTd + (t & 1) * kTile + tlane;
             f32x4 acc[3];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 const int row = 16 * rb + n;
-                const float4 ev = *reinterpret_cast<const float4*>(te + row * 512 + (((4 * w + kq) ^ (row & 7)) * 16));
+                const float4 ev = *reinterpret_cast<const float4*>(te + rb * 8192);
                 pe[rb] = qa * kk[rb] * fma4(ev, ev, ev);
                 if (row < N) m = max4(m, pe[rb]);
             }
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
                 const float4 cs = ld4(tab + c0);
                 const float4 wss = make_float4(acc[rb][0] * (rs * cs.x), acc[rb][1] * (rs * cs.y), acc[rb][2] * (rs * cs.z),
                                                acc[rb][3] * (rs * cs.w));
-                const float4 ev = *reinterpret_cast<const float4*>(te + row * 512 + (((4 * w + kq) ^ (row & 7)) * 16));
+                const float4 ev = *reinterpret_cast<const float4*>(te + rb * 8192);
                 const float4 p = pe[rb] * inv;
                 float4 ds = fma4(p, woi * vv[rb] - abar, wss);
                 if (row >= N) ds = f4(0.f);
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
                 dqa = fma4(dsg, kk[rb], dqa);      // (kk holds alpha k_j)
                 dka[rb] = fma4(dsg, qa, dka[rb]);  // (alpha at the store)
                 const float4 dev = ds * qa * kk[rb] * fma4(f4(2.f), ev, f4(1.f));
-                *reinterpret_cast<float4*>(td + row * 512 + (((4 * w + kq) ^ (row & 7)) * 16)) = dev;
+                *reinterpret_cast<float4*>(td + rb * 8192) = dev;
                 __builtin_amdgcn_sched_barrier(0);      // one row block at a time: bounds the live temporaries
             }
             dqa = row16_sum4(dqa);

@@ -391,6 +391,68 @@ def test_fused_float32_attention_half_forward(B, N):
                                     y2.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), B, 49, C, alpha, eps, st) != 0
 
 
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45), (300, 9)])
+def test_fused_float32_attention_half_backward_part1(B, N):
+    """dg_attn_half_f32_bwd1 -- ln4 backward, ds = dz4 Woe, attention-core backward (reference layers.py:119-135, 186-188,
+    differentiated) as ONE launch -- against fp64 autograd of the same expressions and against the two launches it
+    replaces; more molecules than workgroups (300 > 256); repeated launches bit-identical."""
+    from druggen_amd import functional as dgf
+    lib = _lib().load()
+    C, alpha, eps = 128, 0.25, 1e-5
+    R = B * N * N
+    dy2 = _gen((R, C), 500).float().cuda()
+    pre = (_gen((R, C), 501) * 2 + 0.3).float().cuda()
+    e = (_gen((B, N, N, C), 502) * 0.5).float().cuda()
+    q, k, v, d_o = (_gen((B, N, C), 503 + i).float().cuda() for i in range(4))
+    woe = (_gen((C, C), 507) * 0.1).float().cuda()
+    g4 = (_gen((C,), 508) * 0.1 + 1).float().cuda()
+    mean = pre.double().mean(1).float().contiguous()
+    rstd = (1 / torch.sqrt(pre.double().var(1, unbiased=False) + eps)).float().contiguous()
+    pwo = dgf.packed_weight(woe, 1)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(int(lib.dg_attn_half_f32_bwd1_workspace_bytes(B)), dtype=torch.uint8, device="cuda")
+
+    def run():
+        dz, de = (torch.full((R, C), float("nan"), device="cuda") for _ in range(2))
+        dq, dk, dv = (torch.full((B, N, C), float("nan"), device="cuda") for _ in range(3))
+        dgb = torch.full((2, C), float("nan"), device="cuda")
+        _lib().check(lib.dg_attn_half_f32_bwd1(dy2.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g4.data_ptr(),
+                                               pwo.data_ptr(), e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                               d_o.data_ptr(), dz.data_ptr(), de.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                               dv.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                               B, N, C, alpha, st), "dg_attn_half_f32_bwd1")
+        return dz, de, dq, dk, dv, dgb[0], dgb[1]
+
+    got = run()
+    # fp64 autograd: pre = p0 + sc Woe^T with p0 chosen so that pre is the given pre-LayerNorm sum
+    leaf = lambda t: t.double().cpu().requires_grad_(True)
+    ed, qd, kd, vd, gd = leaf(e), leaf(q), leaf(k), leaf(v), leaf(g4)
+    bd = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    sc = alpha * qd[:, :, None, :] * kd[:, None, :, :] * (ed * ed + ed)
+    od = (torch.softmax(sc, dim=2) * vd[:, None, :, :]).sum(2)
+    wd = woe.double().cpu()
+    p0 = (pre.double().cpu() - sc.detach().reshape(R, C) @ wd.t()).requires_grad_(True)
+    pd = p0 + sc.reshape(R, C) @ wd.t()
+    y2 = torch.nn.functional.layer_norm(pd, (C,), gd, bd, eps)
+    loss = (y2 * dy2.double().cpu()).sum() + (od * d_o.double().cpu()).sum()
+    want = torch.autograd.grad(loss, [p0, ed, qd, kd, vd, gd, bd])
+    for a_, b_ in zip(got, want):
+        assert _rel(a_.reshape(b_.shape), b_) < TOL
+    # the two launches it replaces
+    dz_r, ds_r, dg_r, db_r = dgf.ln_bwd_row_gemm(pre, g4, mean, rstd, dy2, pwo, want_affine=True)
+    dq_r, dk_r, dv_r, de_r = dgf._attn_bwd_launch(q, k, v, e, ds_r.view(B, N, N, C), d_o, alpha)
+    for a_, b_ in zip(got, (dz_r, de_r, dq_r, dk_r, dv_r, dg_r, db_r)):
+        assert _rel(a_.reshape(b_.shape), b_.double().cpu()) < 5e-6
+    for _ in range(2):
+        for a_, b_ in zip(got, run()):
+            assert torch.equal(a_, b_)
+    assert lib.dg_attn_half_f32_bwd1(dy2.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g4.data_ptr(),
+                                     pwo.data_ptr(), e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(),
+                                     got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
+                                     got[4].data_ptr(), got[5].data_ptr(), got[6].data_ptr(), ws.data_ptr(), 16, B, N, C,
+                                     alpha, st) != 0      # workspace too small
+
+
 def test_attn_core_is_bit_reproducible():
     from druggen_amd import functional as dgf
     B, N, C, alpha = 4, 45, 128, 0.25
