@@ -31,10 +31,12 @@ cd $R
 # ---- SQ counters of the kernels this round worked on (one rocprofv3 pass per counter group, kernel trace only)
 scripts/pmc_run.sh $tag/pmc_half attn_half -- python $R/scripts/half_probe.py 2048 45 > $O/pmc_attn_half_fwd.txt 2>&1
 scripts/pmc_run.sh $tag/pmc_hb attn_half_bwd -- python $R/scripts/half_bwd_probe.py 2048 45 > $O/pmc_attn_half_bwd.txt 2>&1
+scripts/pmc_run.sh $tag/pmc_h32 attn_half_f32_fwd -- python $R/scripts/half_f32_probe.py > $O/pmc_attn_half_f32_fwd.txt 2>&1
+scripts/pmc_run.sh $tag/pmc_h32b attn_half_f32_bwd1 -- python $R/scripts/half_f32_bwd_check.py > $O/pmc_attn_half_f32_bwd1.txt 2>&1
 scripts/pmc_run.sh $tag/pmc_wg wgrad_stream -- python $R/scripts/wgrad_probe.py > $O/pmc_wgrad.txt 2>&1
 python scripts/wgrad_probe.py > $O/wgrad_probe_h3.txt 2>&1; DG_WGRAD=sym python scripts/wgrad_probe.py > $O/wgrad_probe_sym.txt 2>&1
 python scripts/lnb_probe.py > $O/lnb_probe.txt 2>&1
-rm -rf $O/pmc_half $O/pmc_hb $O/pmc_wg $O/*.p[0-9].log
+rm -rf $O/pmc_half $O/pmc_hb $O/pmc_h32 $O/pmc_h32b $O/pmc_wg $O/*.p[0-9].log
 cp profiles/traffic.json $O/traffic.json 2>/dev/null || echo '{"records": []}' > $O/traffic.json
 python scripts/pmc_traffic.py $(find $O/pmc_c2_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c2_WRITE_SIZE -name "*counter_collection.csv") c2 f32 256 $commit $O/traffic.json 150e6 > $O/traffic_c2.txt
 python scripts/pmc_traffic.py $(find $O/pmc_c3_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c3_WRITE_SIZE -name "*counter_collection.csv") c3 bf16 2048 $commit $O/traffic.json 600e6 > $O/traffic_c3.txt

@@ -22,8 +22,8 @@ import sys
 
 # bench.py key -> regex on the (mangled or demangled) kernel name
 KEYS = [
-    ("attn_half_fwd", r"attn_half_fwd"),
-    ("attn_half_bwd", r"attn_half_bwd"),
+    ("attn_half_fwd", r"attn_half(_f32)?_fwd"),
+    ("attn_half_bwd", r"attn_half(_f32)?_bwd"),
     ("attn_bwd2", r"attn_bwd2_kernel"),
     ("attn_bwd", r"attn_bwd_kernel"),
     ("attn_fwd", r"attn_fwd_kernel"),
