@@ -310,7 +310,7 @@ def main():
         split = os.environ.get("DG_ROW_GEMM") != "mfma32"
         gemm_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS)
         gemm_how = ("1x v_mfma_f32_*_bf16 per product (bf16 operands, fp32 accumulate)" if bf16 else
-                    ("3x v_mfma_f32_32x32x16_f16 per product (fp32 operands scaled by a power of two and split hi + lo "
+                    ("3x v_mfma_f32_16x16x32_f16 per product (fp32 operands scaled by a power of two and split hi + lo "
                      "into fp16, fp32 accumulate: fp32-class accuracy, tests/test_hip_kernels.py)" if split
                      else "v_mfma_f32_32x32x2_f32"))
         kernels = {}
@@ -337,7 +337,7 @@ def main():
                             peak, how = MFMA_F32_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32"
                         else:
                             peak = MFMA_BF16_PEAK_TFLOPS / 3.0
-                            how = ("3x v_mfma_f32_32x32x16_f16 per product (fp32 operands split hi + lo into fp16 under running "
+                            how = ("3x v_mfma_f32_16x16x32_f16 per product (fp32 operands split hi + lo into fp16 under running "
                                    "power-of-two column scales, fp32 accumulate)")
                     kernels[name].update({"achieved_TFLOPs": tf, "mfma_peak_TFLOPs": peak,
                                           "frac_of_mfma_peak": tf / peak, "mfma": how})
