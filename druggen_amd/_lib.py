@@ -72,6 +72,9 @@ SIGNATURES = {
     "dg_skinny_linear_fwd": (c_int, [_P] * 4 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_dgrad": (c_int, [_P] * 3 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_wgrad": (c_int, [_P] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_head_chain": (c_int, [_P] * 14 + [c_int64, c_int, _P]),
+    "dg_head_bwd": (c_int, [_P] * 10 + [c_int64, c_int, _P]),
+    "dg_head_wgrad": (c_int, [_P] * 12 + [c_int64, _P]),
     "dg_row_gemm_pack_batch": (c_int, [_P, c_int, c_int, c_int, _P]),
     "dg_row_gemm_ln_bwd_workspace_bytes": (c_size_t, [c_int]),
     "dg_row_gemm_ln_bwd": (c_int, [_P] * 3 + [c_int64, c_int] + [_P] * 7 + [_P, c_size_t, c_int, _P]),

@@ -593,6 +593,110 @@ class _Readout(Function):
         return (None if dx is None else dx.view(x.shape)), dw, db
 
 
+_HEAD_ACTS = {"relu": 0, "leaky": 1}
+
+
+def _head_launch(fn, name, *args):
+    _lib.check(fn(*args), name)
+
+
+class _HeadTail(Function):
+    """Tail of the Discriminator head after its first Linear (reference models.py:173-178, 207): act - Linear(64, 32) - act -
+    Linear(32, 16) - act - Linear(16, 1) over the rows of ``z1`` as ONE launch (dg_head_chain); the backward is one launch
+    for the input gradient (dg_head_bwd) and one for the six parameter gradients (dg_head_wgrad), itself differentiable
+    (``_HeadTailBwd``: the gradient penalty's second order is the same chain kernel with the activation pattern as a mask)."""
+
+    @staticmethod
+    def forward(ctx, z1, w2, b2, w3, b3, w4, b4, act):
+        z1 = _c(z1)
+        R = z1.shape[0]
+        dev = z1.device
+        a1, a2, a3 = (torch.empty(R, n, dtype=torch.float32, device=dev) for n in (64, 32, 16))
+        out = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with _dev(z1):
+            _head_launch(lib.dg_head_chain, "dg_head_chain", _lib.ptr(z1), None, None, None, _lib.fptr(_c(w2)), _lib.fptr(_c(b2)),
+                         _lib.fptr(_c(w3)), _lib.fptr(_c(b3)), _lib.fptr(_c(w4)), _lib.fptr(_c(b4)), _lib.ptr(a1), _lib.ptr(a2),
+                         _lib.ptr(a3), _lib.ptr(out), R, act, _lib.stream_of(z1))
+        ctx.save_for_backward(a1, a2, a3, w2, w3, w4)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        a1, a2, a3, w2, w3, w4 = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[1:7]) and not _inputs_only()
+        g1, dw2, db2, dw3, db3, dw4, db4 = _HeadTailBwd.apply(g_out, a1, a2, a3, w2, w3, w4, need_w, ctx.act)
+        return g1, dw2, db2, dw3, db3, dw4, db4, None
+
+
+class _HeadTailBwd(Function):
+    @staticmethod
+    def forward(ctx, g_out, a1, a2, a3, w2, w3, w4, need_w, act):
+        g_out = _c(g_out.float()).reshape(-1, 1)
+        R = a1.shape[0]
+        dev = a1.device
+        g3, g2, g1 = (torch.empty(R, n, dtype=torch.float32, device=dev) for n in (16, 32, 64))
+        lib = _lib.load()
+        dws = [None] * 6
+        with _dev(a1):
+            st = _lib.stream_of(a1)
+            _head_launch(lib.dg_head_bwd, "dg_head_bwd", _lib.ptr(g_out), _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(a3), _lib.fptr(_c(w2)),
+                         _lib.fptr(_c(w3)), _lib.fptr(_c(w4)), _lib.ptr(g3), _lib.ptr(g2), _lib.ptr(g1), R, act, st)
+            if need_w:
+                dw2, dw3, dw4 = torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
+                db2, db3, db4 = (torch.empty(n, dtype=torch.float32, device=dev) for n in (32, 16, 1))
+                _head_launch(lib.dg_head_wgrad, "dg_head_wgrad", _lib.ptr(g_out), _lib.ptr(a3), _lib.ptr(g3), _lib.ptr(a2), _lib.ptr(g2),
+                             _lib.ptr(a1), _lib.ptr(dw4), _lib.ptr(db4), _lib.ptr(dw3), _lib.ptr(db3), _lib.ptr(dw2), _lib.ptr(db2),
+                             R, st)
+                dws = [dw2, db2, dw3, db3, dw4, db4]
+        ctx.save_for_backward(g_out, a1, a2, a3, w2, w3, w4, g2, g3)
+        ctx.act = act
+        ctx.set_materialize_grads(False)
+        return (g1, *dws)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, t1, *tw):
+        if any(t is not None for t in tw):
+            raise RuntimeError("head_tail: second-order terms through parameter gradients are not implemented")
+        if t1 is None:
+            return (None,) * 9
+        g_out, a1, a2, a3, w2, w3, w4, g2, g3 = ctx.saved_tensors
+        t1 = _c(t1.float())
+        R = a1.shape[0]
+        dev = a1.device
+        u1, u2, u3 = (torch.empty(R, n, dtype=torch.float32, device=dev) for n in (64, 32, 16))
+        uo = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        gw2 = gw3 = gw4 = None
+        with _dev(a1):
+            st = _lib.stream_of(a1)
+            _head_launch(lib.dg_head_chain, "dg_head_chain", _lib.ptr(t1), _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(a3), _lib.fptr(_c(w2)),
+                         None, _lib.fptr(_c(w3)), None, _lib.fptr(_c(w4)), None, _lib.ptr(u1), _lib.ptr(u2), _lib.ptr(u3),
+                         _lib.ptr(uo), R, ctx.act, st)
+            if not _inputs_only():
+                gw2, gw3, gw4 = torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
+                _head_launch(lib.dg_head_wgrad, "dg_head_wgrad", _lib.ptr(g_out), _lib.ptr(u3), _lib.ptr(g3), _lib.ptr(u2), _lib.ptr(g2),
+                             _lib.ptr(u1), _lib.ptr(gw4), None, _lib.ptr(gw3), None, _lib.ptr(gw2), None, R, st)
+        # act'' = 0: nothing reaches the forward's activations
+        return uo, None, None, None, gw2, gw3, gw4, None, None
+
+
+def head_tail_supported(z1, layers, act_name) -> bool:
+    """``layers`` = the three Linears after the head's first one."""
+    return (z1.is_cuda and z1.dtype == torch.float32 and z1.dim() == 2 and act_name in _HEAD_ACTS
+            and [tuple(l.weight.shape) for l in layers] == [(32, 64), (16, 32), (1, 16)]
+            and all(l.bias is not None and l.weight.dtype == torch.float32 for l in layers)
+            and os.environ.get("DG_HEAD_TAIL", "fused") != "off")
+
+
+def head_tail(z1, layers, act_name):
+    """act(z1) -> Linear(64, 32) -> act -> Linear(32, 16) -> act -> Linear(16, 1): [R, 64] -> [R, 1]."""
+    l2, l3, l4 = layers
+    return _HeadTail.apply(z1, l2.weight, l2.bias, l3.weight, l3.bias, l4.weight, l4.bias, _HEAD_ACTS[act_name])
+
+
 def readout(x, weight, bias=None):
     """float32 ``F.linear(x.float(), weight, bias)`` for the Generator's readouts (dim 128 -> edge / node classes)."""
     ok = (x.is_cuda and x.dtype in _lib.DTYPES and weight.dim() == 2 and weight.shape[1] == 128 and 1 <= weight.shape[0] <= 16

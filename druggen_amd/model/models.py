@@ -118,7 +118,14 @@ class Discriminator(_Trunk):
 
     def forward(self, z_e, z_n):
         node, _ = self._encode(z_e, z_n, False)
-        return self.node_mlp(node.reshape(node.shape[0], -1).float())
+        h = node.reshape(node.shape[0], -1).float()
+        mlp = self.node_mlp
+        tail = (mlp[2], mlp[4], mlp[6])
+        z1 = mlp[0](h)
+        if dgf.head_tail_supported(z1, tail, self._act_name):
+            # act - Linear(64, 32) - act - Linear(32, 16) - act - Linear(16, 1): one launch per direction (dg_head_*)
+            return dgf.head_tail(z1, tail, self._act_name)
+        return mlp[6](mlp[5](mlp[4](mlp[3](mlp[2](mlp[1](z1))))))
 
 
 class simple_disc(nn.Module):

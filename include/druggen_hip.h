@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 220            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1) */
+#define DG_VERSION 221            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -461,6 +461,27 @@ int dg_skinny_linear_dgrad(const float* dy, const float* w, void* dx, int64_t R,
 /* dw [N,K], db [N] (nullable) from float32 dy [R,N] and x [R,K] of `dtype`; workspace as for dg_linear_wgrad. */
 int dg_skinny_linear_wgrad(const float* dy, const void* x, float* dw, float* db, void* workspace, size_t workspace_bytes,
                            int64_t R, int N, int K, int dtype, dg_stream_t stream);
+
+/* Tail of the Discriminator head (reference models.py:173-178, 207: node_mlp after its first Linear): rows [R,64] of
+ * pre-activations z1 -> a1 = act(z1) [R,64], a2 = act(a1 W2^T + b2) [R,32], a3 = act(a2 W3^T + b3) [R,16], out = a3 W4^T + b4
+ * [R,1] in ONE launch (6 on the BLAS + ATen).  w2 [32,64], w3 [16,32], w4 [1,16], float32; act: 0 ReLU, 1 LeakyReLU(0.01)
+ * (other activations: not served, the caller keeps torch.nn.Sequential).
+ *   dg_head_chain, m1 = m2 = m3 = NULL: the forward (o1..o4 = a1, a2, a3, out).
+ *   dg_head_chain, m1..m3 = a1..a3 (the forward's activations), `in` = t [R,64]: the second order of the gradient penalty --
+ *     o1 = t . act'(a1), o2 = (o1 W2^T) . act'(a2), o3 = (o2 W3^T) . act'(a3), o4 = o3 W4^T (biases unused); with t the
+ *     adjoint of dg_head_bwd's g1, o4 is the adjoint of g_out and (g2, o1), (g3, o2), (g_out, o3) are dg_head_wgrad's operands
+ *     for the adjoints of W2, W3, W4.
+ *   dg_head_bwd: g3 = (g_out W4) . act'(a3) [R,16], g2 = (g3 W3) . act'(a2) [R,32], g1 = (g2 W2) . act'(a1) [R,64] = d z1.
+ *   dg_head_wgrad: dw4 [1,16] = l4^T r4, dw3 [16,32] = l3^T r3, dw2 [32,64] = l2^T r2, db = column sums of l4, l3, l2
+ *     (all three or NULL); first order: l = (g_out, g3, g2), r = (a3, a2, a1).  Rows are summed in ascending order by one
+ *     thread per result element: bit-reproducible.                                                                    */
+int dg_head_chain(const float* in, const float* m1, const float* m2, const float* m3, const float* w2, const float* b2,
+                  const float* w3, const float* b3, const float* w4, const float* b4, float* o1, float* o2, float* o3,
+                  float* o4, int64_t R, int act, dg_stream_t stream);
+int dg_head_bwd(const float* g_out, const float* a1, const float* a2, const float* a3, const float* w2, const float* w3,
+                const float* w4, float* g3, float* g2, float* g1, int64_t R, int act, dg_stream_t stream);
+int dg_head_wgrad(const float* l4, const float* r4, const float* l3, const float* r3, const float* l2, const float* r2,
+                  float* dw4, float* db4, float* dw3, float* db3, float* dw2, float* db2, int64_t R, dg_stream_t stream);
 
 /* dg_argmax_decode: reference inference.py:197-198 `torch.max(x, -1)[1]` on logits
  * [rows, E] -> uint8 labels [rows] (first maximum), so only bytes cross PCIe.      */

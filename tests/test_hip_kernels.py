@@ -1174,3 +1174,60 @@ def test_embed_second_order_entry_rejects_smooth_activations():
     for act, want in ((2, -2), (3, -2)):
         st = lib.dg_embed_sym_bwd2(*args, act, 0, None)
         assert st == want and b"piecewise-linear" in lib.dg_last_error_string()
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky"])
+@pytest.mark.parametrize("R", [1, 5, 64, 300, 512])
+def test_discriminator_head_tail_all_orders(R, act):
+    """dg_head_chain / dg_head_bwd / dg_head_wgrad (the Discriminator head after its first Linear, reference
+    models.py:173-178) against torch.nn.Sequential in float64: output, first-order gradients of z1 and the six
+    parameters, and the gradient-penalty pattern (gradient of a function of d out / d z1 with respect to the parameters
+    and z1's upstream) -- the second order of the same node."""
+    import torch.nn as nn
+    from druggen_amd import functional as dgf
+    torch.manual_seed(7 + R)
+    mk = {"relu": nn.ReLU, "leaky": nn.LeakyReLU}[act]
+    ref = nn.Sequential(mk(), nn.Linear(64, 32), mk(), nn.Linear(32, 16), mk(), nn.Linear(16, 1)).double()
+    lay = [nn.Linear(64, 32), nn.Linear(32, 16), nn.Linear(16, 1)]
+    for l, i in zip(lay, (1, 3, 5)):
+        l.weight.data.copy_(ref[i].weight.data.float())
+        l.bias.data.copy_(ref[i].bias.data.float())
+        ref[i].weight.data.copy_(l.weight.data.double())
+        ref[i].bias.data.copy_(l.bias.data.double())
+        l.cuda()
+    z = _gen((R, 64), 600 + R).float()
+    w_out = _gen((R, 1), 601 + R).float()
+    zc = z.cuda().requires_grad_(True)
+    zd = z.double().requires_grad_(True)
+    assert dgf.head_tail_supported(zc, lay, act)
+    out = dgf.head_tail(zc, lay, act)
+    outd = ref(zd)
+    assert _rel(out.detach(), outd.detach()) < TOL
+    params = [p for l in lay for p in (l.weight, l.bias)]
+    paramsd = [p for i in (1, 3, 5) for p in (ref[i].weight, ref[i].bias)]
+    got = torch.autograd.grad(out, [zc] + params, w_out.cuda(), retain_graph=True)
+    want = torch.autograd.grad(outd, [zd] + paramsd, w_out.double(), retain_graph=True)
+    for a_, b_ in zip(got, want):
+        assert _rel(a_, b_) < TOL
+    # gradient-penalty pattern: ((|d out / d z1| - 1)^2).mean() differentiated with respect to the parameters
+    (gz,) = torch.autograd.grad(out, zc, torch.ones_like(out), create_graph=True)
+    (gzd,) = torch.autograd.grad(outd, zd, torch.ones_like(outd), create_graph=True)
+    pen = ((gz.norm(dim=1) - 1) ** 2).mean()
+    pend = ((gzd.norm(dim=1) - 1) ** 2).mean()
+    assert abs(pen.item() - pend.item()) < 1e-4 * max(1.0, abs(pend.item()))
+    got2 = torch.autograd.grad(pen, [l.weight for l in lay])
+    want2 = torch.autograd.grad(pend, [ref[i].weight for i in (1, 3, 5)])
+    for a_, b_ in zip(got2, want2):
+        assert _rel(a_, b_) < 5e-5
+    if R % 2 == 0:
+        # D(real) and D(fake) as one batch: upstream -1/B for the first half of the rows, +1/B for the second.  The reference
+        # runs two passes whose last-bias gradients (-1, +1) cancel exactly; the summation by halves must too (AdamW turns a
+        # residue of 1e-8 into a full-size step)
+        B = R // 2
+        gsign = torch.cat([torch.full((B, 1), -1.0 / B), torch.full((B, 1), 1.0 / B)]).cuda()
+        gb = torch.autograd.grad(out, lay[2].bias, gsign, retain_graph=True)[0]
+        assert gb.item() == 0.0
+    # launches are bit-reproducible
+    out2 = dgf.head_tail(zc, lay, act)
+    got_again = torch.autograd.grad(out2, [zc] + params, w_out.cuda())
+    assert torch.equal(out, out2) and all(torch.equal(a_, b_) for a_, b_ in zip(got, got_again))
