@@ -727,10 +727,61 @@ def bump_weights_epoch() -> None:
                 del cache[k]
 
 
+_alias_canon = {}      # data pointer -> weakref of the parameter an alias output stands for
+
+
+def _weight_alias(t):
+    """A view of parameter ``t`` that a forward node returns as an extra output and hands to its differentiable backward
+    node in place of ``t`` (second-order forward of the gradient penalty): the second-order gradient of the parameter
+    then comes back to the forward node as the gradient of that output and joins the node's own parameter gradient in
+    one multi-tensor add -- otherwise the autograd engine sums the two contributions of every parameter with a launch
+    each (~50 tiny adds per step)."""
+    a = t.view_as(t)
+    if len(_alias_canon) > 4096:
+        for k in [k for k, r in _alias_canon.items() if r() is None]:
+            del _alias_canon[k]
+    _alias_canon[a.data_ptr()] = weakref.ref(t)
+    return a
+
+
+def _canon(w):
+    """The parameter behind an alias made by ``_weight_alias`` (same storage, shape, version), else ``w``: the pack
+    caches are keyed by the parameter object."""
+    r = _alias_canon.get(w.data_ptr())
+    o = r() if r is not None else None
+    if o is not None and o is not w and o.shape == w.shape and o._version == w._version and o.dtype == w.dtype:
+        return o
+    return w
+
+
+def _join_alias_grads(own, extra):
+    """own[i] += extra[i] where both exist (one multi-tensor launch), own[i] = extra[i] where only the latter does."""
+    own = list(own)
+    have, add = [], []
+    for i, (o, g) in enumerate(zip(own, extra)):
+        if g is None:
+            continue
+        if o is None:
+            own[i] = g
+        elif torch.is_grad_enabled():
+            own[i] = o + g
+        else:
+            have.append(o)
+            add.append(g if g.dtype == o.dtype else g.to(o.dtype))
+    if have:
+        torch._foreach_add_(have, add)
+    return own
+
+
+def _alias_outputs_enabled() -> bool:
+    return os.environ.get("DG_PENALTY_WGRAD", "joined") != "engine"
+
+
 def packed_weight(w, mode: int, dtype=torch.float32):
     """MFMA-fragment-ordered copy of an nn.Linear weight (mode 0: forward, 1: input
     gradient) for activations of ``dtype``, cached per (storage, version): re-packed only after an
     optimizer step."""
+    w = _canon(w)
     key = (id(w), mode, dtype)
     hit = _pack_cache.get(key)
     if (hit is not None and hit[0]() is w and hit[1] == w._version and hit[3] == w.data_ptr()
@@ -759,6 +810,7 @@ def packed_weight3(w0, w1, w2, mode: int):
     """``packed_weight`` for the vertical stack [w0; w1; w2] of three float32 [128,128] weights (q / k / v of an attention
     block) as ONE operand: mode 0 -> the 128 -> 384 forward operand of ``lin3``, mode 1 -> the 384 -> 128 input-gradient
     operand of ``sum3`` (dg_row_gemm_pack3).  Cached per (storages, versions) like ``packed_weight``."""
+    w0, w1, w2 = _canon(w0), _canon(w1), _canon(w2)
     key = (id(w0), id(w1), id(w2), mode)
     ws = (w0, w1, w2)
     hit = _pack3_cache.get(key)
@@ -1270,15 +1322,24 @@ class _FFNLNPair(Function):
         outs = (pn["y"].view(pn["inp"].shape), pn["pre"], pn["mean"], pn["rstd"],
                 pe["y"].view(pe["inp"].shape), pe["pre"], pe["mean"], pe["rstd"])
         ctx.mark_non_differentiable(pn["mean"], pn["rstd"], pe["mean"], pe["rstd"])
+        ctx.alias = False
         if not keep:
             return outs
+        args = list(args)
+        aliases = ()
+        if in_second_order_forward() and _alias_outputs_enabled():
+            # the penalty's forward: w1, w2, gamma of both branches leave as alias outputs (see _weight_alias)
+            ctx.alias = True
+            for i in (1, 3, 5, 8, 10, 12):
+                args[i] = _weight_alias(args[i])
+            aliases = tuple(args[i] for i in (1, 3, 5, 8, 10, 12))
         ctx.save_for_backward(*args[0:7], pn["h"], pn["mean"], pn["rstd"], pn["pre"], pn["bits"],
                               *args[7:14], pe["h"], pe["mean"], pe["rstd"], pe["pre"], pe["bits"])
         ctx.set_materialize_grads(False)
-        return outs
+        return outs + aliases
 
     @staticmethod
-    def backward(ctx, dyn, dpren, _dmn, _drn, dye, dpree, _dme=None, _dre=None):
+    def backward(ctx, dyn, dpren, _dmn, _drn, dye, dpree, _dme=None, _dre=None, *galias):
         sv = ctx.saved_tensors
         call = []
         for base, off, dy, dpre in ((0, 2, dyn, dpren), (12, 9, dye, dpree)):
@@ -1288,7 +1349,11 @@ class _FFNLNPair(Function):
             if dy is None and (dpre is None or torch.is_grad_enabled()):
                 dy = torch.zeros_like(pre)
             call += [x, w1, b1, w2, b2, gamma, h, mean, rstd, pre, bits, dy, dpre, ctx.needs_input_grad[off], want_w, want_aff]
-        o = _FFNLNPairBwd.apply(*call)
+        o = list(_FFNLNPairBwd.apply(*call))
+        if any(g is not None for g in galias):      # second-order gradients of w1, w2, gamma (node), w1, w2, gamma (edge)
+            idx = (1, 3, 5, 8, 10, 12)
+            for i, v in zip(idx, _join_alias_grads([o[i] for i in idx], galias)):
+                o[i] = v
         return (None, None, *o[0:7], *o[7:14])
 
 
@@ -1427,7 +1492,7 @@ def ffn_ln_pair(x, node, y, edge):
         xo = ffn_ln(x, *node)
         yo, handle = ffn_ln(y, *edge, want_handle=True)
         return xo, yo, handle
-    xo, _pn, _mn, _rn, yo, pre, mean, rstd = _FFNLNPair.apply(float(node[6]), float(edge[6]), x, *node[:6], y, *edge[:6])
+    xo, _pn, _mn, _rn, yo, pre, mean, rstd = _FFNLNPair.apply(float(node[6]), float(edge[6]), x, *node[:6], y, *edge[:6])[:8]
     handle = LNHandle(pre, mean, rstd, edge[4], edge[5]) if (pre is not None and pre.requires_grad) else None
     return xo, yo, handle
 
@@ -1690,6 +1755,12 @@ class _AttnBlock(Function):
         r3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3), want_pre=keep)
         x2, mean3, rstd3, pre3 = r3 if keep else (*r3, None)
         outs = [x2.view(B, N, C)]
+        # the penalty's forward: the parameters leave as alias outputs (see _weight_alias)
+        ctx.alias = bool(keep and in_second_order_forward() and _alias_outputs_enabled())
+        aliases = ()
+        if ctx.alias:
+            aliases = tuple(_weight_alias(t) for t in (wq, wk, wv, we, woe, won, g3, g4))
+            wq, wk, wv, we, woe, won, g3, g4 = aliases
         saved = [x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3]
         if need_edge:
             if not fused_edge:
@@ -1709,11 +1780,14 @@ class _AttnBlock(Function):
         # pre3 / pre4 / q / k / v / e are outputs only so that the second order of the gradient penalty
         # can return their adjoints to THIS node, where they join the first-order gradients inside one
         # backward pass (see _AttnBlockBwd.backward); module code never sees them.
-        return tuple(outs) + ((pre3, pre4) if need_edge else (pre3,)) + (q, k, v, e)
+        return tuple(outs) + ((pre3, pre4) if need_edge else (pre3,)) + (q, k, v, e) + aliases
 
     @staticmethod
     def backward(ctx, dx2, *more):
         alpha, eps3, eps4, need_edge, (B, N, C) = ctx.cfg
+        galias = ()
+        if ctx.alias:      # second-order gradients of wq, wk, wv, we, woe, won, g3, g4 (or None each)
+            more, galias = more[:-8], more[-8:]
         sv = ctx.saved_tensors
         x1, y, wq, wk, wv, we, woe, won, g3, g4, q, k, v, e, s, o, mean3, rstd3, pre3 = sv[:19]
         mean4, rstd4, pre4 = sv[19:22] if need_edge else (None, None, None)
@@ -1748,6 +1822,8 @@ class _AttnBlock(Function):
                                    ppre if fuse_prev else None, pmean, prstd, pgamma, want_aff,
                                    not torch.is_grad_enabled())      # (no graph is being recorded: see _AttnBlockBwd)
         (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4, dzp, dgp, dbp) = outs
+        if any(g is not None for g in galias):
+            dwq, dwk, dwv, dwe, dwoe, dwon, dg3, dg4 = _join_alias_grads((dwq, dwk, dwv, dwe, dwoe, dwon, dg3, dg4), galias)
         if not (ctx.needs_input_grad[25] and not _inputs_only()):
             dgp = dbp = None
         return (dx1, dy, dwq, dbq, dwk, dbk, dwv, dbv, dwe, dbe, dwoe, dboe, dwon, dbon, dg3, db3, dg4, db4,

@@ -55,3 +55,16 @@ for ev in prof.events():
 print(f"# leaf ATen ops with device time in one step (B = {B}): {sum(agg.values())}")
 for (name, site, node), n in agg.most_common(70):
     print(f"{n:5d}  {name:30s} {site:50s} {node}")
+# device-to-device copies (hipMemcpyAsync: clone / contiguous / copy_ of contiguous tensors), by enclosing op chain
+cp = collections.Counter()
+for ev in prof.events():
+    if "emcpy" not in ev.name or ev.device_type != torch.autograd.DeviceType.CPU:
+        continue
+    chain, p = [], ev.cpu_parent
+    while p is not None and len(chain) < 4:
+        chain.append(p.name.replace("autograd::engine::evaluate_function: ", ""))
+        p = p.cpu_parent
+    cp[(ev.name, " < ".join(chain))] += 1
+print(f"# memcpy runtime calls in the step: {sum(cp.values())}")
+for (name, chain), n in cp.most_common(30):
+    print(f"{n:5d}  {name:24s} {chain}")
