@@ -72,6 +72,8 @@ SIGNATURES = {
     "dg_skinny_linear_fwd": (c_int, [_P] * 4 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_dgrad": (c_int, [_P] * 3 + [c_int64, c_int, c_int, c_int, _P]),
     "dg_skinny_linear_wgrad": (c_int, [_P] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, _P]),
+    "dg_embed_node_chain": (c_int, [_P] * 9 + [c_int64, c_int, c_int, _P]),
+    "dg_embed_node_bwd": (c_int, [_P] * 8 + [c_int64, c_int, c_int, _P]),
     "dg_head_chain": (c_int, [_P] * 14 + [c_int64, c_int, _P]),
     "dg_head_bwd": (c_int, [_P] * 10 + [c_int64, c_int, _P]),
     "dg_head_wgrad": (c_int, [_P] * 12 + [c_int64, _P]),

@@ -596,6 +596,98 @@ class _Readout(Function):
 _HEAD_ACTS = {"relu": 0, "leaky": 1}
 
 
+class _NodeEmbed(Function):
+    """Linear(E, 64) - act - Linear(64, 128) - act over the node rows (reference models.py:52-56, 154-158) as ONE launch
+    (dg_embed_node_chain); backward: one launch for g2 / g1 / dz (dg_embed_node_bwd) + the two weight gradients on
+    dg_linear_wgrad; differentiable again (``_NodeEmbedBwd``: the penalty's second order is the chain kernel with the
+    activation pattern as a mask)."""
+
+    @staticmethod
+    def forward(ctx, z, w1, b1, w2, b2, act):
+        E = z.shape[-1]
+        z2 = _c(z).reshape(-1, E)
+        R = z2.shape[0]
+        a1 = torch.empty(R, 64, dtype=torch.float32, device=z.device)
+        a2 = torch.empty(R, 128, dtype=torch.float32, device=z.device)
+        lib = _lib.load()
+        with _dev(z2):
+            _lib.check(lib.dg_embed_node_chain(_lib.ptr(z2), None, None, _lib.fptr(_c(w1)), _lib.fptr(_c(b1)), _lib.fptr(_c(w2)),
+                                               _lib.fptr(_c(b2)), _lib.ptr(a1), _lib.ptr(a2), R, E, act, _lib.stream_of(z2)),
+                       "dg_embed_node_chain")
+        ctx.save_for_backward(z2, a1, a2, w1, w2)
+        ctx.act, ctx.zshape = act, z.shape
+        return a2.view(*z.shape[:-1], 128)
+
+    @staticmethod
+    def backward(ctx, g):
+        z2, a1, a2, w1, w2 = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[1:5]) and not _inputs_only()
+        dz, dw1, db1, dw2, db2 = _NodeEmbedBwd.apply(g, z2, a1, a2, w1, w2, ctx.needs_input_grad[0], need_w, ctx.act)
+        return (None if dz is None else dz.view(ctx.zshape)), dw1, db1, dw2, db2, None
+
+
+class _NodeEmbedBwd(Function):
+    @staticmethod
+    def forward(ctx, g, z2, a1, a2, w1, w2, need_z, need_w, act):
+        gshape = g.shape
+        g = _c(g.float()).reshape(-1, 128)
+        R, E = z2.shape
+        dev = z2.device
+        g2 = torch.empty(R, 128, dtype=torch.float32, device=dev)
+        g1 = torch.empty(R, 64, dtype=torch.float32, device=dev)
+        dz = torch.empty(R, E, dtype=torch.float32, device=dev) if need_z else None
+        lib = _lib.load()
+        with _dev(z2):
+            _lib.check(lib.dg_embed_node_bwd(_lib.ptr(g), _lib.ptr(a1), _lib.ptr(a2), _lib.fptr(_c(w1)), _lib.fptr(_c(w2)),
+                                             _lib.ptr(g2), _lib.ptr(g1), _lib.ptr(dz), R, E, act, _lib.stream_of(z2)),
+                       "dg_embed_node_bwd")
+        dw1 = db1 = dw2 = db2 = None
+        if need_w:
+            dw2, db2 = _wgrad(g2, a1, True)
+            dw1, db1 = _wgrad(g1, z2, True)
+        ctx.save_for_backward(z2, a1, a2, w1, w2, g1, g2)
+        ctx.act, ctx.gshape = act, gshape
+        ctx.set_materialize_grads(False)
+        return dz, dw1, db1, dw2, db2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, t_dz, *tw):
+        if any(t is not None for t in tw):
+            raise RuntimeError("node_embed: second-order terms through parameter gradients are not implemented")
+        if t_dz is None:
+            return (None,) * 9
+        z2, a1, a2, w1, w2, g1, g2 = ctx.saved_tensors
+        R, E = z2.shape
+        t = _c(t_dz.float()).reshape(-1, E)
+        dev = z2.device
+        u1 = torch.empty(R, 64, dtype=torch.float32, device=dev)
+        u2 = torch.empty(R, 128, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with _dev(z2):
+            _lib.check(lib.dg_embed_node_chain(_lib.ptr(t), _lib.ptr(a1), _lib.ptr(a2), _lib.fptr(_c(w1)), None, _lib.fptr(_c(w2)),
+                                               None, _lib.ptr(u1), _lib.ptr(u2), R, E, ctx.act, _lib.stream_of(z2)),
+                       "dg_embed_node_chain")
+        gw1 = gw2 = None
+        if not _inputs_only():
+            gw1, _ = _wgrad(g1, t, False)
+            gw2, _ = _wgrad(g2, u1, False)
+        # act'' = 0: nothing reaches the forward's activations or z
+        return u2.view(ctx.gshape), None, None, None, gw1, gw2, None, None, None
+
+
+def node_embed_supported(z, l1, l2, act_name) -> bool:
+    return (z.is_cuda and z.dtype == torch.float32 and act_name in _HEAD_ACTS and 1 <= z.shape[-1] <= 16
+            and tuple(l1.weight.shape) == (64, z.shape[-1]) and tuple(l2.weight.shape) == (128, 64)
+            and l1.bias is not None and l2.bias is not None and l1.weight.dtype == torch.float32
+            and os.environ.get("DG_NODE_EMBED", "fused") != "off")
+
+
+def node_embed(z, l1, l2, act_name):
+    """act(Linear(64, 128)(act(Linear(E, 64)(z)))) over the last dimension of ``z``: float32 [..., 128]."""
+    return _NodeEmbed.apply(z, l1.weight, l1.bias, l2.weight, l2.bias, _HEAD_ACTS[act_name])
+
+
 def _head_launch(fn, name, *args):
     _lib.check(fn(*args), name)
 

@@ -36,6 +36,8 @@ class _Trunk(nn.Module):
     def _embed(self, seq, z):
         """Linear(in,64) - act - Linear(64,dim) - act - Dropout (models.py:52-61); the
         second Linear's weight gradient (64 -> dim over all edge rows) uses dg_linear_wgrad."""
+        if (not (self.training and self.dropout > 0.0)) and dgf.node_embed_supported(z, seq[0], seq[2], self._act_name):
+            return dgf.node_embed(z, seq[0], seq[2], self._act_name)      # both layers: one launch per direction
         h = self._act(dgf.linear(z, seq[0].weight, seq[0].bias))
         h = self._act(dgf.linear(h, seq[2].weight, seq[2].bias))
         return seq[4](h)

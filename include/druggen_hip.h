@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 221            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail */
+#define DG_VERSION 222            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail, node embedding */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -482,6 +482,20 @@ int dg_head_bwd(const float* g_out, const float* a1, const float* a2, const floa
                 const float* w4, float* g3, float* g2, float* g1, int64_t R, int act, dg_stream_t stream);
 int dg_head_wgrad(const float* l4, const float* r4, const float* l3, const float* r3, const float* l2, const float* r2,
                   float* dw4, float* db4, float* dw3, float* db3, float* dw2, float* db2, int64_t R, dg_stream_t stream);
+
+/* Node embedding (reference models.py:52-56, 154-158: node_layers = Linear(E, 64) - act - Linear(64, 128) - act - Dropout,
+ * applied at :91 / :196) over the R = B N node rows, float32, E <= 16; act: 0 ReLU, 1 LeakyReLU(0.01).
+ *   dg_embed_node_chain, m1 = m2 = NULL: o1 = act(in W1^T + b1) [R,64], o2 = act(o1 W2^T + b2) [R,128] in one launch.
+ *   dg_embed_node_chain, m1 / m2 = the forward's o1 / o2, `in` = t [R,E]: the gradient penalty's second order --
+ *     o1 = (t W1^T) . act'(m1), o2 = (o1 W2^T) . act'(m2) (biases unused): with t the adjoint of dg_embed_node_bwd's dz, o2 is
+ *     the adjoint of its upstream gradient g, and g1^T t, g2^T o1 (dg_linear_wgrad) are the adjoints of W1, W2.
+ *   dg_embed_node_bwd: g2 = g . act'(a2) [R,128], g1 = (g2 W2) . act'(a1) [R,64], dz = g1 W1 [R,E] (dz may be NULL).
+ *     The parameter gradients are dg_linear_wgrad(g2, a1) and dg_linear_wgrad(g1, z).                               */
+int dg_embed_node_chain(const float* in, const float* m1, const float* m2, const float* w1, const float* b1,
+                        const float* w2, const float* b2, float* o1, float* o2, int64_t R, int E, int act,
+                        dg_stream_t stream);
+int dg_embed_node_bwd(const float* g, const float* a1, const float* a2, const float* w1, const float* w2, float* g2,
+                      float* g1, float* dz, int64_t R, int E, int act, dg_stream_t stream);
 
 /* dg_argmax_decode: reference inference.py:197-198 `torch.max(x, -1)[1]` on logits
  * [rows, E] -> uint8 labels [rows] (first maximum), so only bytes cross PCIe.      */

@@ -1231,3 +1231,46 @@ def test_discriminator_head_tail_all_orders(R, act):
     out2 = dgf.head_tail(zc, lay, act)
     got_again = torch.autograd.grad(out2, [zc] + params, w_out.cuda())
     assert torch.equal(out, out2) and all(torch.equal(a_, b_) for a_, b_ in zip(got, got_again))
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky"])
+@pytest.mark.parametrize("B,N,E", [(1, 1, 5), (3, 9, 5), (4, 45, 13), (130, 45, 13), (2, 33, 16)])
+def test_node_embedding_all_orders(B, N, E, act):
+    """dg_embed_node_chain / dg_embed_node_bwd (node_layers, reference models.py:52-56, 154-158) against
+    torch.nn.Sequential in float64: output, first-order gradients (input and the four parameters), and the
+    gradient-penalty pattern (a function of d out / d z differentiated with respect to the parameters)."""
+    import torch.nn as nn
+    from druggen_amd import functional as dgf
+    torch.manual_seed(11 + B + E)
+    mk = {"relu": nn.ReLU, "leaky": nn.LeakyReLU}[act]
+    l1, l2 = nn.Linear(E, 64), nn.Linear(64, 128)
+    ref = nn.Sequential(nn.Linear(E, 64), mk(), nn.Linear(64, 128), mk()).double()
+    for l, i in ((l1, 0), (l2, 2)):
+        ref[i].weight.data.copy_(l.weight.data.double())
+        ref[i].bias.data.copy_(l.bias.data.double())
+        l.cuda()
+    z = _gen((B, N, E), 700 + B).float()
+    up = _gen((B, N, 128), 701 + B).float()
+    zc, zd = z.cuda().requires_grad_(True), z.double().requires_grad_(True)
+    assert dgf.node_embed_supported(zc, l1, l2, act)
+    out, outd = dgf.node_embed(zc, l1, l2, act), ref(zd)
+    assert out.shape == (B, N, 128) and _rel(out.detach(), outd.detach()) < TOL
+    params = [l1.weight, l1.bias, l2.weight, l2.bias]
+    paramsd = [ref[0].weight, ref[0].bias, ref[2].weight, ref[2].bias]
+    got = torch.autograd.grad(out, [zc] + params, up.cuda(), retain_graph=True)
+    want = torch.autograd.grad(outd, [zd] + paramsd, up.double(), retain_graph=True)
+    for a_, b_ in zip(got, want):
+        assert _rel(a_, b_) < TOL
+    (gz,) = torch.autograd.grad(out, zc, up.cuda(), create_graph=True)
+    (gzd,) = torch.autograd.grad(outd, zd, up.double(), create_graph=True)
+    pen, pend = ((gz.norm(dim=-1) - 1) ** 2).mean(), ((gzd.norm(dim=-1) - 1) ** 2).mean()
+    assert abs(pen.item() - pend.item()) < 1e-4 * max(1.0, abs(pend.item()))
+    got2 = torch.autograd.grad(pen, [l1.weight, l2.weight])
+    want2 = torch.autograd.grad(pend, [ref[0].weight, ref[2].weight])
+    for a_, b_ in zip(got2, want2):
+        assert _rel(a_, b_) < 5e-5
+    out2 = dgf.node_embed(zc, l1, l2, act)
+    assert torch.equal(out, out2)
+    lib = _lib().load()
+    assert lib.dg_embed_node_chain(zc.data_ptr(), None, None, l1.weight.data_ptr(), None, l2.weight.data_ptr(), None,
+                                   out.data_ptr(), out.data_ptr(), 1, 17, 0, torch.cuda.current_stream().cuda_stream) != 0
