@@ -47,7 +47,7 @@ SIGNATURES = {
     "dg_attn_half_fwd": (c_int, [_P] * 14 + [c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "dg_attn_half_f32_fwd": (c_int, [_P] * 17 + [c_int, c_int, c_int, c_float, c_float, _P]),
     "dg_attn_half_f32_bwd1_workspace_bytes": (c_size_t, [c_int]),
-    "dg_attn_half_f32_bwd1": (c_int, [_P] * 18 + [_P, c_size_t, c_int, c_int, c_int, c_float, _P]),
+    "dg_attn_half_f32_bwd1": (c_int, [_P] * 19 + [_P, c_size_t, c_int, c_int, c_int, c_float, _P]),
     "dg_attn_half_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dg_attn_half_bwd": (c_int, [_P] * 16 + [_P, c_size_t, c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_ln_residual_fwd": (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_int, _P]),

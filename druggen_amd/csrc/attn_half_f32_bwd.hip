@@ -104,6 +104,7 @@ struct HalfBwdArgs {
     const float* d_o;     // [B,N,128]
     float* dz;            // [B,N,N,128]: LayerNorm input gradient
     float* de;            // [B,N,N,128]
+    float* ds;            // [B,N,N,128]: dz4 Woe, written only by the DS instance (a second order will differentiate this pass)
     float* dq;            // [B,N,128]
     float* dk;
     float* dv;
@@ -134,6 +135,7 @@ struct Cursor {
     }
 };
 
+template <bool DS>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kernel(const HalfBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -428,6 +430,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
             const float4 abar = A * inv;
             // pass 2: dsc, the k / v / q gradients, de
             float4 dqa = f4(0.f);
+            __amdgpu_buffer_rsrc_t rds;
+            if constexpr (DS) rds = __builtin_amdgcn_make_buffer_rsrc(a.ds + wh.g * N * 128, 0, rowbytes, 0x00020000);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 const int row = 16 * rb + n;
@@ -435,6 +439,9 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_bwd1_kerne
                 const float4 cs = ld4(tab + c0);
                 const float4 wss = make_float4(acc[rb][0] * (rs * cs.x), acc[rb][1] * (rs * cs.y), acc[rb][2] * (rs * cs.z),
                                                acc[rb][3] * (rs * cs.w));
+                if constexpr (DS)      // (rows past N fall outside the buffer range: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, wss), rds,
+                                                           static_cast<unsigned>(row * 512 + c0 * 4), 0, 0);
                 const float4 ev = *reinterpret_cast<const float4*>(te + rb * 8192);
                 const float4 p = pe[rb] * inv;
                 float4 ds = fma4(p, woi * vv[rb] - abar, wss);
@@ -481,8 +488,8 @@ extern "C" size_t dg_attn_half_f32_bwd1_workspace_bytes(int B) {
 /* First part of the float32 attention-half backward: see include/druggen_hip.h. */
 extern "C" int dg_attn_half_f32_bwd1(const float* dy2, const float* pre4, const float* mean4, const float* rstd4,
                                      const float* gamma4, const void* woe_dgrad_packed, const float* e, const float* q,
-                                     const float* k, const float* v, const float* d_o, float* dz4, float* de, float* dq,
-                                     float* dk, float* dv, float* dgamma4, float* dbeta4, void* workspace,
+                                     const float* k, const float* v, const float* d_o, float* dz4, float* ds, float* de,
+                                     float* dq, float* dk, float* dv, float* dgamma4, float* dbeta4, void* workspace,
                                      size_t workspace_bytes, int B, int N, int C, float alpha, dg_stream_t stream_) {
     if (!dy2 || !pre4 || !mean4 || !rstd4 || !gamma4 || !woe_dgrad_packed || !e || !q || !k || !v || !d_o || !dz4 || !de || !dq ||
         !dk || !dv || !workspace)
@@ -496,12 +503,17 @@ extern "C" int dg_attn_half_f32_bwd1(const float* dy2, const float* pre4, const 
     const int blocks = B < 256 ? B : 256;
     float* part = static_cast<float*>(workspace);
     HalfBwdArgs a{dy2, pre4, mean4, rstd4, gamma4, static_cast<const f16x8*>(woe_dgrad_packed), e, q, k, v, d_o,
-                  dz4, de, dq, dk, dv, (dgamma4 || dbeta4) ? part : nullptr, B, N, alpha};
+                  dz4, de, ds, dq, dk, dv, (dgamma4 || dbeta4) ? part : nullptr, B, N, alpha};
     {
         ProfScope prof(DG_K_ATTN_HALF_BWD, stream);
         note_forward(static_cast<int64_t>(B) * N * N);      // (dgamma / dbeta partial sums, dk / dv accumulation: fixed order)
-        DG_OPT_IN_LDS((&attn_half_f32_bwd1_kernel), kLds);
-        hipLaunchKernelGGL(attn_half_f32_bwd1_kernel, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+        if (ds) {
+            DG_OPT_IN_LDS((&attn_half_f32_bwd1_kernel<true>), kLds);
+            hipLaunchKernelGGL(attn_half_f32_bwd1_kernel<true>, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+        } else {
+            DG_OPT_IN_LDS((&attn_half_f32_bwd1_kernel<false>), kLds);
+            hipLaunchKernelGGL(attn_half_f32_bwd1_kernel<false>, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+        }
     }
     // inside dg_linear_wgrad_batch_begin / _end the reduction joins that batch's single launch (dgamma4 and dbeta4 adjacent)
     if ((dgamma4 || dbeta4) &&

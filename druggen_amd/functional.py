@@ -1783,13 +1783,14 @@ def attn_half_f32_supported(yf, N: int, C: int) -> bool:
             and os.environ.get("DG_ATTN_HALF_F32", "fused") != "off")
 
 
-def attn_half_f32_bwd1_supported(dy2f, B: int, N: int, C: int) -> bool:
+def attn_half_f32_bwd1_supported(dy2f, B: int, N: int, C: int, graph: bool = False) -> bool:
     """dg_attn_half_f32_bwd1 (ln4 backward + out_e input gradient + attention-core backward as one float32 launch) serves
     C = 128 and row groups of at most 48 neighbours; its workgroups walk whole molecules, so it needs a batch that fills the
-    chip (B >= 128; DG_ATTN_HALF_F32_BWD=force lifts that for tests, =off keeps the two launches)."""
+    chip (B >= 128; DG_ATTN_HALF_F32_BWD=force lifts that for tests, =off keeps the two launches, =nograph keeps them only
+    for passes a second order differentiates)."""
     mode = os.environ.get("DG_ATTN_HALF_F32_BWD", "fused")
     return (dy2f.is_cuda and dy2f.dtype == torch.float32 and C == 128 and N <= 48 and _h3_row_gemm() and mode != "off"
-            and (B >= 128 or mode == "force"))
+            and (B >= 128 or mode == "force") and (not graph or mode != "nograph"))
 
 
 class _AttnBlock(Function):
@@ -1989,24 +1990,25 @@ class _AttnBlockBwd(Function):
         fused1 = None
         if need_edge:
             dy2f = _c(cast(dy2)).reshape(-1, C)
-            if (add4 is None and all(t is None for t in (aq, ak, av, ae)) and no_graph
-                    and attn_half_f32_bwd1_supported(dy2f, B, N, C)):
-                # ln4 backward + ds = dz4 Woe + the attention core's backward: one launch, ds never reaches HBM (no graph is being
-                # recorded: the second order would need ds)
+            if (add4 is None and all(t is None for t in (aq, ak, av, ae))
+                    and attn_half_f32_bwd1_supported(dy2f, B, N, C, graph=not no_graph)):
+                # ln4 backward + ds = dz4 Woe + the attention core's backward: one launch; ds stays on chip unless a graph is
+                # being recorded (the penalty's first backward: its second order reads ds)
                 lib = _lib.load()
                 dev = dy2f.device
                 dz4, de = torch.empty_like(dy2f), torch.empty_like(dy2f)
+                ds = None if no_graph else torch.empty_like(dy2f).view(B, N, N, C)
                 dq, dk, dv = (torch.empty(B, N, C, dtype=adt, device=dev) for _ in range(3))
                 dg4, db4 = (torch.empty(2, C, dtype=torch.float32, device=dev).unbind(0) if want_aff else (None, None))
                 with _dev(dy2f):
                     ws = _scratch(dy2f, int(lib.dg_attn_half_f32_bwd1_workspace_bytes(B)), "ahb_batch" if inb else "ahb")
                     _lib.check(lib.dg_attn_half_f32_bwd1(_lib.ptr(dy2f), _lib.ptr(pre4), _lib.ptr(mean4), _lib.ptr(rstd4),
                                                          _lib.fptr(_c(g4)), pw(woe, 1).data_ptr(), _lib.ptr(ev), _lib.ptr(qv),
-                                                         _lib.ptr(kv), _lib.ptr(vv), _lib.ptr(do), _lib.ptr(dz4), _lib.ptr(de),
+                                                         _lib.ptr(kv), _lib.ptr(vv), _lib.ptr(do), _lib.ptr(dz4), _lib.ptr(ds), _lib.ptr(de),
                                                          _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(dg4), _lib.ptr(db4),
                                                          ws.data_ptr(), ws.numel(), B, N, C, alpha, _lib.stream_of(dy2f)),
                                "dg_attn_half_f32_bwd1")
-                _account("attn_half_bwd", 4 * (dy2f.shape[0] * C * 5 + 7 * B * N * C), 2 * dy2f.shape[0] * C * C)
+                _account("attn_half_bwd", 4 * (dy2f.shape[0] * C * (5 if ds is None else 6) + 7 * B * N * C), 2 * dy2f.shape[0] * C * C)
                 de = de.view(B, N, N, C)
                 fused1 = (dq, dk, dv, de)
             elif add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):

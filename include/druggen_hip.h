@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 222            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail, node embedding */
+#define DG_VERSION 223            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail, node embedding */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
@@ -122,13 +122,14 @@ int dg_attn_half_f32_fwd(const float* y, const float* q, const float* k, const f
  * The second part is dy = de We + dz4: dg_row_gemm (residual epilogue) or dg_row_gemm_ln_bwd.  woe_dgrad_packed:
  * dg_row_gemm_pack(out_e.weight, 128, 128, mode 1).  C == 128, N <= 48; a workgroup walks whole molecules (dk / dv are summed
  * over i in registers, fixed order), so fewer than ~128 molecules leave compute units idle: small batches take
- * dg_row_gemm_ln_bwd_in + dg_attn_core_bwd.  workspace >= dg_attn_half_f32_bwd1_workspace_bytes(B).                    */
+ * dg_row_gemm_ln_bwd_in + dg_attn_core_bwd.  workspace >= dg_attn_half_f32_bwd1_workspace_bytes(B).  ds: NULL, or [B,N,N,128]
+ * to ALSO write ds (a pass that a second order differentiates -- the gradient penalty's first backward -- saves it).      */
 size_t dg_attn_half_f32_bwd1_workspace_bytes(int B);
 int dg_attn_half_f32_bwd1(const float* dy2, const float* pre4, const float* mean4, const float* rstd4, const float* gamma4,
                           const void* woe_dgrad_packed, const float* e, const float* q, const float* k, const float* v,
-                          const float* d_o, float* dz4, float* de, float* dq, float* dk, float* dv, float* dgamma4,
-                          float* dbeta4, void* workspace, size_t workspace_bytes, int B, int N, int C, float alpha,
-                          dg_stream_t stream);
+                          const float* d_o, float* dz4, float* ds, float* de, float* dq, float* dk, float* dv,
+                          float* dgamma4, float* dbeta4, void* workspace, size_t workspace_bytes, int B, int N, int C,
+                          float alpha, dg_stream_t stream);
 
 /* Backward of dg_attn_half_fwd given dz4 = d loss / d (y + s Woe^T + boe) -- the ln4 backward (dg_ln_residual_bwd on
  * pre4, mean4, rstd4) runs first and also yields dgamma4 / dbeta4 -- and d_o = d loss / d o.  e, s, p are recomputed

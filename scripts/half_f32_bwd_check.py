@@ -26,9 +26,11 @@ for (B, N) in ((2, 9), (3, 45), (5, 48), (64, 45), (256, 45), (512, 45)):
     dq, dk, dv = (torch.empty(B, N, C, device=dev) for _ in range(3))
     dgb = torch.empty(2, C, device=dev)
     ws = torch.empty(int(lib.dg_attn_half_f32_bwd1_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+    ds_out = torch.empty(R, C, device=dev)
+    DS = None
     def fused():
         _lib.check(lib.dg_attn_half_f32_bwd1(dy2.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g4.data_ptr(), pwo.data_ptr(),
-                                             e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(), dz.data_ptr(), de.data_ptr(),
+                                             e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(), dz.data_ptr(), DS, de.data_ptr(),
                                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                                              ws.numel(), B, N, C, alpha, torch.cuda.current_stream().cuda_stream), "bwd1")
     fused(); torch.cuda.synchronize()
@@ -39,4 +41,7 @@ for (B, N) in ((2, 9), (3, 45), (5, 48), (64, 45), (256, 45), (512, 45)):
         def two():
             a_, b_, _, _ = dgf.ln_bwd_row_gemm(pre, g4, mean, rstd, dy2, pwo, want_affine=True)
             dgf._attn_bwd_launch(q, k, v, e, b_.view(B, N, N, C), d_o, alpha)
-        print(f"   B = {B}: fused {timeit(fused):7.1f} us   two launches {timeit(two):7.1f} us")
+        t_plain = timeit(fused)
+        DS = ds_out.data_ptr()
+        print(f"   B = {B}: fused {t_plain:7.1f} us   fused + ds output {timeit(fused):7.1f} us   two launches {timeit(two):7.1f} us")
+        DS = None

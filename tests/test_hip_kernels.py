@@ -412,13 +412,14 @@ def test_fused_float32_attention_half_backward_part1(B, N):
     st = torch.cuda.current_stream().cuda_stream
     ws = torch.empty(int(lib.dg_attn_half_f32_bwd1_workspace_bytes(B)), dtype=torch.uint8, device="cuda")
 
-    def run():
+    def run(ds=None):
         dz, de = (torch.full((R, C), float("nan"), device="cuda") for _ in range(2))
         dq, dk, dv = (torch.full((B, N, C), float("nan"), device="cuda") for _ in range(3))
         dgb = torch.full((2, C), float("nan"), device="cuda")
         _lib().check(lib.dg_attn_half_f32_bwd1(dy2.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g4.data_ptr(),
                                                pwo.data_ptr(), e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                               d_o.data_ptr(), dz.data_ptr(), de.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                               d_o.data_ptr(), dz.data_ptr(), None if ds is None else ds.data_ptr(),
+                                               de.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                                dv.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(),
                                                B, N, C, alpha, st), "dg_attn_half_f32_bwd1")
         return dz, de, dq, dk, dv, dgb[0], dgb[1]
@@ -446,9 +447,14 @@ def test_fused_float32_attention_half_backward_part1(B, N):
     for _ in range(2):
         for a_, b_ in zip(got, run()):
             assert torch.equal(a_, b_)
+    # the instance that also writes ds (a pass whose second order will read it): same results, ds = dz4 Woe
+    ds = torch.full((R, C), float("nan"), device="cuda")
+    for a_, b_ in zip(got, run(ds)):
+        assert torch.equal(a_, b_)
+    assert _rel(ds, want[0] @ wd) < TOL and _rel(ds, ds_r.double().cpu()) < 5e-6
     assert lib.dg_attn_half_f32_bwd1(dy2.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g4.data_ptr(),
                                      pwo.data_ptr(), e.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), d_o.data_ptr(),
-                                     got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
+                                     got[0].data_ptr(), None, got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
                                      got[4].data_ptr(), got[5].data_ptr(), got[6].data_ptr(), ws.data_ptr(), 16, B, N, C,
                                      alpha, st) != 0      # workspace too small
 
