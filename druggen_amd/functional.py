@@ -2027,9 +2027,11 @@ class _AttnBlockBwd(Function):
         fold = ae is not None and adt == torch.float32 and os.environ.get("DG_ATTN_ADD", "kernel") != "post"
         aef = _c(cast(ae)).view(B, N, N, C) if fold else None      # joins de inside the kernel
         dq, dk, dv, de = fused1 if fused1 is not None else _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha, add_e=aef)
-        for got, extra in ((dq, aq), (dk, ak), (dv, av), (de, None if fold else ae)):
-            if extra is not None:
-                got.add_(extra.view(got.shape))
+        pairs = [(got, extra.view(got.shape)) for got, extra in ((dq, aq), (dk, ak), (dv, av)) if extra is not None]
+        if pairs:      # the node-level adjoints of q, k, v (second pass of the penalty): one multi-tensor launch
+            torch._foreach_add_([g_ for g_, _ in pairs], [e_ if e_.dtype == g_.dtype else e_.to(g_.dtype) for g_, e_ in pairs])
+        if ae is not None and not fold:
+            de.add_(ae.view(de.shape))
         ctx.third = any(t is not None for t in (add3, add4, aq, ak, av, ae))
         dqf, dkf, dvf, def_ = dq.view(-1, C), dk.view(-1, C), dv.view(-1, C), de.view(-1, C)
         dy = dx1 = dzp = dgp = dbp = None

@@ -31,7 +31,7 @@ stepper = GANStep(G, D, lambda_gp=10.0)
 for _ in range(2):
     stepper.step(*batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     stepper.step(*batch)
     torch.cuda.synchronize()
 agg = collections.Counter()
@@ -51,7 +51,7 @@ for ev in prof.events():
             node = p.name.replace("autograd::engine::evaluate_function: ", "")
             break
         p = p.cpu_parent
-    agg[(ev.name, site, node)] += 1
+    agg[(ev.name, site or str(getattr(ev, 'input_shapes', ''))[:60], node)] += 1
 print(f"# leaf ATen ops with device time in one step (B = {B}): {sum(agg.values())}")
 for (name, site, node), n in agg.most_common(70):
     print(f"{n:5d}  {name:30s} {site:50s} {node}")
