@@ -212,32 +212,44 @@ class _LNResidual(Function):
                                               _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), R, C, eps,
                                               _lib.dt(a), _lib.stream_of(a)), "dg_ln_residual_fwd")
         _account("ln_fwd", a.element_size() * R * C * (3 if r is not None else 2))
+        # the penalty's forward (r is None: ln1): the input leaves as an alias output, so that the second-order adjoint of
+        # the input comes back to THIS node and joins dz inside the backward kernel (dz_add) instead of an engine add
+        ctx.alias = bool(r is None and ctx.needs_input_grad[0] and in_second_order_forward() and _alias_outputs_enabled())
+        if ctx.alias:
+            a = a.view_as(a)
         ctx.save_for_backward(a, r, gamma, mean, rstd)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, a) if ctx.alias else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, ga=None):
         a, r, gamma, mean, rstd = ctx.saved_tensors
-        dz, dgamma, dbeta = _LNResidualBwd.apply(a, r, gamma, mean, rstd, dy)
+        want_aff = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and not _inputs_only()
+        if dy is None:
+            dy = torch.zeros_like(a)
+        dz, dgamma, dbeta = _LNResidualBwd.apply(a, r, gamma, mean, rstd, dy, want_aff, ga)
         return dz, (dz if r is not None else None), dgamma, dbeta, None
 
 
 class _LNResidualBwd(Function):
     @staticmethod
-    def forward(ctx, a, r, gamma, mean, rstd, dy):
+    def forward(ctx, a, r, gamma, mean, rstd, dy, want_aff=True, dz_add=None):
         dy = _c(dy if dy.dtype == a.dtype else dy.to(a.dtype))
+        if dz_add is not None:
+            dz_add = _c(dz_add if dz_add.dtype == a.dtype else dz_add.to(a.dtype))
         C = a.shape[-1]
         R = a.numel() // C
         lib = _lib.load()
         dz = torch.empty_like(a)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dgamma, dbeta = (torch.empty_like(gamma), torch.empty_like(gamma)) if want_aff else (None, None)
         with _dev(a):
             ws, need = _workspace(a, R, C)
-            _lib.check(lib.dg_ln_residual_bwd(_lib.ptr(a), _lib.ptr(r), _lib.fptr(_c(gamma)), _lib.ptr(mean),
-                                              _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(dz), _lib.ptr(dgamma),
-                                              _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, C, _lib.dt(a),
-                                              _lib.stream_of(a)), "dg_ln_residual_bwd")
-        _account("ln_bwd", a.element_size() * R * C * (4 if r is not None else 3))
+            _lib.check(lib.dg_ln_residual_bwd_add(_lib.ptr(a), _lib.ptr(r), _lib.fptr(_c(gamma)), _lib.ptr(mean),
+                                                  _lib.ptr(rstd), _lib.ptr(dy), _lib.ptr(dz_add), _lib.ptr(dz), _lib.ptr(dgamma),
+                                                  _lib.ptr(dbeta), ws.data_ptr(), ws.numel(), R, C, _lib.dt(a),
+                                                  _lib.stream_of(a)), "dg_ln_residual_bwd")
+        _account("ln_bwd", a.element_size() * R * C * ((4 if r is not None else 3) + (dz_add is not None)))
+        ctx.third = dz_add is not None
         ctx.save_for_backward(a, r, gamma, mean, rstd, dy)
         ctx.set_materialize_grads(False)
         return dz, dgamma, dbeta
@@ -251,7 +263,9 @@ class _LNResidualBwd(Function):
             # the WGAN-GP path differentiates the input gradient only (loss.py:32-39)
             raise RuntimeError("ln_residual: second-order terms through dgamma/dbeta are not implemented")
         if tz is None:
-            return None, None, None, None, None, None
+            return (None,) * 8
+        if ctx.third:
+            raise RuntimeError("ln_residual: third-order differentiation is not implemented")
         tz = _c(tz)
         C = a.shape[-1]
         R = a.numel() // C
@@ -265,12 +279,13 @@ class _LNResidualBwd(Function):
                                                _lib.ptr(gdy), _lib.ptr(ggamma), ws.data_ptr(), ws.numel(), R, C,
                                                _lib.dt(a), _lib.stream_of(a)), "dg_ln_residual_bwd2")
         _account("ln_bwd2", a.element_size() * R * C * (6 if r is not None else 5))
-        return gz, (gz if r is not None else None), ggamma, None, None, gdy
+        return gz, (gz if r is not None else None), ggamma, None, None, gdy, None, None
 
 
 def ln_residual(a, r, gamma, beta, eps: float = 1e-5):
     """LayerNorm(a + r) * gamma + beta over the last dim; ``r`` may be None."""
-    return _LNResidual.apply(a, r, gamma, beta, float(eps))
+    out = _LNResidual.apply(a, r, gamma, beta, float(eps))
+    return out[0] if isinstance(out, tuple) else out
 
 
 # --------------------------------------------------------------------------
@@ -841,7 +856,8 @@ def _canon(w):
     caches are keyed by the parameter object."""
     r = _alias_canon.get(w.data_ptr())
     o = r() if r is not None else None
-    if o is not None and o is not w and o.shape == w.shape and o._version == w._version and o.dtype == w.dtype:
+    if (o is not None and o is not w and o.data_ptr() == w.data_ptr() and o.shape == w.shape and o.stride() == w.stride()
+            and o._version == w._version and o.dtype == w.dtype):
         return o
     return w
 
