@@ -16,6 +16,7 @@
 #include "traversal.h"
 
 namespace dg {
+void launch_ln_finish(const float* part, int nblocks, int K, int C, float* out0, float* out1, hipStream_t stream);      // layernorm.hip
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -686,25 +687,40 @@ __global__ __launch_bounds__(256, 2) void embed_sym_bwd2_kernel(
     }
 }
 
-// out[i] = sum_s part[s][i] (fixed order)
-__global__ __launch_bounds__(256) void embed_reduce_kernel(const float* __restrict__ part, int S, int n,
-                                                         float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// Column sums of the partial vectors [dW2 | db2 | dW1(16-padded) | db1] of the backward kernels, written straight into the
+// caller's tensors: one block per 32 elements, 32 row groups stride over the S partials with eight loads in flight, then a
+// fixed-order LDS sum (bit-reproducible).  (One thread per element walking all S partials was 33 us of dependent loads; a
+// separate scatter launch followed.)
+__global__ __launch_bounds__(1024) void embed_finish_kernel(const float* __restrict__ part, int S, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, int E) {
+    __shared__ float red[32][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int g = threadIdx.x >> 5;
     float s = 0.f;
-#pragma unroll 8
-    for (int p = 0; p < S; ++p) s += part[static_cast<size_t>(p) * n + i];
-    out[i] = s;
-}
-
-// scatter the reduced [dW2 | db2 | dW1(16-padded) | db1] vector into the caller's tensors
-__global__ void embed_unpack_kernel(const float* __restrict__ red, float* __restrict__ dw1, float* __restrict__ db1,
-                                    float* __restrict__ dw2, float* __restrict__ db2, int E) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < kC * kHid) dw2[i] = red[BwdPart::kW2 + i];
-    if (db2 && i < kC) db2[i] = red[BwdPart::kB2 + i];
-    if (i < kHid * E) dw1[i] = red[BwdPart::kW1 + (i / E) * kMaxE + (i % E)];
-    if (db1 && i < kHid) db1[i] = red[BwdPart::kB1 + i];
+    if (c < BwdPart::kTotal) {
+        const float* src = part + c;
+        int b = g;
+        for (; b + 7 * 32 < S; b += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(b + 32 * u) * BwdPart::kTotal];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; b < S; b += 32) s += src[static_cast<size_t>(b) * BwdPart::kTotal];
+    }
+    red[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && c < BwdPart::kTotal) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+        if (c >= BwdPart::kW2 && c < BwdPart::kW2 + kC * kHid) dw2[c - BwdPart::kW2] = t;
+        else if (c >= BwdPart::kB2 && c < BwdPart::kB2 + kC) { if (db2) db2[c - BwdPart::kB2] = t; }
+        else if (c >= BwdPart::kW1 && c < BwdPart::kW1 + kHid * kMaxE) {
+            const int i = c - BwdPart::kW1;
+            if (i % kMaxE < E) dw1[(i / kMaxE) * E + i % kMaxE] = t;
+        } else if (c >= BwdPart::kB1 && c < BwdPart::kB1 + kHid) { if (db1) db1[c - BwdPart::kB1] = t; }
+    }
 }
 
 // ---------------------------------------------------------------- one-hot inputs ----
@@ -850,7 +866,6 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
-    float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kD1Pitch + 64 * kMaxE + kHid * 16) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
     note_forward(static_cast<int64_t>(B) * N * N);
@@ -879,10 +894,8 @@ extern "C" int dg_embed_sym_bwd(const float* a, const float* w1, const float* b1
 #undef BWD_A
 #undef BWD_D
 #undef BWD
-    hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
-                       BwdPart::kTotal, red);
-    hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, dw1, db1, dw2, db2,
-                       E);
+    hipLaunchKernelGGL(embed_finish_kernel, dim3((BwdPart::kTotal + 31) / 32), dim3(1024), 0, stream, part, grid, dw1, db1, dw2,
+                       db2, E);
     return check_launch("dg_embed_sym_bwd");
 }
 
@@ -903,7 +916,6 @@ extern "C" int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b
     const int tpm = (N * (N + 1) / 2 + kPairs - 1) / kPairs;
     const int grid = embed_grid(B * tpm, kBwdPerCu);
     float* part = static_cast<float*>(workspace);
-    float* red = part + static_cast<size_t>(grid) * BwdPart::kTotal;
     constexpr int lds_bytes = (64 * kHid + 64 * kC + 64 * kHid + 2 * 64 * kMaxE + kPairs * kC) * 4 + kPairs * 2 * 4;
     ProfScope prof(DG_K_EMBED_SYM, stream);
     note_forward(static_cast<int64_t>(B) * N * N);
@@ -923,9 +935,7 @@ extern "C" int dg_embed_sym_bwd2(const float* a, const float* w1, const float* b
     }
 #undef BWD2
 #undef BWD2_A
-    hipLaunchKernelGGL(embed_reduce_kernel, dim3((BwdPart::kTotal + 255) / 256), dim3(256), 0, stream, part, grid,
-                       BwdPart::kTotal, red);
-    hipLaunchKernelGGL(embed_unpack_kernel, dim3((kC * kHid + 255) / 256), dim3(256), 0, stream, red, gw1,
+    hipLaunchKernelGGL(embed_finish_kernel, dim3((BwdPart::kTotal + 31) / 32), dim3(1024), 0, stream, part, grid, gw1,
                        static_cast<float*>(nullptr), gw2, static_cast<float*>(nullptr), E);
     return check_launch("dg_embed_sym_bwd2");
 }
@@ -977,6 +987,6 @@ extern "C" int dg_onehot_embed_bwd(const int* labels, const void* g, float* dtab
         if (E <= 8) { BWD(float, 8) } else { BWD(float, 16) }
     }
 #undef BWD
-    hipLaunchKernelGGL(embed_reduce_kernel, dim3((E * C + 255) / 256), dim3(256), 0, stream, part, grid, E * C, dtable);
+    launch_ln_finish(part, grid, 1, E * C, dtable, nullptr, stream);      // column sums of the [grid][E C] partials, fixed order
     return check_launch("dg_onehot_embed_bwd");
 }

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 namespace dg {
+void launch_ln_finish(const float* part, int nblocks, int K, int C, float* out0, float* out1, hipStream_t stream);      // layernorm.hip
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -615,17 +616,6 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const TY* __restrict_
     }
 }
 
-// generic fixed-order reduce for the skinny path (element granularity, any count)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S, int64_t n,
-                                                            float* __restrict__ out) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-#pragma unroll 8
-    for (int p = 0; p < S; ++p) s += part[static_cast<size_t>(p) * n + i];
-    out[i] = s;
-}
-
 constexpr int kSkinnyBlocks = 512;
 
 bool skinny_ok(int N, int K) { return N >= 1 && N <= 16 && K >= 4 && K % 4 == 0 && K <= 1024 && 256 % (K / 4) == 0; }
@@ -775,9 +765,10 @@ static int skinny_wgrad(const void* dy_, bool dy_f32, const void* x_, bool x_bf,
 #undef SKINNY_N
 #undef SKINNY
     const int64_t nw = static_cast<int64_t>(N) * K;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + 255) / 256)), dim3(256), 0, stream,
-                       part_w, S, nw, dw);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part_b, S, static_cast<int64_t>(N), db);
+    // column sums of the [S][N K] / [S][N] partials: 32 row groups per column block, fixed order (one thread per element walking
+    // all S partials was 14 us of dependent loads)
+    launch_ln_finish(part_w, S, 1, static_cast<int>(nw), dw, nullptr, stream);
+    if (db) launch_ln_finish(part_b, S, 1, N, db, nullptr, stream);
     return check_launch("dg_linear_wgrad(skinny)");
 }
 
