@@ -13,15 +13,18 @@ mlp_ratio 3), N=45 atoms, E=5 bond classes, M=13 atom classes, batch 256 per GPU
 fp32.  Multi-GPU: one process per GPU, the batch is sharded (weak scaling: 256
 molecules per rank), gradients averaged with one RCCL all-reduce per backward.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+Rank 0 prints ONE JSON line of < 6 KB.  Besides the contract fields it carries
   roofline      the time-dominant edge-level kernel of the step (chosen by
                 measurement: one instrumented step before the timed region ranks
                 them): algorithmic bytes / HIP-event time measured during the timed
-                steps, against the 8 TB/s HBM3E peak (+ its MFMA-side fraction);
+                steps, against the 8 TB/s HBM3E peak (+ its MFMA-side fraction, its
+                kernel symbol, and the same rate against the section-8d FLOOR bytes:
+                inputs + outputs only, nothing saved for a backward);
   roofline_attention  the same for the attention kernel north_star names;
-  kernels       the same figure for every profiled HIP kernel;
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on the
                 host cores on a bounded sample of the same workload.
+The per-kernel table of every profiled HIP kernel (`kernels`, `roofline_all`) goes to
+profiles/bench_detail_<config>_<dtype>.json (and gpurun_out/ when that exists), not to stdout.
 """
 from __future__ import annotations
 
@@ -114,24 +117,21 @@ def cpu_baseline(workload, batch: int, threads: int = 0):
     c1 = dict(WORKLOAD, vertexes=9, nodes=5, depth=1)
     ref_threads = threads or min(5, logical)
     variants = []
-    for name, wl, b, thr, n, budget in (("bench workload shape", workload, batch, ref_threads, 5, 60.0),
-                                        ("bench workload shape", workload, batch, min(physical, 64), 2, 15.0),
-                                        ("BASELINE configs[0] (N=9, L=1)", c1, 32, ref_threads, 5, 10.0),
-                                        ("BASELINE configs[0] (N=9, L=1)", c1, 32, min(physical, 64), 5, 10.0)):
+    for name, wl, b, thr, n, budget in (("bench", workload, batch, ref_threads, 5, 60.0),
+                                        ("bench", workload, batch, min(physical, 64), 5, 90.0),
+                                        ("c1", c1, 32, ref_threads, 5, 10.0),
+                                        ("c1", c1, 32, min(physical, 64), 5, 10.0)):
         rate, steps = _cpu_gan_step_rate(wl, b, thr, n, budget)
         variants.append({"workload": name, "batch": b, "threads": thr, "value": rate, "steps": steps,
                          "statistic": "median step time"})
     head = variants[0]
-    note = ""
-    if variants[1]["value"] < head["value"]:
-        note = (f"; the all-cores variant ({variants[1]['threads']} threads) is SLOWER than the reference's 5-thread setting at "
-                f"this size ({variants[1]['value']:.2f} vs {head['value']:.2f} molecules/s): the oracle's eager ops are too "
-                f"small to scale past a few cores")
     return {"value": head["value"], "unit": "molecules/s", "cores": head["threads"], "kind": "port",
-            "sample": f"oracle (torch CPU restatement of src/model) GAN step at the bench workload's shape, batch "
-                      f"{head['batch']}, median of {head['steps']} step(s) after 1 warm-up, {head['threads']} threads "
-                      f"(the reference's train.py:16 setting) of {logical} logical cores" + note,
-            "variants": variants, "logical_cores": logical}
+            "sample": f"oracle GAN step (torch CPU restatement of src/model + train.py:351-384) at the bench workload's "
+                      f"shape, batch {head['batch']}, median of {head['steps']} steps after 1 warm-up, {head['threads']} "
+                      f"threads (train.py:16) of {logical} logical cores",
+            # [workload, batch, threads, molecules/s, steps]; c1 = BASELINE configs[0] (N=9, L=1)
+            "variants": [[v["workload"], v["batch"], v["threads"], round(v["value"], 2), v["steps"]] for v in variants],
+            "logical_cores": logical}
 
 
 def secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w, batch=2048, steps=4, warmup=2):
@@ -158,10 +158,10 @@ def secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w, batch=2048, steps=4, 
         ok = all(bool(torch.isfinite(v)) for v in losses)
     finally:
         dgf.set_activation_dtype(prev)
-    return {"metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs", "value": batch * steps / dt, "unit": "molecules/s",
-            "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "dtype": "bf16", "batch_per_gpu": batch,
-            "config": "BASELINE configs[2]: same model, bf16 activations in HBM (fp32 parameters / optimizer / statistics), "
-                      "batch 2048, 1 GPU", "finite_losses": ok}
+    return {"value": batch * steps / dt, "unit": "molecules/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "warmup": warmup, "dtype": "bf16", "batch_per_gpu": batch, "finite_losses": ok,
+            "config": "BASELINE configs[2]: same model, bf16 activations in HBM, batch 2048, 1 GPU (a 1-2 % gradient-error "
+                      "configuration, README: never the headline)"}
 
 
 def main():
@@ -261,7 +261,7 @@ def main():
     _lib.prof_enable(False)
     n_ar, ms_ar = stepper.collective_ms() if world > 1 else (0, 0.0)      # the timed steps' all-reduces only
     stepper.time_collectives(False)
-    attn_stats = {k: (_lib.prof_read(k), dgf.traffic_bytes(k)) for k in attn_kernels}
+    attn_stats = {k: (_lib.prof_read(k), dgf.traffic_bytes(k), dgf.traffic_floor_bytes(k)) for k in attn_kernels}
     # per-kernel table of every HIP kernel: two extra, untimed, fully instrumented steps
     _lib.prof_reset()
     dgf.traffic_reset()
@@ -287,8 +287,8 @@ def main():
         dist.all_gather(gathered, mine)
         per_rank = [float(g.item()) for g in gathered]
         allreduce = {"per_rank_ms_per_step": per_rank, "max_ms_per_step": max(per_rank), "collectives_per_step": n_ar / max(1, args.steps),
-                     "backend": backend, "what": "HIP events around the D-gradient and the G-gradient flat-bucket all-reduce "
-                                                 "(6.3 MB + 4.9 MB fp32) of every timed step"}
+                     "backend": backend, "what": "HIP events around the D- and G-gradient flat-bucket all-reduces (6.3 + 4.9 MB fp32) of "
+                                                 "every timed step" + ("; gloo: host-side copy time, not a device collective" if backend != "nccl" else "")}
         sums = torch.stack([p.detach().double().sum() for p in list(G.parameters()) + list(D.parameters())] +
                            [p.detach().double().abs().sum() for p in list(G.parameters()) + list(D.parameters())])
         lo, hi = sums.clone(), sums.clone()
@@ -314,16 +314,19 @@ def main():
                      "into fp16, fp32 accumulate: fp32-class accuracy, tests/test_hip_kernels.py)" if split
                      else "v_mfma_f32_32x32x2_f32"))
         kernels = {}
-        step_bytes = 0.0
+        step_bytes = step_floor = 0.0
         for name in _lib.KERNEL_IDS:
             n, ms = _lib.prof_read(name)
             nbytes = dgf.traffic_bytes(name)
+            floor = dgf.traffic_floor_bytes(name)
             step_bytes += float(nbytes)
+            step_floor += float(floor)
             if n:
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 kernels[name] = {"launches_per_step": n / detail_steps, "avg_us": 1e3 * ms / n,
-                                 "algorithmic_MB_per_launch": nbytes / n / 1e6,
+                                 "algorithmic_MB_per_launch": nbytes / n / 1e6, "floor_MB_per_launch": floor / n / 1e6,
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                                 "frac_of_floor": (floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0,
                                  "share_of_step": ms * 1e-3 / detail_elapsed}
                 fl = dgf.traffic_flops(name)
                 if fl:          # GEMM-shaped kernels: flop rate against the MFMA ceiling of their arithmetic
@@ -357,26 +360,44 @@ def main():
                   "ffn": "fused bf16 feed-forward (forward, dx), edge-level launches",
                   "ffn_wgrad": "fused bf16 feed-forward weight gradients, edge-level launches"}
 
+        # kernel symbols as rocprofv3 --kernel-trace prints them (profiles/*_kernel_stats.txt)
+        SYMBOLS = {"row_gemm_e128": "dg::row_gemm_h3_kernel<1,1,...> (plain / +LayerNorm / LayerNorm-backward variants)"
+                                    if not bf16 else "dg::row_gemm_bf16_kernel<1,1>",
+                   "row_gemm_e_n384": "dg::row_gemm_n384_kernel" if not bf16 else "dg::row_gemm_bf16_kernel<1,3>",
+                   "row_gemm_e_k384": "dg::row_gemm_k384_kernel<*>" if not bf16 else "dg::row_gemm_bf16_kernel<3,1>",
+                   "attn_fwd": "dg::attn_fwd_kernel", "attn_bwd": "dg::attn_bwd_kernel", "attn_bwd2": "dg::attn_bwd2_kernel",
+                   "attn_half_fwd": "dg::attn_half_fwd_kernel (bf16)" if bf16 else "dg::attn_half_f32_fwd_kernel",
+                   "attn_half_bwd": "dg::attn_half_bwd_kernel (bf16)" if bf16 else "dg::attn_half_f32_bwd1_kernel",
+                   "linear_wgrad_e128": "dg::wgrad_stream_kernel<4,4,*>" if not bf16 else "dg::wgrad_kernel<bf16,...>",
+                   "linear_wgrad_e_n384": "dg::wgrad_stream_kernel<12,4,*>" if not bf16 else "dg::wgrad_kernel<bf16,...>",
+                   "linear_wgrad_e_k384": "dg::wgrad_stream_kernel<4,12,*>" if not bf16 else "dg::wgrad_kernel<bf16,...>",
+                   "ffn": "dg::ffn_fwd_bf16_v2_kernel / dg::ffn_bwd_dx_bf16_kernel",
+                   "ffn_wgrad": "dg::ffn_bwd_dw2_bf16_kernel / dg::ffn_bwd_dw1_bf16_kernel"}
+
         def timed_block(name):
-            (n, ms), nbytes = attn_stats[name]
+            (n, ms), nbytes, floor = attn_stats[name]
             if not n or ms <= 0:
                 return None
             gbs = nbytes / (ms * 1e-3) / 1e9
-            blk = {"kernel": name, "what": SHAPES[name], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": n, "avg_us": 1e3 * ms / n,
-                   "algorithmic_bytes_per_launch": nbytes / n, "share_of_step": ms * 1e-3 / elapsed}
+            blk = {"kernel": name, "kernel_symbol": SYMBOLS.get(name, name), "what": SHAPES[name], "bound": "hbm",
+                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "launches_timed": n,
+                   "avg_us": 1e3 * ms / n, "algorithmic_bytes_per_launch": nbytes / n,
+                   # SURVEY 8d floor: inputs + outputs of the launch only -- nothing it saves for a backward pass
+                   "bytes_floor_per_launch": floor / n, "frac_of_floor": floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "share_of_step": ms * 1e-3 / elapsed}
             fl = kernels.get(name, {}).get("achieved_TFLOPs")
             if fl is not None:      # GEMM-shaped: report the MFMA side too and name the binding roof
                 kt = kernels[name]
                 blk.update({"frac_of_mfma_peak": kt["frac_of_mfma_peak"], "mfma_peak_TFLOPs": kt["mfma_peak_TFLOPs"],
-                            "achieved_TFLOPs": kt["achieved_TFLOPs"], "mfma": kt["mfma"]})
+                            "achieved_TFLOPs": kt["achieved_TFLOPs"]})
             return blk
 
         blocks = [b for b in (timed_block(k) for k in attn_kernels) if b]
         # every edge-level kernel from the two extra instrumented steps (not the timed region)
-        all_blocks = [dict(kernel=k, what=SHAPES.get(k, k), bound="hbm", achieved=v["achieved_GBps"], peak=HBM_PEAK_GBS,
-                           unit="GB/s", frac=v["frac_of_hbm_peak"], launches_timed=None, avg_us=v["avg_us"],
+        all_blocks = [dict(kernel=k, kernel_symbol=SYMBOLS.get(k, k), what=SHAPES.get(k, k), bound="hbm", achieved=v["achieved_GBps"],
+                           peak=HBM_PEAK_GBS, unit="GB/s", frac=v["frac_of_hbm_peak"], launches_timed=None, avg_us=v["avg_us"],
                            algorithmic_bytes_per_launch=v["algorithmic_MB_per_launch"] * 1e6,
+                           bytes_floor_per_launch=v["floor_MB_per_launch"] * 1e6, frac_of_floor=v["frac_of_floor"],
                            share_of_step=v["share_of_step"], measured="instrumented steps after the timed region")
                       for k, v in kernels.items() if k in SHAPES]
         if args.graph or not blocks:        # --graph: events cannot sit inside a replayed graph
@@ -387,8 +408,7 @@ def main():
             max(blocks, key=lambda b: b["share_of_step"]) if blocks else {})
         if dominant:
             dominant["is_time_dominant_edge_kernel"] = bool(top_all == dominant["kernel"])
-            dominant["chosen_by"] = ("largest total HIP-event time among the edge-level kernels in one instrumented step "
-                                     "before the timed region")
+            dominant["chosen_by"] = "largest total HIP-event time among the edge-level profiler keys in one instrumented step before the timed region"
         attention = next((b for b in blocks if b["kernel"] == attn_key), None)
         # HBM bytes per launch from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
         # scripts/pmc_traffic.py): only reported when the pass was taken on THIS workload, dtype and batch; the record
@@ -405,7 +425,7 @@ def main():
         for blk in blocks + [b for b in all_blocks if b not in blocks]:
             t = traffic_rec.get("kernels", {}).get(blk["kernel"])
             blk["traffic"] = None if not t else t["bytes_per_launch"]
-            blk["traffic_source"] = None if not t else {k: traffic_rec.get(k) for k in ("commit", "measured", "method")}
+            blk["traffic_commit"] = None if not t else traffic_rec.get("commit")
         out = {
             "metric": "molecules/sec GAN step (G+D fwd+bwd), N=45 graphs" if w["vertexes"] == 45 else
                       f"molecules/sec GAN step (G+D fwd+bwd), N={w['vertexes']} graphs",
@@ -421,27 +441,27 @@ def main():
                        "vertexes": w["vertexes"], "edges": w["edges"], "depth": w["depth"],
                        "hip_graph_replay": bool(args.graph and world == 1),
                        "gemm_arithmetic": gemm_how,
+                       "hidden_storage": dgf.hidden_storage() if hasattr(dgf, "hidden_storage") else "f32",
                        "activations": "bf16 in HBM; fp32 parameters, optimizer state, weight gradients, softmax and "
                                       "LayerNorm statistics" if bf16 else "fp32"},
             # the time-dominant kernel AND shape of the step (largest share of the timed region among the edge-level
-            # kernels), then the attention kernel north_star names, then every timed kernel
+            # kernels), then the attention kernel north_star names
             "roofline": dominant,
             "roofline_attention": attention,
-            "roofline_all": all_blocks,
             # the whole step against the HBM roof: algorithmic bytes of every HIP kernel launch of a step (the per-kernel
-            # formulas of DESIGN.md section 3, accumulated by functional._account) / wall time of the instrumented steps
+            # formulas of DESIGN.md section 3, accumulated by functional._account) / wall time of two fully instrumented
+            # steps after the timed region
             "step_hbm": {"algorithmic_GB_per_step": step_bytes / detail_steps / 1e9,
+                         "floor_GB_per_step": step_floor / detail_steps / 1e9,
                          "achieved_GBps": step_bytes / detail_elapsed / 1e9,
-                         "frac_of_hbm_peak": step_bytes / detail_elapsed / 1e9 / HBM_PEAK_GBS,
-                         "note": "two fully instrumented steps after the timed region (HIP events around every launch: "
-                                 "slightly slower than the timed steps)"},
-            "kernels": kernels,
+                         "frac_of_hbm_peak": step_bytes / detail_elapsed / 1e9 / HBM_PEAK_GBS},
             "losses": {"d_loss": d_loss, "g_loss": g_loss},
             "replicas_identical": replicas_identical,
             "allreduce": allreduce,
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
         }
+        detail = {"kernels": kernels, "roofline_all": all_blocks}
         if world == 1 and args.config == "c2" and act_dtype == "f32" and not args.no_extra and not args.graph:
             # the same step replayed from a captured hipGraph (trainer.GraphedGANStep; single GPU): reported beside the eager
             # headline, never as it -- the N > 1 lines of this benchmark run eagerly (the all-reduce is not captured)
@@ -462,7 +482,38 @@ def main():
             out["bf16_configs2"] = secondary_bf16_line(dev, G, D, synth, dgf, GANStep, w)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_batch, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+        # per-kernel detail: a file, not stdout (round 4's 21 KB line could not be parsed by the driver)
+        detail.update({k: out[k] for k in ("metric", "value", "ms_per_step", "dtype", "config")})
+        name = f"bench_detail_{args.config}_{act_dtype}" + ("" if B == cfg_batch else f"_b{B}") + ".json"
+        written = None
+        for d in (os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")):
+            try:
+                if os.path.isdir(d):
+                    with open(os.path.join(d, name), "w") as f:
+                        json.dump(detail, f, indent=1)
+                    written = written or os.path.relpath(os.path.join(d, name), ROOT)
+            except OSError:
+                pass
+        out["detail_file"] = written
+
+        def rnd(v):      # 6 significant digits: the line must stay under 6 KB
+            if isinstance(v, float):
+                return float(f"{v:.6g}")
+            if isinstance(v, dict):
+                return {k: rnd(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return [rnd(x) for x in v]
+            return v
+        line = json.dumps(rnd(out), separators=(",", ":"))
+        if len(line) >= 6144:      # never again an unparseable record: drop the optional blocks, largest first
+            for k in ("cpu_baseline", "bf16_configs2", "roofline_attention", "step_hbm"):
+                slim = dict(out)
+                slim[k] = {kk: vv for kk, vv in out[k].items() if kk in ("value", "unit", "cores", "kind", "frac", "kernel")} if isinstance(out.get(k), dict) else out.get(k)
+                out = slim
+                line = json.dumps(rnd(out), separators=(",", ":"))
+                if len(line) < 6144:
+                    break
+        print(line, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,6 +113,8 @@ SIGNATURES = {
     "dg_prof_enable": (c_int, [c_int]),
     "dg_prof_reset": (c_int, []),
     "dg_prof_read": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
+    "dg_set_edge_rows": (c_int, [c_int64]),
+    "dg_edge_rows": (c_int64, []),
 }
 
 KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd": 4, "ln_bwd2": 5, "linear_wgrad": 6, "row_gemm": 7, "embed_sym": 8, "ffn": 9, "ffn_wgrad": 10,
@@ -120,7 +122,23 @@ KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd
               "row_gemm_e128": 13, "row_gemm_e_n384": 14, "row_gemm_e_k384": 15,
               "linear_wgrad_e128": 16, "linear_wgrad_e_n384": 17, "linear_wgrad_e_k384": 18,
               "ffn_node": 19, "ffn_wgrad_node": 20}
-EDGE_ROWS = 65536        # DG_EDGE_ROWS of include/druggen_hip.h
+EDGE_ROWS = 65536        # DG_EDGE_ROWS of include/druggen_hip.h: the default of dg_set_edge_rows()
+_edge_rows = EDGE_ROWS
+
+
+def edge_rows() -> int:
+    """Row count from which a launch counts as edge-level (profiler / traffic keys, traversal direction)."""
+    return _edge_rows
+
+
+def set_edge_rows(rows: int = 0) -> None:
+    """dg_set_edge_rows: process-wide; ``rows <= 0`` restores DG_EDGE_ROWS.  ``GANStep.step`` sets it to B N^2 / 2 (never
+    below the default), between the node-level (B N, 2 B N) and edge-level (B N^2) row counts of its batch."""
+    global _edge_rows
+    rows = int(rows) if rows and rows > 0 else EDGE_ROWS
+    if rows != _edge_rows:
+        check(load().dg_set_edge_rows(rows), "dg_set_edge_rows")
+        _edge_rows = rows
 
 _lock = threading.Lock()
 _lib = None

@@ -38,6 +38,9 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- edge-level threshold (dg_set_edge_rows; runtime.hip) ---------------------
+int64_t edge_rows();
+
 // ---- float4 arithmetic ------------------------------------------------------
 __device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

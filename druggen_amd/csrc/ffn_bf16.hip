@@ -650,7 +650,7 @@ extern "C" int dg_ffn_ln_fwd_bf16(const void* x, const void* packed, const float
     if (R < 0) return fail(DG_E_SHAPE, "dg_ffn_ln_fwd_bf16: negative row count");
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_FFN_NODE : DG_K_FFN, stream);
+    ProfScope prof(R < edge_rows() ? DG_K_FFN_NODE : DG_K_FFN, stream);
     // lean kernel: stores whole 64-row tiles -- y, pre_ln, mean, rstd must hold dg_ffn_bf16_padded_rows(R) rows
     constexpr int lds = 2 * kXBytes + kHBytes + kZBytes + 1024;
     const bool save = pre != nullptr && relu_bits != nullptr;
@@ -688,7 +688,7 @@ extern "C" int dg_ffn_ln_bwd_bf16(const void* x, const void* pre, const float* m
     {
         constexpr int lds = kXBytes + kHBytes + kZBytes;
         DG_OPT_IN_LDS((&ffn_bwd_dx_bf16_kernel), lds);
-        ProfScope prof(R < DG_EDGE_ROWS ? DG_K_FFN_NODE : DG_K_FFN, stream);
+        ProfScope prof(R < edge_rows() ? DG_K_FFN_NODE : DG_K_FFN, stream);
         hipLaunchKernelGGL(ffn_bwd_dx_bf16_kernel, dim3(grid), dim3(512), lds, stream, static_cast<const bf16_t*>(dy),
                            static_cast<const bf16_t*>(pre), mean, rstd, relu_bits, gamma, pk, static_cast<bf16_t*>(dz),
                            static_cast<bf16_t*>(dx), part_ln, R);
@@ -700,13 +700,13 @@ extern "C" int dg_ffn_ln_bwd_bf16(const void* x, const void* pre, const float* m
         DG_OPT_IN_LDS((&ffn_bwd_dw_bf16_kernel<1>), lds);
         DG_OPT_IN_LDS((&ffn_bwd_dw_bf16_kernel<2>), lds);
         {
-            ProfScope prof(R < DG_EDGE_ROWS ? DG_K_FFN_WGRAD_NODE : DG_K_FFN_WGRAD, stream);
+            ProfScope prof(R < edge_rows() ? DG_K_FFN_WGRAD_NODE : DG_K_FFN_WGRAD, stream);
             hipLaunchKernelGGL((ffn_bwd_dw_bf16_kernel<1>), dim3(grid), dim3(512), lds, stream, static_cast<const bf16_t*>(x),
                                static_cast<const bf16_t*>(dz), b1, pk, bits_scratch, part_w, static_cast<float*>(nullptr), R);
         }
         launch_splitk_reduce(part_w, grid, static_cast<int64_t>(kC) * kH / 4, dw2, stream);
         {
-            ProfScope prof(R < DG_EDGE_ROWS ? DG_K_FFN_WGRAD_NODE : DG_K_FFN_WGRAD, stream);
+            ProfScope prof(R < edge_rows() ? DG_K_FFN_WGRAD_NODE : DG_K_FFN_WGRAD, stream);
             hipLaunchKernelGGL((ffn_bwd_dw_bf16_kernel<2>), dim3(grid), dim3(512), lds, stream, static_cast<const bf16_t*>(x),
                                static_cast<const bf16_t*>(dz), b1, pk, bits_scratch, part_w, part_b, R);
         }

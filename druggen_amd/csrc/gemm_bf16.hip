@@ -271,7 +271,7 @@ int row_gemm_bf16(const bf16_t* a, const void* packed, bf16_t* y, int64_t R, int
     EpiB ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
     const int64_t tiles = (R + kRowsPerTile - 1) / kRowsPerTile;
     const bf16x8* pk = static_cast<const bf16x8*>(packed);
-    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : (K == 384 ? DG_K_ROW_GEMM_E_K384 : (N == 384 ? DG_K_ROW_GEMM_E_N384 : DG_K_ROW_GEMM_E_128)), stream);
+    ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : (K == 384 ? DG_K_ROW_GEMM_E_K384 : (N == 384 ? DG_K_ROW_GEMM_E_N384 : DG_K_ROW_GEMM_E_128)), stream);
 #define LAUNCH(KC_, NC_, PER_CU_)                                                                                  \
     {                                                                                                              \
         constexpr int lds = 2 * kRowsPerTile * 128 * KC_ * 2 + kRowsPerTile * 128 * NC_ * 4;                       \

@@ -622,7 +622,7 @@ bool skinny_ok(int N, int K) { return N >= 1 && N <= 16 && K >= 4 && K % 4 == 0 
 
 // profiler key: edge-level launches by shape, everything else together
 int wgrad_prof_key(int64_t R, int N, int K) {
-    if (R < DG_EDGE_ROWS) return DG_K_LINEAR_WGRAD;
+    if (R < edge_rows()) return DG_K_LINEAR_WGRAD;
     if (N == 128 && K == 128) return DG_K_LINEAR_WGRAD_E_128;
     if (N == 384 && K == 128) return DG_K_LINEAR_WGRAD_E_N384;
     if (N == 128 && K == 384) return DG_K_LINEAR_WGRAD_E_K384;

@@ -5,6 +5,10 @@
 // not issued but kept -- one per kernel -- and rides in the NEXT launch of the same kernel: that launch runs two problems,
 // the workgroups split in proportion to their stages.  The caller guarantees that nothing reads a rider's output before
 // its carrier is launched (functional.py: the paired feed-forward nodes issue node, edge, node, edge ...).
+// LIFETIME CONTRACT: a waiting launch is a set of raw device pointers.  Every buffer handed to a launch inside the region
+// must stay allocated (not returned to a stream-ordered / caching allocator) until dg_launch_pair_end() has returned; the
+// Python binding references all operands of such launches until then (functional._pair_hold).  A ProfScope around a call
+// that only parks a rider records an empty span: the rider's time is part of its carrier's span.
 #pragma once
 
 #include "common.h"

@@ -1671,7 +1671,7 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
     if (R == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Epilogue ep{bias, mask_bits, relu_bits_out, residual, gamma, beta, mean, rstd, pre_ln, eps, relu};
-    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : (K == 384 ? DG_K_ROW_GEMM_E_K384 : (N == 384 ? DG_K_ROW_GEMM_E_N384 : DG_K_ROW_GEMM_E_128)), stream);
+    ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : (K == 384 ? DG_K_ROW_GEMM_E_K384 : (N == 384 ? DG_K_ROW_GEMM_E_N384 : DG_K_ROW_GEMM_E_128)), stream);
     if (use_x6()) {
         const int ng = N / 128;
         const int64_t tiles = (R + kTR - 1) / kTR;
@@ -1780,7 +1780,7 @@ int row_gemm_f32_ln_bwd(const float* a, const float* packed, float* dz, int64_t 
     const int64_t tiles = (R + kTR - 1) / kTR;
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
     {
-        ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
         note_forward(R);      // (dgamma / dbeta partial sums: the order of the rows matters)
         DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, true, 4, true>), kH3Lds);
         hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, true, 4, true>), dim3(seqs), dim3(512), kH3Lds, stream, a,
@@ -1811,7 +1811,7 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
     const int64_t tiles = (R + kTR - 1) / kTR;
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
     {
-        ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
+        ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_128, stream);
         note_forward(R);      // (dgamma / dbeta partial sums: the order of the rows matters)
         constexpr int lds = kH3Lds + 4 * 32 * 32 * 4;
         DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 4, false, true>), lds);
@@ -1842,7 +1842,7 @@ int row_gemm_f32_lin3(const float* a, const float* packed, float* y0, float* y1,
     const int64_t tiles = (R + kTR - 1) / kTR;
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
     // profiler / roofline: an edge-level launch of this kernel is a 128 -> 384 launch
-    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_N384, stream);
+    ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_N384, stream);
     // the column-group kernel (B fragments streamed per group: these launches are node-level, one or two tiles per
     // workgroup, where residency buys nothing; the resident-B instance with three outputs spills 168 B / lane)
     constexpr int lds3 = kH3Lds + 4 * 32 * 32 * 4;
@@ -1866,7 +1866,7 @@ int row_gemm_f32_sum3(const float* a0, const float* a1, const float* a2, const f
     ep.a_alt[1] = a2;
     const int64_t tiles = (R + kTR - 1) / kTR;
     const int seqs = static_cast<int>(tiles < 256 ? tiles : 256);
-    ProfScope prof(R < DG_EDGE_ROWS ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_K384, stream);
+    ProfScope prof(R < edge_rows() ? DG_K_ROW_GEMM : DG_K_ROW_GEMM_E_K384, stream);
     constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;
     if (residual) {
         DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<true, true>), lds384);

@@ -84,6 +84,9 @@ ProfScope::~ProfScope() {
     if (idx < g_spans.size()) (void)hipEventRecord(g_spans[idx].stop, stream);
 }
 
+static std::atomic<int64_t> g_edge_rows{DG_EDGE_ROWS};
+int64_t edge_rows() { return g_edge_rows.load(std::memory_order_relaxed); }
+
 static thread_local int g_pair_depth = 0;      // dg_launch_pair_begin / _end nest: launches wait while the depth is > 0
 bool pair_mode() { return g_pair_depth > 0; }
 
@@ -93,12 +96,12 @@ static bool alternate_traversal() {
     return on;
 }
 int take_direction(int64_t R) {
-    if (R < DG_EDGE_ROWS || !alternate_traversal()) return 0;
+    if (R < edge_rows() || !alternate_traversal()) return 0;
     g_last_dir = !g_last_dir;
     return g_last_dir;
 }
 void note_forward(int64_t R) {
-    if (R >= DG_EDGE_ROWS) g_last_dir = 0;
+    if (R >= edge_rows()) g_last_dir = 0;
 }
 
 }  // namespace dg
@@ -122,6 +125,13 @@ int dg_launch_pair_end(dg_stream_t stream_) {
 }
 
 int dg_version(void) { return DG_VERSION; }
+
+int dg_set_edge_rows(int64_t rows) {
+    dg::g_edge_rows.store(rows > 0 ? rows : static_cast<int64_t>(DG_EDGE_ROWS), std::memory_order_relaxed);
+    return 0;
+}
+
+int64_t dg_edge_rows(void) { return dg::edge_rows(); }
 
 const char* dg_last_error_string(void) { return dg::error_buffer(); }
 

@@ -22,7 +22,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
-           "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops",
+           "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops", "traffic_floor_bytes",
            "set_activation_dtype", "activation_dtype", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
@@ -38,22 +38,30 @@ def traffic_bytes(kernel: str) -> int:
     return _traffic.get(kernel, 0)
 
 
-def _account(kernel: str, nbytes: int, flops: int = 0) -> None:
+def _account(kernel: str, nbytes: int, flops: int = 0, floor: int = -1) -> None:
+    """``nbytes``: what the launch must move given what it is asked to produce (inputs + outputs + tensors it saves for a
+    backward).  ``floor``: inputs + outputs only (nothing saved, a backward recomputes) -- defaults to
+    ``nbytes`` for launches that save nothing."""
     _traffic[kernel] = _traffic.get(kernel, 0) + nbytes
+    _traffic[kernel + ":floor"] = _traffic.get(kernel + ":floor", 0) + (nbytes if floor < 0 else floor)
     if flops:
         _traffic[kernel + ":flops"] = _traffic.get(kernel + ":flops", 0) + flops
 
 
+def traffic_floor_bytes(kernel: str) -> int:
+    return _traffic.get(kernel + ":floor", 0)
+
+
 def _gemm_key(R: int, K: int, N: int) -> str:
     """Profiler / traffic key of a row GEMM launch: edge-level launches by shape (DG_K_ROW_GEMM_E_*), the rest together."""
-    if R < _lib.EDGE_ROWS:
+    if R < _lib.edge_rows():
         return "row_gemm"
     return "row_gemm_e_k384" if K == 384 else ("row_gemm_e_n384" if N == 384 else "row_gemm_e128")
 
 
 def _wgrad_key(R: int, N: int, K: int) -> str:
     """Profiler / traffic key of a weight-gradient launch (DG_K_LINEAR_WGRAD_E_*: edge-level launches by shape of dW)."""
-    if R >= _lib.EDGE_ROWS:
+    if R >= _lib.edge_rows():
         if (N, K) == (128, 128):
             return "linear_wgrad_e128"
         if (N, K) == (384, 128):
@@ -173,6 +181,7 @@ def attn_core(q, k, v, e, alpha: float, need_s: bool = True):
 # residual + LayerNorm  (reference src/model/layers.py:185-192)
 # --------------------------------------------------------------------------
 _ws_cache = {}
+_cache_lock = threading.Lock()      # nn.DataParallel replica threads insert into / sweep the module-level caches concurrently
 
 
 def _scratch(ref, need, tag="ln"):
@@ -182,12 +191,13 @@ def _scratch(ref, need, tag="ln"):
     key = (ref.device, _lib.stream_of(ref), threading.get_ident(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
-        if len(_ws_cache) > 256:      # nn.DataParallel starts fresh replica threads per forward: drop dead threads' buffers
-            alive = {t.ident for t in threading.enumerate()}
-            for k in [k for k in _ws_cache if k[2] not in alive]:
-                del _ws_cache[k]
         buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ref.device)
-        _ws_cache[key] = buf
+        with _cache_lock:
+            if len(_ws_cache) > 256:      # nn.DataParallel starts fresh replica threads per forward: drop dead threads' buffers
+                alive = {t.ident for t in threading.enumerate()}
+                for k in [k for k in list(_ws_cache) if k[2] not in alive]:
+                    _ws_cache.pop(k, None)
+            _ws_cache[key] = buf
     return buf
 
 
@@ -379,6 +389,19 @@ def _reduce_batch(ref, on=True):
             _lib.check(lib.dg_linear_wgrad_batch_end(_lib.stream_of(ref)), "dg_linear_wgrad_batch_end")
 
 
+_pair_tls = threading.local()
+
+
+def _pair_hold(*tensors) -> None:
+    """Lifetime contract of riding launches (csrc/pair.h keeps RAW device pointers of a waiting launch until its carrier or
+    dg_launch_pair_end): every operand of a launch issued inside ``_pair_launches`` is referenced from here until the
+    region ends, so a temporary (a ``.contiguous()`` / ``.to()`` copy) cannot go back to the caching allocator -- and be
+    handed to a kernel that is launched EARLIER in stream order -- while a rider still points at it."""
+    keep = getattr(_pair_tls, "keep", None)
+    if keep is not None:
+        keep.extend(t for t in tensors if t is not None)
+
+
 @contextlib.contextmanager
 def _pair_launches(ref, on=True):
     """dg_launch_pair_begin / _end: node-level launches of the 384-wide row GEMMs and of the producer / consumer weight
@@ -388,12 +411,19 @@ def _pair_launches(ref, on=True):
         yield False
         return
     lib = _lib.load()
+    outer = getattr(_pair_tls, "keep", None)
+    if outer is None:
+        _pair_tls.keep = []
     with _dev(ref):
         _lib.check(lib.dg_launch_pair_begin(), "dg_launch_pair_begin")
         try:
             yield True
         finally:
-            _lib.check(lib.dg_launch_pair_end(_lib.stream_of(ref)), "dg_launch_pair_end")
+            try:      # (also on an exception path: whatever waits is launched before its operands can be freed)
+                _lib.check(lib.dg_launch_pair_end(_lib.stream_of(ref)), "dg_launch_pair_end")
+            finally:
+                if outer is None:
+                    _pair_tls.keep = None
 
 
 def _wgrad_many(items, open_batch=True, pair_from=None):
@@ -483,6 +513,7 @@ def _wgrad(dy2, x2, want_bias, dy_mask=None, ws=None):
             ws = _scratch(dy2, need, "wgrad")
         _lib.check(lib.dg_linear_wgrad(_lib.ptr(dy2), _lib.ptr(dy_mask), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(),
                                        ws.numel(), R, N, K, _lib.dt(dy2), _lib.stream_of(dy2)), "dg_linear_wgrad")
+    _pair_hold(dy2, dy_mask, x2, dw, db, ws)
     _account(_wgrad_key(R, N, K), dy2.element_size() * R * (N * (2 if dy_mask is not None else 1) + K), 2 * R * N * K)
     return dw, db
 
@@ -829,9 +860,10 @@ def bump_weights_epoch() -> None:
     global _weights_epoch
     _weights_epoch += 1
     if len(_pack_cache) + len(_embed_pack_cache) > 8192:
-        for cache in (_pack_cache, _embed_pack_cache):
-            for k in [k for k, v in cache.items() if v[0]() is None]:
-                del cache[k]
+        with _cache_lock:
+            for cache in (_pack_cache, _embed_pack_cache):
+                for k in [k for k, v in list(cache.items()) if v[0]() is None]:
+                    cache.pop(k, None)
 
 
 _alias_canon = {}      # data pointer -> weakref of the parameter an alias output stands for
@@ -844,10 +876,11 @@ def _weight_alias(t):
     one multi-tensor add -- otherwise the autograd engine sums the two contributions of every parameter with a launch
     each (~50 tiny adds per step)."""
     a = t.view_as(t)
-    if len(_alias_canon) > 4096:
-        for k in [k for k, r in _alias_canon.items() if r() is None]:
-            del _alias_canon[k]
-    _alias_canon[a.data_ptr()] = weakref.ref(t)
+    with _cache_lock:
+        if len(_alias_canon) > 4096:
+            for k in [k for k, r in list(_alias_canon.items()) if r() is None]:
+                _alias_canon.pop(k, None)
+        _alias_canon[a.data_ptr()] = weakref.ref(t)
     return a
 
 
@@ -896,8 +929,9 @@ def packed_weight(w, mode: int, dtype=torch.float32):
             and hit[4] == _weights_epoch):
         return hit[2]
     if len(_pack_cache) > 4096:       # entries of dead tensors (e.g. DataParallel replicas)
-        for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
-            del _pack_cache[k]
+        with _cache_lock:
+            for k in [k for k, v in list(_pack_cache.items()) if v[0]() is None]:
+                _pack_cache.pop(k, None)
     lib = _lib.load()
     rows, cols = w.shape
     n_out, k = (rows, cols) if mode == 0 else (cols, rows)
@@ -926,8 +960,9 @@ def packed_weight3(w0, w1, w2, mode: int):
             and hit[3] == tuple(w.data_ptr() for w in ws) and hit[4] == _weights_epoch):
         return hit[2]
     if len(_pack3_cache) > 1024:
-        for k in [k for k, v in _pack3_cache.items() if any(r() is None for r in v[0])]:
-            del _pack3_cache[k]
+        with _cache_lock:
+            for k in [k for k, v in list(_pack3_cache.items()) if any(r() is None for r in v[0])]:
+                _pack3_cache.pop(k, None)
     lib = _lib.load()
     n_out, k = (384, 128) if mode == 0 else (128, 384)
     packed = torch.empty(int(lib.dg_row_gemm_packed_bytes(n_out, k, 0)), dtype=torch.uint8, device=w0.device)
@@ -1085,7 +1120,9 @@ def row_gemm(a2, packed, K, N, bias=None, relu=False, want_relu_bits=False, mask
                                    None if mask_bits is None else mask_bits.data_ptr(), _lib.ptr(residual),
                                    _lib.fptr(gamma), _lib.fptr(beta), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(pre),
                                    float(eps), code, _lib.stream_of(a2)), "dg_row_gemm")
-    _account(_gemm_key(R, K, N), es * R * (K + N * (1 + (residual is not None) + (pre is not None))), 2 * R * K * N)
+    _pair_hold(a2, packed, y, bias, bits, mask_bits, residual, gamma, beta, mean, rstd, pre)
+    _account(_gemm_key(R, K, N), es * R * (K + N * (1 + (residual is not None) + (pre is not None))), 2 * R * K * N,
+             floor=es * R * (K + N * (1 + (residual is not None))))
     if ln is not None:
         return (y, mean, rstd, pre) if want_pre else (y, mean, rstd)
     return (y, bits) if want_relu_bits else y
@@ -1268,7 +1305,7 @@ class _FFNLN(Function):
                                               _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
                                               _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
         _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
-        _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H)
+        _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H, floor=es * R * (H + 2 * C))
         if not keep:
             ctx.mark_non_differentiable(mean, rstd)
             return y.view(x.shape), None, mean, rstd
@@ -1425,7 +1462,7 @@ class _FFNLNPair(Function):
         for p in probs:
             R, C, H = p["R"], p["C"], p["H"]
             _account(_gemm_key(R, C, H), es * R * (C + H), 2 * R * C * H)
-            _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H)
+            _account(_gemm_key(R, H, C), es * R * (H + (3 if keep else 2) * C), 2 * R * C * H, floor=es * R * (H + 2 * C))
         pn, pe = probs
         outs = (pn["y"].view(pn["inp"].shape), pn["pre"], pn["mean"], pn["rstd"],
                 pe["y"].view(pe["inp"].shape), pe["pre"], pe["mean"], pe["rstd"])
@@ -1655,7 +1692,8 @@ class _FFNLNFusedBF16(Function):
                                               _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd),
                                               None if bits is None else bits.data_ptr(), R, eps, _lib.stream_of(x2)),
                        "dg_ffn_ln_fwd_bf16")
-        _account("ffn" if R >= _lib.EDGE_ROWS else "ffn_node", 2 * R * C * (3 if record else 2) + (48 * R if record else 0), 4 * R * C * 3 * C)
+        _account("ffn" if R >= _lib.edge_rows() else "ffn_node", 2 * R * C * (3 if record else 2) + (48 * R if record else 0), 4 * R * C * 3 * C,
+                 floor=2 * R * C * 2)
         if record:
             ctx.save_for_backward(x, w1, b1, w2, b2, gamma, beta, pre, mean, rstd, bits)
         ctx.eps = eps
@@ -1693,7 +1731,7 @@ class _FFNLNFusedBF16(Function):
                                               _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2), _lib.ptr(db2),
                                               None if bits2 is None else bits2.data_ptr(), ws.data_ptr(), ws.numel(), R,
                                               _lib.stream_of(x2)), "dg_ffn_ln_bwd_bf16")
-        lvl = "" if R >= _lib.EDGE_ROWS else "_node"
+        lvl = "" if R >= _lib.edge_rows() else "_node"
         _account("ffn" + lvl, 2 * R * C * (4 if want_x else 3) + 48 * R, 4 * R * C * H if want_x else 2 * R * C * H)
         if want_w:
             _account("ffn_wgrad" + lvl, 2 * (2 * R * C * 2 + 48 * R), 8 * R * C * H)
@@ -1853,7 +1891,8 @@ class _AttnBlock(Function):
                                                     _lib.fptr(_c(b4)), _lib.ptr(e), _lib.ptr(s), _lib.ptr(o), _lib.ptr(y2),
                                                     _lib.ptr(pre4), _lib.ptr(mean4), _lib.ptr(rstd4), B, N, C, alpha, eps4,
                                                     _lib.stream_of(q)), "dg_attn_half_f32_fwd")
-            _account("attn_half_fwd", 4 * (R * C * (5 if keep else 2) + 4 * B * N * C), 4 * R * C * C)
+            _account("attn_half_fwd", 4 * (R * C * (5 if keep else 2) + 4 * B * N * C), 4 * R * C * C,
+                     floor=4 * (R * C * 2 + 4 * B * N * C))
         else:
             e = row_gemm(yf, pw(we, 0), C, C, bias=be)
             s = torch.empty_like(e) if need_edge else None
@@ -2027,7 +2066,7 @@ class _AttnBlockBwd(Function):
                 _account("attn_half_bwd", 4 * (dy2f.shape[0] * C * (5 if ds is None else 6) + 7 * B * N * C), 2 * dy2f.shape[0] * C * C)
                 de = de.view(B, N, N, C)
                 fused1 = (dq, dk, dv, de)
-            elif add4 is None and dy2f.shape[0] >= _lib.EDGE_ROWS and ln_bwd_row_gemm_supported(dy2f, C, C):
+            elif add4 is None and dy2f.shape[0] >= _lib.edge_rows() and ln_bwd_row_gemm_supported(dy2f, C, C):
                 # ln4's backward runs in the producer waves of the out_e input-gradient GEMM (edge-level launches only:
                 # at node level the three small launches it replaces are faster)
                 dz4, ds, dg4, db4 = ln_bwd_row_gemm(pre4, g4, mean4, rstd4, dy2f, pw(woe, 1), want_affine=want_aff,
@@ -2223,7 +2262,7 @@ class _AttnBlockFused(Function):
                                             B, N, C, alpha, eps4, code, _lib.stream_of(q)), "dg_attn_half_fwd")
         es = q.element_size()
         _account("attn_half_fwd", es * B * ((3 if need_edge else 1) * N * N * C + 4 * N * C),
-                 2 * B * N * N * C * C * (2 if need_edge else 1))
+                 2 * B * N * N * C * C * (2 if need_edge else 1), floor=es * B * ((2 if need_edge else 1) * N * N * C + 4 * N * C))
         x2, mean3, rstd3, pre3 = row_gemm(o, pw(won, 0), C, C, bias=bon, residual=x1f, ln=(_c(g3), _c(b3), eps3),
                                           want_pre=True)
         ctx.save_for_backward(x1, yc, wq, wk, wv, we, woe, won, g3, g4, be, q, k, v, o, mean3, rstd3, pre3, mean4, rstd4,

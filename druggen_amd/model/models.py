@@ -32,6 +32,10 @@ class _Trunk(nn.Module):
                                                      mlp_ratio=mlp_ratio, drop_rate=dropout)
         self._act = act
         self._act_name = {nn.ReLU: "relu", nn.LeakyReLU: "leaky", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh"}.get(type(act))
+        # the fused kernels hard-code nn.LeakyReLU's default slope (what the reference's "leaky" builds, models.py:42): a
+        # user-supplied module with another slope takes the composite torch path
+        if isinstance(act, nn.LeakyReLU) and float(act.negative_slope) != 0.01:
+            self._act_name = None
 
     def _embed(self, seq, z):
         """Linear(in,64) - act - Linear(64,dim) - act - Dropout (models.py:52-61); the

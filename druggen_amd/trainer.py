@@ -25,6 +25,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from .model.loss import discriminator_loss, generator_loss
 from .functional import as_one_hot, attach_one_hot_labels, bump_weights_epoch, one_hot_labels
 from .optim import FlatAdamW
@@ -143,11 +144,16 @@ class GANStep:
         self.collective_events = [] if on else None
 
     def collective_ms(self):
-        """(all-reduces timed, total ms between their events) since ``time_collectives()``; synchronises the events."""
+        """(all-reduces timed, total ms between their events) since ``time_collectives()`` or the previous call; synchronises
+        the events.  The events sit on the current HIP stream: with the `nccl` backend the span is the device-side collective,
+        with `gloo` it is the host-side copy + reduction the stream waits for."""
         ev = self.collective_events or []
         if ev:
             ev[-1][1].synchronize()
-        return len(ev), float(sum(a.elapsed_time(b) for a, b in ev))
+        n, ms = len(ev), float(sum(a.elapsed_time(b) for a, b in ev))
+        if self.collective_events is not None:      # read once: the events are released, a long run does not accumulate them
+            self.collective_events = []
+        return n, ms
 
     def _low_memory(self, gen_edge) -> bool:
         if self.memory != "auto":
@@ -198,7 +204,8 @@ class GANStep:
                     flat.div_(ws)
                 if timed:
                     e1.record()
-                    self.collective_events.append((e0, e1))
+                    if len(self.collective_events) < 4096:      # bounded: timing left on for a long run keeps the first 4096
+                        self.collective_events.append((e0, e1))
             opt.step(packed=True)
         else:
             bucket.all_reduce_mean()
@@ -212,6 +219,9 @@ class GANStep:
         """One iteration on this rank's shard.  Returns (d_loss, g_loss) as
         0-dim device tensors (local-shard values; no host sync)."""
         B, dev = gen_node.shape[0], gen_node.device
+        # edge-level = at least half of this shard's B N^2 edge rows (profiler keys, traversal direction): a large batch's
+        # node-level launches (B = 2048: 92 160 / 184 320 rows) must not be filed with the edge-level ones
+        _lib.set_edge_rows(max(_lib.EDGE_ROWS, B * gen_node.shape[1] ** 2 // 2))
         # dataset graphs are one-hot (reference utils.py:15-23): checked once per tensor object, then the edge
         # embedding of these two batches is a table gather instead of an MLP over B N^2 rows
         gen_edge, disc_edge = as_one_hot(gen_edge), as_one_hot(disc_edge)

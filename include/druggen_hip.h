@@ -43,7 +43,7 @@ extern "C" {
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */
-#define DG_EDGE_ROWS 65536        /* profiler only: row GEMMs with at least this many rows count as edge-level */
+#define DG_EDGE_ROWS 65536        /* default of dg_set_edge_rows(): launches over at least this many rows count as edge-level */
 
 typedef void* dg_stream_t;        /* hipStream_t */
 
@@ -535,6 +535,12 @@ enum {
 };
 int dg_prof_enable(int mask);
 int dg_prof_reset(void);
+/* The row count from which a launch counts as EDGE-level (profiler keys above, traversal direction of the streaming kernels):
+ * process-wide, default DG_EDGE_ROWS.  A caller that knows its batch sets it between the node-level (B N, 2 B N) and the
+ * edge-level (B N^2) row counts of its step -- e.g. B N^2 / 2 -- so that a large batch's node-level launches (B = 2048:
+ * 92 160 rows) are not filed under the edge-level keys.  rows <= 0 restores the default.                                    */
+int     dg_set_edge_rows(int64_t rows);
+int64_t dg_edge_rows(void);
 int dg_prof_read(int kernel_id, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus

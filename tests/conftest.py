@@ -21,3 +21,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _default_edge_rows():
+    """GANStep.step raises the process-wide edge-level threshold to B N^2 / 2 of its batch (dg_set_edge_rows): every test
+    starts from the library default, so that kernel-level tests do not depend on which step test ran before them."""
+    import torch
+    if torch.cuda.is_available():
+        from druggen_amd import _lib
+        _lib.set_edge_rows(0)
+    yield

@@ -264,6 +264,29 @@ def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(
     assert len(ar["per_rank_ms_per_step"]) == 2 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
 
 
+def test_bench_line_is_one_short_parseable_record(tmp_path):
+    """The driver stores bench.py's stdout line; round 4's 21 KB line was recorded as unparseable.  The default single-GPU
+    line (with the CPU baseline, the secondary blocks switched off for speed) must be ONE JSON object under 6 KB that
+    carries the contract fields, `roofline` (with its kernel symbol and the floor-bytes fraction) and `cpu_baseline`."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--no-extra",
+           "--cpu-batch", "2"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6144, (len(lines), [len(l) for l in lines])
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_symbol", "bytes_floor_per_launch", "frac_of_floor"):
+        assert k in rf, k
+    assert 0 < rf["frac_of_floor"] <= rf["frac"] < 1.0
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    assert "kernels" not in out and "roofline_all" not in out
+
+
 def test_dataparallel_replicas_on_one_device_run_the_gradient_penalty():
     """The reference's --parallel path (train.py:220-223) wraps D in nn.DataParallel: replicas are THREADS.  Two replicas
     on cuda:0 (device_ids=[0, 0]) go through discriminator_loss -- the batched D(real, fake) forward, the gradient
