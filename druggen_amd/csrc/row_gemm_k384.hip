@@ -18,6 +18,12 @@
 //                channels of ONE row.  Per stage 24 ds_read_b128, 36 MFMAs, three folds, + bias (ReLU), one 16-byte LDS
 //                write.  No global memory operation.
 //   one s_barrier per stage; planes and output tile double-buffered.
+//
+// H16 instances (DG_DTYPE_F32_H16, include/druggen_hip.h): the [R,384] operand arrives as ONE fp16 plane with one inverse
+// power-of-two scale per row (what row_gemm_n384.hip's H16 instance writes).  The producers then only MOVE it: 16-byte pieces HBM
+// -> registers -> LDS (row-major stage [16][768 B], the 16-byte slot index xor-ed with the row inside each 256-byte group:
+// conflict-free for the writes of 16 consecutive lanes and for the fragment reads of 16 rows), 12 KiB per stage, six stages in
+// flight.  The consumers run TWO products per k-step (x . w_hi, x . w_lo) on six independent chains and fold once.
 #include "common.h"
 #include "row_gemm_k384.h"
 #include "pair.h"
@@ -98,14 +104,15 @@ struct EpiK {
 // One problem of a launch; workgroups [0, nb0) run problem 0, the others problem 1 (a node-level GEMM riding in the
 // edge-level launch of the same kernel: pair.h, row_gemm_n384.hip).
 struct ProbK {
-    const float* a;
+    const float* a;           // [R,384] float32, or (H16) [R,384] fp16
+    const float* ascale;      // H16: inverse row scales [R]
     const f16x8* packed;
     float* y;
     int64_t R;
     EpiK ep;
 };
 
-template <bool RES, bool LN>
+template <bool RES, bool LN, bool H16>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const ProbK p0, const ProbK p1, const int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
     const float* __restrict__ const a = second ? p1.a : p0.a;
+    const float* __restrict__ const ascale = second ? p1.ascale : p0.ascale;
     const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
     float* __restrict__ const y = second ? p1.y : p0.y;
     const int64_t R = second ? p1.R : p0.R;
@@ -127,7 +135,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         const int64_t st = bidx + static_cast<int64_t>(t) * nblk;
         return ep.reverse ? total - 1 - st : st;
     };
-    const int TP = (T + kDepth - 1) / kDepth * kDepth;
+    constexpr int DEPTH = H16 ? 2 * kDepth : kDepth;      // stages in flight (H16 stages are half the bytes: twice as many)
+    const int TP = (T + DEPTH - 1) / DEPTH * DEPTH;
 
     if (w >= kCons) {
         // ------------------------------------------------------------------------------------------ producers
@@ -139,11 +148,36 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             tab[pt] = ep.gamma[pt];
             tab[128 + pt] = ep.beta[pt];
         }
-        float4 pf[kDepth][6];
+        float4 pf[DEPTH][H16 ? 4 : 6];      // (H16: three pieces + the stage's inverse row scales, kept in .x of the fourth)
         // half-wave hw streams rows 2 hw, 2 hw + 1 of the stage: six consecutive 512-byte pieces (row-major, chunk minor)
         const unsigned voff = static_cast<unsigned>(hw) * 3072u + static_cast<unsigned>(l32) * 16u;
-        auto fetch = [&](float4 (&set)[6], int t) {
+        // H16: thread pt moves the 16-byte pieces pt, pt + 256, pt + 512 of the stage's 768 (= 16 rows x 48); piece q is slot
+        // q % 48 of row q / 48 and goes to LDS slot (slot ^ (row & 15)) of that row (the xor stays inside a 16-slot group)
+        unsigned hdst[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = pt + 256 * i, row = q / 48, slot = q % 48;
+            hdst[i] = static_cast<unsigned>(row * 768 + ((slot & ~15) | ((slot & 15) ^ row)) * 16);
+        }
+        auto fetch = [&](float4 (&set)[H16 ? 4 : 6], int t) {
             if (t > T - 1) t = T - 1;
+            if (H16) {
+                const int64_t r0 = stage_of(t) * kSR;
+                const int64_t left = (R - r0) * 768;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<_Float16*>(const_cast<float*>(a)) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)),
+                    0x00020000);
+                const int64_t lefts = (R - r0) * 4;
+                const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(ascale) + r0, 0, static_cast<int>(lefts < 64 ? lefts : 64), 0x00020000);
+                if (K3_DBG & 8) return;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<unsigned>(pt) * 16u, i * 4096, 0));
+                // threads 0..15: the inverse scale of row pt (rows past the end read as 0: their products are never stored)
+                set[3].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, pt < 16 ? static_cast<unsigned>(pt) * 4u : 0x7FFFFFF0u, 0, 0));
+                return;
+            }
             const int64_t r0 = stage_of(t) * kSR;
             const int64_t left = (R - r0) * 1536;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -156,8 +190,18 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         // piece i of the thread: row 2 hw + i / 3, chunk i % 3; float4 column c = l32 of the chunk covers k = 4c .. 4c + 3:
         // block (chunk, c >> 1), half c & 1; row r of a block sits at position r ^ (block & 7)
         const int blk = l32 >> 1;
-        auto split = [&](float4 (&set)[6], int t) {      // stage t -> planes[t & 1]
+        auto split = [&](float4 (&set)[H16 ? 4 : 6], int t) {      // stage t -> planes[t & 1]
             char* const pl = smem + (t & 1) * kStage;
+            if (H16) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // (volatile: the first use of the loads stays behind the previous iteration's barrier)
+                    asm volatile("" : "+v"(set[i].x), "+v"(set[i].y), "+v"(set[i].z), "+v"(set[i].w));
+                    *reinterpret_cast<float4*>(pl + hdst[i]) = set[i];
+                }
+                if (pt < 16) *reinterpret_cast<float*>(pl + 2 * kPlane + pt * 4) = set[3].x;
+                return;
+            }
             if (K3_DBG & 2) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
@@ -271,30 +315,22 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, goff, j * 512, 0);
             }
         };
-        fetch(pf[0], 0);
-        fetch(pf[1], 1);
-        fetch(pf[2], 2);
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) fetch(pf[u], u);
         split(pf[0], 0);
-        fetch(pf[0], 3);
+        fetch(pf[0], DEPTH);
         __syncthreads();
-        for (int t = 0; t < TP; t += 3) {
-            // iteration t: the consumers are on stage t; planes of stage t + 1 are written, the tile of stage t - 1 is finished
-            // with the residual rows requested an iteration ago, the residual rows of stage t are requested
-            split(pf[1], t + 1);
-            fetch(pf[1], t + 4);
-            finish(t - 1);
-            fetch_res(t);
-            __syncthreads();
-            split(pf[2], t + 2);
-            fetch(pf[2], t + 5);
-            finish(t);
-            fetch_res(t + 1);
-            __syncthreads();
-            split(pf[0], t + 3);
-            fetch(pf[0], t + 6);
-            finish(t + 1);
-            fetch_res(t + 2);
-            __syncthreads();
+        for (int t = 0; t < TP; t += DEPTH) {
+            // iteration t + u: the consumers are on stage t + u; planes of stage t + u + 1 are written, the tile of stage
+            // t + u - 1 is finished with the residual rows requested an iteration ago, the residual rows of stage t + u are requested
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                split(pf[(u + 1) % DEPTH], t + u + 1);
+                fetch(pf[(u + 1) % DEPTH], t + u + 1 + DEPTH);
+                finish(t + u - 1);
+                fetch_res(t + u);
+                __syncthreads();
+            }
         }
         finish(TP - 1);
         return;
@@ -320,14 +356,46 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
     // activation fragment of lane (row n, quarter kq) in k-step ks of a chunk: block 4 ks + kq, position n ^ ((4 ks + kq) & 7)
     const unsigned xo_e = static_cast<unsigned>(kq * 256 + ((n ^ kq) * 16));            // even k-steps
     const unsigned xo_o = static_cast<unsigned>(kq * 256 + ((n ^ (4 + kq)) * 16));      // odd k-steps
+    // H16: slot 4 ks + kq of chunk kc of row n sits at row n, slot 16 kc + ((4 ks + kq) ^ n)
+    unsigned xo_h[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xo_h[ks] = static_cast<unsigned>(n * 768 + (((4 * ks + kq) ^ n) * 16));
     __builtin_amdgcn_s_waitcnt(0x0F70);      // weight fragments, scales and bias are in registers
     __syncthreads();                         // stage 0 is in planes[0], gamma / beta are written
     for (int t = 0; t < TP; ++t) {
         if (t < T) {
             const char* pl = smem + (t & 1) * kStage;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (H16) {
+                // two products per k-step, six independent chains (chunk x weight plane), one fold with the row's inverse scale
+                f32x4 pl0[3], ph0[3];
 #pragma unroll
-            for (int kc = 0; kc < 3; ++kc) {
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int kc = 0; kc < 3; ++kc) {
+                        const f16x8 xh = (K3_DBG & 16) ? wf[ks][0] : *reinterpret_cast<const f16x8*>(pl + kc * 256 + xo_h[ks]);
+                        const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][1];
+                        if (K3_DBG & 1) {
+                            if (ks == 0) pl0[kc] = ph0[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            pl0[kc][0] += static_cast<float>(xh[0]) * static_cast<float>(wl[0]);
+                        } else if (ks == 0) {
+                            mfma16_first(pl0[kc], wl, xh);
+                            mfma16_first(ph0[kc], wh, xh);
+                        } else {
+                            mfma16(pl0[kc], wl, xh);
+                            mfma16(ph0[kc], wh, xh);
+                        }
+                    }
+                const float rs = *reinterpret_cast<const float*>(pl + 2 * kPlane + n * 4);
+                mfma_results_ready();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = (pl0[0][i] + pl0[1][i]) + pl0[2][i], hi = (ph0[0][i] + ph0[1][i]) + ph0[2][i];
+                    acc[i] = (lo + hi) * (rs * (i == 0 ? cs.x : i == 1 ? cs.y : i == 2 ? cs.z : cs.w));
+                }
+            }
+#pragma unroll
+            for (int kc = 0; kc < (H16 ? 0 : 3); ++kc) {
                 // three accumulation chains per chunk (lo.hi, hi.lo, hi.hi): two independent MFMAs between dependent ones
                 f32x4 p0, p1, p2;
 #pragma unroll
@@ -382,24 +450,28 @@ struct Pending {
 thread_local Pending g_rider;
 
 // the kernel variant a problem needs: residual and LayerNorm epilogues are template parameters
-int variant(const ProbK& p) { return (p.ep.residual ? 1 : 0) + (p.ep.gamma ? 2 : 0); }
+int variant(const ProbK& p) { return (p.ep.residual ? 1 : 0) + (p.ep.gamma ? 2 : 0) + (p.ascale ? 4 : 0); }
 
 int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
     const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
     int nb0, nb1;
     pair_split(st0, st1, 256, &nb0, &nb1);
     const ProbK& q1 = p1 ? *p1 : p0;
-#define DG_K384_LAUNCH(RES_, LN_)                                                                                  \
+#define DG_K384_LAUNCH(RES_, LN_, H16_)                                                                            \
     {                                                                                                              \
-        DG_OPT_IN_LDS((&row_gemm_k384_kernel<RES_, LN_>), kLds);                                                   \
-        hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
+        DG_OPT_IN_LDS((&row_gemm_k384_kernel<RES_, LN_, H16_>), kLds);                                             \
+        hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_, H16_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
                            q1, nb0);                                                                               \
     }
     switch (variant(p0)) {
-        case 3: DG_K384_LAUNCH(true, true) break;
-        case 1: DG_K384_LAUNCH(true, false) break;
-        case 2: DG_K384_LAUNCH(false, true) break;
-        default: DG_K384_LAUNCH(false, false) break;
+        case 3: DG_K384_LAUNCH(true, true, false) break;
+        case 1: DG_K384_LAUNCH(true, false, false) break;
+        case 2: DG_K384_LAUNCH(false, true, false) break;
+        case 7: DG_K384_LAUNCH(true, true, true) break;
+        case 5: DG_K384_LAUNCH(true, false, true) break;
+        case 6: DG_K384_LAUNCH(false, true, true) break;
+        case 4: DG_K384_LAUNCH(false, false, true) break;
+        default: DG_K384_LAUNCH(false, false, false) break;
     }
 #undef DG_K384_LAUNCH
     return 0;
@@ -412,10 +484,11 @@ int flush_row_gemm_k384(hipStream_t stream) {
     return launch(g_rider.p, nullptr, stream);
 }
 
-int launch_row_gemm_k384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+int launch_row_gemm_k384(const void* a, const float* ascale, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
                          float* pre_ln, float eps, hipStream_t stream) {
-    const ProbK p{a, static_cast<const f16x8*>(packed), y, R, EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu, take_direction(R)}};
+    const ProbK p{static_cast<const float*>(a), ascale, static_cast<const f16x8*>(packed), y, R,
+                  EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;
         g_rider.p = p;

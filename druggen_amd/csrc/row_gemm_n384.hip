@@ -19,6 +19,11 @@
 //                write per block into the output tile.  No global memory operation at all: the ReLU mask words travel
 //                through LDS too (a consumer that stored its own word waited for that store, vmcnt(0), every stage).
 //   one s_barrier per stage; planes and output tile double-buffered.
+//
+// H16 instance (DG_DTYPE_F32_H16, include/druggen_hip.h): the [R,384] result leaves as ONE fp16 plane -- every row scaled by the
+// power of two that puts its largest magnitude into [2^14, 2^15), rounded to nearest -- plus one inverse scale per row (768 + 4
+// bytes per row instead of 1536).  The producers do it on the way out of the output tile: a half-wave owns a whole row there,
+// so the row maximum is the same four DPP steps + one v_permlane16_swap as on the way in.
 #include "common.h"
 #include "row_gemm_n384.h"
 #include "pair.h"
@@ -78,11 +83,13 @@ struct Epi {
 struct Prob {
     const float* a;
     const f16x8* packed;
-    float* y;
+    float* y;             // [R,384] float32, or (H16) [R,384] fp16
+    float* yscale;        // H16: inverse row scales [R]
     int64_t R;
     Epi ep;
 };
 
+template <bool H16>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
     const float* __restrict__ const a = second ? p1.a : p0.a;
     const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
     float* __restrict__ const y = second ? p1.y : p0.y;
+    float* __restrict__ const yscale = second ? p1.yscale : p0.yscale;
     const int64_t R = second ? p1.R : p0.R;
     const Epi ep = second ? p1.ep : p0.ep;
     const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
@@ -201,15 +209,64 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             const bool ok = t >= 0 && t < T;
             const int tc = ok ? t : 0;
             const int64_t r0 = stage_of(tc) * kSR;
-            const int64_t left = (R - r0) * 1536;
-            const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 384, 0, bytes, 0x00020000);
             const char* ot = smem + kOffOut + (tc & 1) * kOut;
+            if (H16) {
+                // one fp16 plane + one inverse scale per row: rows hw + 8 k, a half-wave per row (three 512-byte pieces per lane)
+                const int64_t left = R - r0;
+                const int rows = ok ? static_cast<int>(left < kSR ? left : kSR) : 0;      // 0: every store is dropped
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<_Float16*>(y) + r0 * 384, 0, rows * 768, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(yscale + r0, 0, rows * 4, 0x00020000);
+                const unsigned hoff = static_cast<unsigned>(hw) * 768u + static_cast<unsigned>(l32 ^ hw) * 8u;
+                const unsigned soff = l32 == 0 ? static_cast<unsigned>(hw) * 4u : 0x7FFFFFF0u;      // one lane per row
+                float4 v[4][3];
+                unsigned m[4];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int k = i / 3, qq = i % 3;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ooff + k * 8 * 1536 + qq * 512);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, goff, k * 8 * 1536 + qq * 512, 0);
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq) v[k][qq] = *reinterpret_cast<const float4*>(ot + ooff + k * 8 * 1536 + qq * 512);
+                    float a0, a1, a2, u;
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a0) : "v"(v[k][0].x), "v"(v[k][0].y), "v"(v[k][0].z));
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a1) : "v"(v[k][0].w), "v"(v[k][1].x), "v"(v[k][1].y));
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a2) : "v"(v[k][1].z), "v"(v[k][1].w), "v"(v[k][2].x));
+                    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(a0) : "v"(a0), "v"(v[k][2].y), "v"(v[k][2].z));
+                    asm("v_max3_f32 %0, %1, %2, |%3|" : "=v"(u) : "v"(a0), "v"(a1), "v"(v[k][2].w));
+                    m[k] = __float_as_uint(fmaxf(u, a2));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0xB1>(m[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x4E>(m[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x141>(m[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x140>(m[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(m[k], m[k], false, false);
+                    const unsigned xm = r[0] > r[1] ? r[0] : r[1];
+                    unsigned e = xm >> 23;
+                    e = e < 15u ? 15u : e;
+                    const float sc = __uint_as_float((268u - e) << 23);      // the row maximum lands in [2^14, 2^15)
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq) {
+                        const f32x2 xa = f32x2{v[k][qq].x, v[k][qq].y} * sc, xb = f32x2{v[k][qq].z, v[k][qq].w} * sc;
+                        const f16x2 ha = __builtin_convertvector(xa, f16x2), hb = __builtin_convertvector(xb, f16x2);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)},
+                                                              rsrc, hoff, k * 8 * 768 + qq * 256, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32((e - 14u) << 23, rsc, soff, k * 32, 0);
+                }
+            } else {
+                const int64_t left = (R - r0) * 1536;
+                const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 384, 0, bytes, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const int k = i / 3, qq = i % 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ot + ooff + k * 8 * 1536 + qq * 512);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, goff, k * 8 * 1536 + qq * 512, 0);
+                }
             }
             // the stage's ReLU bit words (written by the consumers next to the tile)
             const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(
@@ -344,8 +401,13 @@ int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
     const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
     int nb0, nb1;
     pair_split(st0, st1, 256, &nb0, &nb1);
-    DG_OPT_IN_LDS((&row_gemm_n384_kernel), kLds);
-    hipLaunchKernelGGL(row_gemm_n384_kernel, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
+    if (p0.yscale) {
+        DG_OPT_IN_LDS((&row_gemm_n384_kernel<true>), kLds);
+        hipLaunchKernelGGL(row_gemm_n384_kernel<true>, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
+    } else {
+        DG_OPT_IN_LDS((&row_gemm_n384_kernel<false>), kLds);
+        hipLaunchKernelGGL(row_gemm_n384_kernel<false>, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
+    }
     return 0;
 }
 }  // namespace
@@ -356,9 +418,10 @@ int flush_row_gemm_n384(hipStream_t stream) {
     return launch(g_rider.p, nullptr, stream);
 }
 
-int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R, const float* bias, int relu,
+int launch_row_gemm_n384(const float* a, const void* packed, void* y, float* yscale, int64_t R, const float* bias, int relu,
                          unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream) {
-    const Prob p{a, static_cast<const f16x8*>(packed), y, R, Epi{bias, mask_bits, relu_bits, relu, take_direction(R)}};
+    const Prob p{a, static_cast<const f16x8*>(packed), static_cast<float*>(y), yscale, R,
+                 Epi{bias, mask_bits, relu_bits, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;
         g_rider.p = p;
@@ -366,7 +429,8 @@ int launch_row_gemm_n384(const float* a, const void* packed, float* y, int64_t R
     }
     if (g_rider.valid) {
         g_rider.valid = false;
-        return launch(p, &g_rider.p, stream);
+        if ((g_rider.p.yscale != nullptr) == (yscale != nullptr)) return launch(p, &g_rider.p, stream);
+        if (int st = launch(g_rider.p, nullptr, stream)) return st;      // another output format: on its own, first
     }
     return launch(p, nullptr, stream);
 }
