@@ -38,6 +38,8 @@ class FFNBwdArgs(ctypes.Structure):
 SIGNATURES = {
     "dg_version": (c_int, []),
     "dg_last_error_string": (c_char_p, []),
+    "dg_hidden_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "dg_hidden_scale_offset": (c_size_t, [c_int64, c_int]),
     "dg_attn_core_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_float, c_int, _P]),
     "dg_attn_core_bwd_add": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_float, c_int, _P]),
@@ -175,6 +177,7 @@ def check(status: int, what: str) -> None:
 
 
 DTYPES = {torch.float32: 0, torch.bfloat16: 1}     # DG_DTYPE_F32 / DG_DTYPE_BF16 of include/druggen_hip.h
+F32_H16 = 2      # DG_DTYPE_F32_H16: float32 activations, the [R,384] feed-forward hidden tensors as one scaled fp16 plane
 
 
 def dt(t) -> int:

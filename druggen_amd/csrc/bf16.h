@@ -65,6 +65,9 @@ __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = static_cast<__bf16>(v); }
 
 inline bool dtype_ok(int dtype) { return dtype == DG_DTYPE_F32 || dtype == DG_DTYPE_BF16; }
+// DG_DTYPE_F32_H16 is float32 everywhere except the 384-wide hidden operands
+inline int act_dtype(int dtype) { return dtype == DG_DTYPE_F32_H16 ? DG_DTYPE_F32 : dtype; }
+inline size_t hidden_scale_offset(int64_t R, int H) { return (static_cast<size_t>(R) * H * 2 + 255) / 256 * 256; }
 inline size_t dtype_size(int dtype) { return dtype == DG_DTYPE_BF16 ? 2 : 4; }
 
 }  // namespace dg

@@ -11,7 +11,7 @@
 //         dh = (dz W2) * (h > 0)            [dg_row_gemm, packed ReLU mask in the epilogue]
 //         dx = dz + dh W1                   [dg_row_gemm, residual epilogue]
 //         dW2, db2 = dz^T h, sum dz ; dW1, db1 = dh^T x, sum dh      [dg_linear_wgrad]
-#include "common.h"
+#include "bf16.h"
 
 using namespace dg;
 
@@ -59,7 +59,7 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
     // (dg_row_gemm_ln_bwd) and dz holds the result; dgamma / dbeta are not touched
     if (dy)
         st = dg_ln_residual_bwd_add(pre_ln, nullptr, gamma, mean, rstd, dy, dz_add, dz, dgamma, dbeta, workspace,
-                                    lnb, R, C, dtype, stream);
+                                    lnb, R, C, act_dtype(dtype), stream);
     if (st) {
         if (batch) dg_linear_wgrad_batch_end(stream);
         return st;
@@ -116,7 +116,7 @@ int ffn_bwd_phase(const dg_ffn_bwd_args& a, int phase, int C, int H, int dtype, 
         case 0:      // dz = LN'(dy) (+ dz_add); dy == NULL: dz already holds it
             if (!a.dy) return 0;
             return dg_ln_residual_bwd_add(a.pre_ln, nullptr, a.gamma, a.mean, a.rstd, a.dy, a.dz_add, a.dz, a.dgamma, a.dbeta, ws,
-                                          lnb, R, C, dtype, stream);
+                                          lnb, R, C, act_dtype(dtype), stream);
         case 1:      // dh = (dz W2) masked by the forward's ReLU bits
             return dg_row_gemm(a.dz, a.w2_dgrad_packed, a.dh, R, C, H, nullptr, 0, nullptr, a.relu_bits, nullptr, nullptr,
                                nullptr, nullptr, nullptr, nullptr, 0.f, dtype, stream);

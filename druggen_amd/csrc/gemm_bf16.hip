@@ -41,7 +41,8 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
                        size_t workspace_bytes, int64_t R, dg_stream_t stream);
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
                  unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
-                 const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream);
+                 const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream,
+                 const float* ascale = nullptr, float* yscale = nullptr);
 
 namespace {
 
@@ -293,6 +294,7 @@ using namespace dg;
 // ---- public entry points: dispatch on dtype -------------------------------------------------------
 extern "C" size_t dg_row_gemm_packed_bytes(int n_out, int k_contract, int dtype) {
     if (n_out < 1 || k_contract < 1) return 0;
+    dtype = act_dtype(dtype);
     if (dtype == DG_DTYPE_BF16) return static_cast<size_t>(n_out) * k_contract * 2;
     return row_gemm_f32_packed_floats(n_out, k_contract) * sizeof(float);
 }
@@ -301,6 +303,7 @@ extern "C" int dg_row_gemm_pack(const float* w, void* packed, int rows, int cols
                                 dg_stream_t stream_) {
     if (!w || !packed) return fail(DG_E_ARG, "dg_row_gemm_pack: null pointer");
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
+    dtype = act_dtype(dtype);
     if (dtype == DG_DTYPE_BF16) return pack_bf16(w, packed, rows, cols, mode, 32, static_cast<hipStream_t>(stream_));
     if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm_pack: unknown dtype %d", dtype);
     return row_gemm_f32_pack(w, static_cast<float*>(packed), rows, cols, mode, stream_);
@@ -331,7 +334,7 @@ extern "C" int dg_row_gemm_sum3(const void* a0, const void* a1, const void* a2, 
 }
 
 extern "C" size_t dg_row_gemm_mask_words(int64_t R, int K, int N, int dtype) {
-    return dtype == DG_DTYPE_BF16 ? row_gemm_bf16_mask_words(R, K, N) : row_gemm_f32_mask_words(R, K, N);
+    return act_dtype(dtype) == DG_DTYPE_BF16 ? row_gemm_bf16_mask_words(R, K, N) : row_gemm_f32_mask_words(R, K, N);
 }
 
 extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R, int K, int N, const float* bias,
@@ -344,10 +347,24 @@ extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R
         return row_gemm_bf16(static_cast<const bf16_t*>(a), packed, static_cast<bf16_t*>(y), R, K, N, bias, relu,
                              relu_bits_out, mask_bits, static_cast<const bf16_t*>(residual), gamma, beta, mean, rstd,
                              static_cast<bf16_t*>(pre_ln), eps, static_cast<hipStream_t>(stream_));
-    if (dtype != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm: unknown dtype %d", dtype);
+    if (dtype != DG_DTYPE_F32 && dtype != DG_DTYPE_F32_H16) return fail(DG_E_ARG, "dg_row_gemm: unknown dtype %d", dtype);
+    // DG_DTYPE_F32_H16: the 384-wide operand (a for K = 384, y for N = 384) is an fp16 plane + inverse row scales
+    const float* ascale = nullptr;
+    float* yscale = nullptr;
+    if (dtype == DG_DTYPE_F32_H16 && K == 384)
+        ascale = reinterpret_cast<const float*>(static_cast<const char*>(a) + hidden_scale_offset(R, 384));
+    if (dtype == DG_DTYPE_F32_H16 && N == 384) yscale = reinterpret_cast<float*>(static_cast<char*>(y) + hidden_scale_offset(R, 384));
     return row_gemm_f32(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y), R, K, N,
                         bias, relu, relu_bits_out, mask_bits, static_cast<const float*>(residual), gamma, beta, mean, rstd,
-                        static_cast<float*>(pre_ln), eps, stream_);
+                        static_cast<float*>(pre_ln), eps, stream_, ascale, yscale);
+}
+
+extern "C" size_t dg_hidden_scale_offset(int64_t R, int H) { return R < 0 || H < 1 ? 0 : hidden_scale_offset(R, H); }
+
+extern "C" size_t dg_hidden_bytes(int64_t R, int H, int dtype) {
+    if (R < 0 || H < 1) return 0;
+    if (dtype == DG_DTYPE_F32_H16) return hidden_scale_offset(R, H) + static_cast<size_t>(R) * 4;
+    return static_cast<size_t>(R) * H * dtype_size(dtype);
 }
 
 extern "C" size_t dg_row_gemm_ln_bwd_workspace_bytes(int dtype) {

@@ -89,7 +89,11 @@ struct Prob {
     Epi ep;
 };
 
-template <bool H16>
+// MODE: the consumers' epilogue.  0 generic (bias, optional ReLU, optional mask in, bits out); 1 the forward of fc1 -- bias + ReLU +
+// bits out, no mask in; 2 its twin in the backward -- mask in only (dh = (dz W2) * m).  The generic form spends ~8 vector
+// instructions per element on selects whose conditions are launch constants (and a wait state per v_cmp -> v_cndmask pair); the
+// two hot forms need 3 and 2.
+template <bool H16, int MODE>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -211,52 +215,62 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             const int64_t r0 = stage_of(tc) * kSR;
             const char* ot = smem + kOffOut + (tc & 1) * kOut;
             if (H16) {
-                // one fp16 plane + one inverse scale per row: rows hw + 8 k, a half-wave per row (three 512-byte pieces per lane)
+                // one fp16 plane + one inverse scale per row.  Eight lanes per row, six pairs of 16-byte tile slots (= 8
+                // consecutive channels = one 16-byte store) per lane: thread pt -> row 2 (pt >> 4) + ((pt >> 3) & 1), pairs
+                // (pt & 7) + 8 m.  A pair's lower-channel half sits at tile position 2 j + (row & 1): the even row of a
+                // 16-lane group reads even positions while the odd row reads odd ones -- conflict-free ds_read_b128.
                 const int64_t left = R - r0;
                 const int rows = ok ? static_cast<int>(left < kSR ? left : kSR) : 0;      // 0: every store is dropped
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<_Float16*>(y) + r0 * 384, 0, rows * 768, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(yscale + r0, 0, rows * 4, 0x00020000);
-                const unsigned hoff = static_cast<unsigned>(hw) * 768u + static_cast<unsigned>(l32 ^ hw) * 8u;
-                const unsigned soff = l32 == 0 ? static_cast<unsigned>(hw) * 4u : 0x7FFFFFF0u;      // one lane per row
-                float4 v[4][3];
-                unsigned m[4];
+                const int g = pt >> 4, sub = (pt >> 3) & 1, l8 = pt & 7, row = 2 * g + sub;
+                const unsigned lo_off = static_cast<unsigned>(row * 1536 + l8 * 32 + sub * 16);
+                const unsigned hi_off = static_cast<unsigned>(row * 1536 + l8 * 32 + (1 - sub) * 16);
+                const unsigned hoff = static_cast<unsigned>(row * 768 + ((l8 ^ (g & 3)) * 16));
+                const unsigned soff = l8 == 0 ? static_cast<unsigned>(row) * 4u : 0x7FFFFFF0u;      // one lane per row
+                float4 vl[6], vh[6];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                    for (int qq = 0; qq < 3; ++qq) v[k][qq] = *reinterpret_cast<const float4*>(ot + ooff + k * 8 * 1536 + qq * 512);
-                    float a0, a1, a2, u;
-                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a0) : "v"(v[k][0].x), "v"(v[k][0].y), "v"(v[k][0].z));
-                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a1) : "v"(v[k][0].w), "v"(v[k][1].x), "v"(v[k][1].y));
-                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a2) : "v"(v[k][1].z), "v"(v[k][1].w), "v"(v[k][2].x));
-                    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(a0) : "v"(a0), "v"(v[k][2].y), "v"(v[k][2].z));
-                    asm("v_max3_f32 %0, %1, %2, |%3|" : "=v"(u) : "v"(a0), "v"(a1), "v"(v[k][2].w));
-                    m[k] = __float_as_uint(fmaxf(u, a2));
+                for (int mm = 0; mm < 6; ++mm) {
+                    vl[mm] = *reinterpret_cast<const float4*>(ot + lo_off + mm * 256);
+                    vh[mm] = *reinterpret_cast<const float4*>(ot + hi_off + mm * 256);
                 }
+                float mx = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0xB1>(m[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x4E>(m[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x141>(m[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = umax_dpp<0x140>(m[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const auto r = __builtin_amdgcn_permlane16_swap(m[k], m[k], false, false);
-                    const unsigned xm = r[0] > r[1] ? r[0] : r[1];
-                    unsigned e = xm >> 23;
-                    e = e < 15u ? 15u : e;
-                    const float sc = __uint_as_float((268u - e) << 23);      // the row maximum lands in [2^14, 2^15)
-#pragma unroll
-                    for (int qq = 0; qq < 3; ++qq) {
-                        const f32x2 xa = f32x2{v[k][qq].x, v[k][qq].y} * sc, xb = f32x2{v[k][qq].z, v[k][qq].w} * sc;
-                        const f16x2 ha = __builtin_convertvector(xa, f16x2), hb = __builtin_convertvector(xb, f16x2);
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)},
-                                                              rsrc, hoff, k * 8 * 768 + qq * 256, 0);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32((e - 14u) << 23, rsc, soff, k * 32, 0);
+                for (int mm = 0; mm < 6; ++mm) {
+                    float a0, a1;
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a0) : "v"(vl[mm].x), "v"(vl[mm].y), "v"(vl[mm].z));
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a1) : "v"(vl[mm].w), "v"(vh[mm].x), "v"(vh[mm].y));
+                    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(a0) : "v"(a0), "v"(vh[mm].z), "v"(vh[mm].w));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(a0), "v"(a1));
                 }
+                unsigned m = __float_as_uint(mx);
+                m = umax_dpp<0xB1>(m);
+                m = umax_dpp<0x4E>(m);
+                m = umax_dpp<0x141>(m);      // the 8 lanes of the row
+                unsigned e = m >> 23;
+                e = e < 15u ? 15u : e;
+                const float sc = __uint_as_float((268u - e) << 23);      // the row maximum lands in [2^14, 2^15)
+                // All six packed vectors first, in registers of their own, then the stores back to back: a 16-byte store reads
+                // its data registers over many cycles, and a VALU write into them right behind the store (hipcc reuses the
+                // registers of the previous vector; it only pads stores WITHOUT an SGPR offset) corrupted the second dword of
+                // lanes 12..15 of every DPP row (found by tests/test_hip_kernels.py::test_hidden_fp16_plane_*).
+                u32x4 hq[6];
+#pragma unroll
+                for (int mm = 0; mm < 6; ++mm) {
+                    const f32x2 x0 = f32x2{vl[mm].x, vl[mm].y} * sc, x1 = f32x2{vl[mm].z, vl[mm].w} * sc;
+                    const f32x2 x2 = f32x2{vh[mm].x, vh[mm].y} * sc, x3 = f32x2{vh[mm].z, vh[mm].w} * sc;
+                    const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
+                    const f16x2 h2 = __builtin_convertvector(x2, f16x2), h3 = __builtin_convertvector(x3, f16x2);
+                    hq[mm] = u32x4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2),
+                                   __builtin_bit_cast(unsigned, h3)};
+                }
+                unsigned inv = (e - 14u) << 23, so = soff;
+                asm volatile("" : "+v"(hq[0]), "+v"(hq[1]), "+v"(hq[2]), "+v"(hq[3]), "+v"(hq[4]), "+v"(hq[5]), "+v"(inv), "+v"(so));
+#pragma unroll
+                for (int mm = 0; mm < 6; ++mm) __builtin_amdgcn_raw_buffer_store_b128(hq[mm], rsrc, hoff, mm * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(inv, rsc, so, 0, 0);
+                asm volatile("s_nop 15" ::: "memory");
             } else {
                 const int64_t left = (R - r0) * 1536;
                 const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
@@ -372,9 +386,18 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int bit = (rb * 3 + cb) * 4 + i;
-                        newbits |= (v[i] > 0.f ? 1u : 0u) << bit;
-                        v[i] = __uint_as_float((__float_as_uint(fmaxf(v[i], 0.f)) & relu_sel) | (__float_as_uint(v[i]) & ~relu_sel));
-                        v[i] = (bits >> bit) & 1u ? v[i] : 0.f;
+                        if (MODE == 1) {
+                            newbits |= v[i] > 0.f ? (1u << bit) : 0u;
+                            v[i] = fmaxf(v[i], 0.f);
+                        } else if (MODE == 2) {
+                            // bit -> 0 / ~0 (one v_bfe_i32), and: no compare, no select
+                            const int keep = __builtin_amdgcn_sbfe(static_cast<int>(bits), bit, 1);
+                            v[i] = __uint_as_float(__float_as_uint(v[i]) & static_cast<unsigned>(keep));
+                        } else {
+                            newbits |= (v[i] > 0.f ? 1u : 0u) << bit;
+                            v[i] = __uint_as_float((__float_as_uint(fmaxf(v[i], 0.f)) & relu_sel) | (__float_as_uint(v[i]) & ~relu_sel));
+                            v[i] = (bits >> bit) & 1u ? v[i] : 0.f;
+                        }
                     }
                     const int slot = (c0 >> 2) ^ (row & 7);
                     *reinterpret_cast<float4*>(ot + row * 1536 + slot * 16) = make_float4(v[0], v[1], v[2], v[3]);
@@ -397,17 +420,35 @@ struct Pending {
 };
 thread_local Pending g_rider;
 
+// the epilogue form a problem can take (see MODE); a launch of two problems needs the same form and output storage for both
+int mode_of(const Prob& p) {
+    if (p.ep.relu && !p.ep.mask_bits) return 1;
+    if (!p.ep.relu && p.ep.mask_bits && !p.ep.relu_bits && !p.ep.bias) return 2;
+    return 0;
+}
+bool same_kernel(const Prob& a, const Prob& b) { return (a.yscale != nullptr) == (b.yscale != nullptr) && mode_of(a) == mode_of(b); }
+
 int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
     const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
     int nb0, nb1;
     pair_split(st0, st1, 256, &nb0, &nb1);
-    if (p0.yscale) {
-        DG_OPT_IN_LDS((&row_gemm_n384_kernel<true>), kLds);
-        hipLaunchKernelGGL(row_gemm_n384_kernel<true>, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
-    } else {
-        DG_OPT_IN_LDS((&row_gemm_n384_kernel<false>), kLds);
-        hipLaunchKernelGGL(row_gemm_n384_kernel<false>, dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, p1 ? *p1 : p0, nb0);
+    const int mode = mode_of(p0);
+#define DG_N384_LAUNCH(H16_, MODE_)                                                                                      \
+    {                                                                                                                    \
+        DG_OPT_IN_LDS((&row_gemm_n384_kernel<H16_, MODE_>), kLds);                                                       \
+        hipLaunchKernelGGL((row_gemm_n384_kernel<H16_, MODE_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
+                           p1 ? *p1 : p0, nb0);                                                                          \
     }
+    if (p0.yscale) {
+        if (mode == 1) DG_N384_LAUNCH(true, 1)
+        else if (mode == 2) DG_N384_LAUNCH(true, 2)
+        else DG_N384_LAUNCH(true, 0)
+    } else {
+        if (mode == 1) DG_N384_LAUNCH(false, 1)
+        else if (mode == 2) DG_N384_LAUNCH(false, 2)
+        else DG_N384_LAUNCH(false, 0)
+    }
+#undef DG_N384_LAUNCH
     return 0;
 }
 }  // namespace
@@ -429,8 +470,8 @@ int launch_row_gemm_n384(const float* a, const void* packed, void* y, float* ysc
     }
     if (g_rider.valid) {
         g_rider.valid = false;
-        if ((g_rider.p.yscale != nullptr) == (yscale != nullptr)) return launch(p, &g_rider.p, stream);
-        if (int st = launch(g_rider.p, nullptr, stream)) return st;      // another output format: on its own, first
+        if (same_kernel(p, g_rider.p)) return launch(p, &g_rider.p, stream);
+        if (int st = launch(g_rider.p, nullptr, stream)) return st;      // another output format / epilogue: on its own, first
     }
     return launch(p, nullptr, stream);
 }

@@ -12,8 +12,11 @@ bool wgrad_stream_supported(int N, int K);
 int wgrad_stream_blocks(int64_t R, int N, int K, bool may_wait = false);
 // part_w [blocks][N][K], part_b [blocks][N] (nullable): partial sums, reduced by the caller in a fixed order
 // dy1 / dy2 (N = 384, K = 128 only): dy's three 128-column blocks given as three [R,128] matrices
-int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream, const float* dy1 = nullptr, const float* dy2 = nullptr, bool may_wait = false);
+// hscale != NULL (DG_DTYPE_F32_H16): the 384-wide operand (dy for N = 384, x for K = 384) is one fp16 plane with the inverse row
+// scales hscale [R]; the other operand is float32
+int launch_wgrad_stream(const void* dy, const void* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
+                        hipStream_t stream, const float* dy1 = nullptr, const float* dy2 = nullptr, bool may_wait = false,
+                        const float* hscale = nullptr);
 // launches a problem that is still waiting for its carrier (pair.h)
 int flush_wgrad_stream(hipStream_t stream);
 

@@ -22,6 +22,14 @@
 // A column whose values outgrow its scale (a handful of times per launch) is announced by its producer through a
 // per-stage tag + ratio array in LDS; the consumers leave the hot loop, multiply the accumulators of that column by
 // the exact power-of-two ratio and re-enter.
+//
+// HID instances (DG_DTYPE_F32_H16, include/druggen_hip.h): the 384-wide operand -- dy (HID = 1: dW1 = dh^T x) or x (HID = 2:
+// dW2 = dz^T h) -- arrives as ONE fp16 plane with one inverse power-of-two scale per ROW (row_gemm_n384.hip's H16 output).  The
+// contraction runs over the rows, so the row scale moves to the OTHER operand: sum_r dy[r][n] (s_r xh[r][k]) = sum_r (s_r dy[r][n])
+// xh[r][k], exact (a power of two).  The three producers of the fp16 operand only transpose 8 rows x 4 columns of halves into
+// fragment order (16 v_perm_b32, no maxima, no split, scale 1 for ever: |xh| < 2^15 by construction, 8-byte loads, six stages in
+// flight); the producer of the float32 operand multiplies its rows by s_r in front of its usual running-scale split; the
+// consumers run TWO products per tile pair (the fp16 operand has no lo plane).
 #include "bf16.h"
 #include "wgrad_stream.h"
 #include "pair.h"
@@ -80,18 +88,20 @@ struct ProbW {
     const float* dy1;
     const float* dy2;
     const float* x;
+    const float* hscale;      // HID != 0: inverse row scales [R] of the fp16 operand
     float* part_w;
     float* part_b;
     int64_t R;
 };
 
-template <int NT, int KT, int CN, int CK>
+template <int NT, int KT, int CN, int CK, int HID = 0>
 __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_kernel(const ProbW p0, const ProbW p1, const int nb0) {
     const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
     const float* __restrict__ const dy = second ? p1.dy : p0.dy;
     const float* __restrict__ const dy1 = second ? p1.dy1 : p0.dy1;
     const float* __restrict__ const dy2 = second ? p1.dy2 : p0.dy2;
     const float* __restrict__ const x = second ? p1.x : p0.x;
+    const float* __restrict__ const hscale = second ? p1.hscale : p0.hscale;
     float* __restrict__ const part_w = second ? p1.part_w : p0.part_w;
     float* __restrict__ const part_b = second ? p1.part_b : p0.part_b;
     const int64_t R = second ? p1.R : p0.R;
@@ -104,6 +114,8 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
     constexpr int SR = 8 * RG, SUB = SR / 16;      // rows per stage, 16-row MFMA sub-steps per stage
     static_assert(CN * CK == kConsumers && NT % CN == 0 && KT % CK == 0, "consumer grid");
     static_assert(SR * COLS * 4 == kStageBytes && (LPR == 32 || LPR == 16) && N % CW == 0, "stage geometry");
+    static_assert(HID == 0 || (CW == 128 && ((HID == 1 && N == 384) || (HID == 2 && K == 384))), "fp16 operand: the 384-wide one");
+    constexpr int DEPTH_ALL = HID ? 2 * kDepth : kDepth;      // iterations are padded to whole groups of this
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* const tags = reinterpret_cast<unsigned*>(smem + kHdr);                       // [2][4]
     float* const ratios = reinterpret_cast<float*>(smem + kHdr + 64);                     // [2][COLS]
@@ -116,13 +128,103 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
     const int64_t q = total / nblk, rem = total % nblk;
     const int64_t s_lo = bidx * q + (bidx < rem ? bidx : rem);
     const int T = static_cast<int>(q + (bidx < rem ? 1 : 0));      // >= 1 (workgroups of a problem <= its stages)
-    const int TP = (T + kDepth - 1) / kDepth * kDepth;                    // iterations incl. padding (whole groups of kDepth)
+    const int TP = (T + DEPTH_ALL - 1) / DEPTH_ALL * DEPTH_ALL;          // iterations incl. padding (whole groups)
 
     if (w >= kConsumers) {
         // ------------------------------------------------------------------------------------------ producers
         __builtin_amdgcn_s_setprio(3);
         const int p = w - kConsumers;
         const bool is_dy = p * CW < N;
+        if (HID != 0 && is_dy == (HID == 1)) {
+            // ---- a 128-column chunk of the fp16 operand: transpose into fragment order, nothing else
+            const _Float16* hsrc = reinterpret_cast<const _Float16*>(is_dy ? dy : x);
+            const int coff = is_dy ? p * CW : p * CW - N;
+            const int cq = lane & 31, rg = lane >> 5;
+            const unsigned voff0 = static_cast<unsigned>((8 * rg) * 384 + coff + 4 * cq) * 2u;
+            unsigned wa[4];
+            {
+                const int tile = (p * CW + 4 * cq) >> 5, kh = rg & 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * (cq & 7) + j, pc = c ^ (c >> 3);
+                    wa[j] = static_cast<unsigned>(tile * 2048 + kh * 512 + pc * 16);
+                }
+            }
+            if (lane == 0) {
+                tags[p] = 0u;
+                tags[4 + p] = 0u;
+            }
+            constexpr int D = 2 * kDepth;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 ph[D][8];
+            float psc[D];
+            float4 bsum = f4(0.f);
+            const bool want_b = part_b && is_dy;
+            auto fetch = [&](u32x2 (&set)[8], float& sv, int t) {
+                if (t > T - 1) t = T - 1;
+                const int64_t r0 = (s_lo + t) * SR;
+                const int64_t left = (R - r0) * 768;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<_Float16*>(hsrc) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+                if (want_b) {      // lane l: the inverse scale of row 8 (l >> 5) + (l & 7) of the stage
+                    const int64_t lefts = (R - r0) * 4;
+                    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(hscale) + r0, 0, static_cast<int>(lefts < SR * 4 ? lefts : SR * 4), 0x00020000);
+                    sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, static_cast<unsigned>(8 * rg + (lane & 7)) * 4u, 0, 0));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) set[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff0, i * 768, 0);
+            };
+            auto process = [&](u32x2 (&set)[8], float sv, int t) {
+                char* const st = smem + (t & 1) * kStageBytes;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(set[i]));      // first use behind the previous barrier
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u32x4 hw;
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr)
+                        hw[pr] = __builtin_amdgcn_perm(set[2 * pr + 1][j >> 1], set[2 * pr][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                    if (!(WS_DBG & 4)) *reinterpret_cast<u32x4*>(st + wa[j]) = hw;
+                }
+                if (want_b && t < T) {      // db[n] = sum_r s_r xh[r][n]
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+                        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 32 + i));
+                        const float si = rg ? hi : lo;
+                        const f16x8 hv = __builtin_bit_cast(f16x8, u32x4{set[i][0], set[i][1], 0u, 0u});
+                        bsum.x = fmaf(static_cast<float>(hv[0]), si, bsum.x);
+                        bsum.y = fmaf(static_cast<float>(hv[1]), si, bsum.y);
+                        bsum.z = fmaf(static_cast<float>(hv[2]), si, bsum.z);
+                        bsum.w = fmaf(static_cast<float>(hv[3]), si, bsum.w);
+                    }
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < D; ++u) fetch(ph[u], psc[u], u);
+            process(ph[0], psc[0], 0);
+            fetch(ph[0], psc[0], D);
+            __syncthreads();
+            for (int t = 1; t < TP + 1; t += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    process(ph[(u + 1) % D], psc[(u + 1) % D], t + u);
+                    fetch(ph[(u + 1) % D], psc[(u + 1) % D], t + u + D);
+                    __syncthreads();
+                }
+            }
+            if (rg == 0) st4(fin + p * CW + 4 * cq, f4(1.0f));      // the plane is exact: scale 1
+            __syncthreads();
+            if (want_b) {
+                bsum.x = xor_step<false>(bsum.x, 32);
+                bsum.y = xor_step<false>(bsum.y, 32);
+                bsum.z = xor_step<false>(bsum.z, 32);
+                bsum.w = xor_step<false>(bsum.w, 32);
+                if (rg == 0) st4(part_b + static_cast<size_t>(bidx) * N + p * CW + 4 * cq, bsum);
+            }
+            return;
+        }
         // dy1 / dy2 non-null (N = 384, CW = 128): the three 128-column blocks of dy are three separate [R,128] matrices
         // (dq, dk, dv of an attention block: one launch gives the stacked weight gradient of q / k / v)
         const bool three = dy1 != nullptr && is_dy;
@@ -149,25 +251,45 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         float sc[4] = {8.507059e37f, 8.507059e37f, 8.507059e37f, 8.507059e37f};      // 2^126: nothing seen yet
         float4 bsum = f4(0.f);
         float4 pf[kDepth][8];
+        float psc[kDepth];      // HID: lane l holds the fp16 operand's inverse scale of row 8 (l >> 5) + (l & 7) of the stage
 
         // Stage loads go through a buffer descriptor whose range ends at the last row of the launch: rows past the end
         // read as zeros (no clamping, no tail branch), the eight rows of a lane share ONE offset register (row i is a
         // scalar / immediate offset).  Straight-line on purpose: with branches around the loads hipcc can no longer
         // count how many younger loads may stay in flight and drains the queue (vmcnt(0)) before every split.
-        auto fetch = [&](float4 (&set)[8], int t) {
+        auto fetch = [&](float4 (&set)[8], float& sv, int t) {
             if (t > T - 1) t = T - 1;
             const int64_t r0 = (s_lo + t) * SR;
             const int64_t left = (R - r0) * LD * 4;      // bytes from the stage's first row to the end of the matrix
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(src) + r0 * LD, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
+            if (HID != 0) {      // (in front of the data loads: loads return in order)
+                const int64_t lefts = (R - r0) * 4;
+                const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(hscale) + r0, 0, static_cast<int>(lefts < SR * 4 ? lefts : SR * 4), 0x00020000);
+                sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, static_cast<unsigned>(8 * (lane >> 5) + (lane & 7)) * 4u, 0, 0));
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (WS_DBG & 16) set[i] = f4(static_cast<float>(i + t));
                 else set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff0, i * rowb, 0));
             }
         };
-        auto process = [&](float4 (&set)[8], int t) {
+        auto process = [&](float4 (&set)[8], float sv, int t) {
             const bool live = t < T;
+            if (HID != 0) {
+                // the column sums of dy are sums of the UNSCALED rows; then the rows take the fp16 operand's row scales
+                if (part_b && is_dy && live) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bsum += set[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), 32 + i));
+                    set[i] = (rg ? hi : lo) * set[i];
+                }
+            }
             // column maxima over the stage's rows: 8 in this lane, the rest in the lanes of the other row groups
             float m[4];
 #pragma unroll
@@ -222,27 +344,27 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                     *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
                 }
             }
-            if (part_b && is_dy && live) {
+            if (HID == 0 && part_b && is_dy && live) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bsum += set[i];
             }
         };
-        fetch(pf[0], 0);
-        fetch(pf[1], 1);
-        fetch(pf[2], 2);
-        process(pf[0], 0);
-        fetch(pf[0], 3);
+        fetch(pf[0], psc[0], 0);
+        fetch(pf[1], psc[1], 1);
+        fetch(pf[2], psc[2], 2);
+        process(pf[0], psc[0], 0);
+        fetch(pf[0], psc[0], 3);
         __syncthreads();
         for (int t = 1; t < TP + 1; t += 3) {
             // iteration t writes stage t (the consumers are on stage t - 1) and refills its register set
-            process(pf[1], t);
-            fetch(pf[1], t + 3);
+            process(pf[1], psc[1], t);
+            fetch(pf[1], psc[1], t + 3);
             __syncthreads();
-            process(pf[2], t + 1);
-            fetch(pf[2], t + 4);
+            process(pf[2], psc[2], t + 1);
+            fetch(pf[2], psc[2], t + 4);
             __syncthreads();
-            process(pf[0], t + 2);
-            fetch(pf[0], t + 5);
+            process(pf[0], psc[0], t + 2);
+            fetch(pf[0], psc[0], t + 5);
             __syncthreads();
         }
         // final inverse scales for the consumers' un-scaling; column sums of dy
@@ -305,12 +427,12 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
 #pragma unroll
                     for (int i = 0; i < TN; ++i) {
                         yh[i] = *reinterpret_cast<const f16x8*>(st + off_y + (u * NTILES + i) * 2048);
-                        yl[i] = *reinterpret_cast<const f16x8*>(st + off_y + (u * NTILES + i) * 2048 + 1024);
+                        if (HID != 1) yl[i] = *reinterpret_cast<const f16x8*>(st + off_y + (u * NTILES + i) * 2048 + 1024);
                     }
 #pragma unroll
                     for (int j = 0; j < TK; ++j) {
                         xh[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048);
-                        xl[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048 + 1024);
+                        if (HID != 2) xl[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048 + 1024);
                     }
                 };
                 // the stage's tags first, the first sub-step's fragments right behind them: the tag test then waits for
@@ -336,6 +458,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                         for (int i = 0; i < TN; ++i)
 #pragma unroll
                             for (int j = 0; j < TK; ++j) {
+                                if ((HID == 1 && part == 0) || (HID == 2 && part == 1)) continue;      // no lo plane of the fp16 operand
                                 if (WS_DBG & 1) asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xl[j]), "v"(xh[j]));
                                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? yl[i] : yh[i], part == 1 ? xl[j] : xh[j],
                                                                                        acc[i][j], 0, 0, 0);
@@ -410,15 +533,19 @@ thread_local Pending g_rider;
 int launch(const ProbW& p0, int nb0, const ProbW* p1, int nb1, int N, int K, hipStream_t stream) {
     const int lds = kHdr + 64 + 3 * (N + K) * 4;
     const ProbW& q1 = p1 ? *p1 : p0;
-#define DG_WS_LAUNCH(NT_, KT_, CN_, CK_)                                                                          \
+#define DG_WS_LAUNCH(NT_, KT_, CN_, CK_, HID_)                                                                    \
     {                                                                                                            \
-        DG_OPT_IN_LDS((&wgrad_stream_kernel<NT_, KT_, CN_, CK_>), lds);                                           \
-        hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_>), dim3(nb0 + nb1), dim3(64 * (kConsumers + kProducers)), \
+        DG_OPT_IN_LDS((&wgrad_stream_kernel<NT_, KT_, CN_, CK_, HID_>), lds);                                     \
+        hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_, HID_>), dim3(nb0 + nb1), dim3(64 * (kConsumers + kProducers)), \
                            lds, stream, p0, q1, nb0);                                                            \
     }
-    if (N == 128 && K == 128) DG_WS_LAUNCH(4, 4, 4, 2)
-    else if (N == 384 && K == 128) DG_WS_LAUNCH(12, 4, 4, 2)
-    else if (N == 128 && K == 384) DG_WS_LAUNCH(4, 12, 2, 4)
+    const bool hid = p0.hscale != nullptr;
+    if (hid && p0.dy1) return fail(DG_E_ARG, "wgrad_stream: three dy matrices cannot be combined with an fp16 operand");
+    if (N == 128 && K == 128 && !hid) DG_WS_LAUNCH(4, 4, 4, 2, 0)
+    else if (N == 384 && K == 128 && !hid) DG_WS_LAUNCH(12, 4, 4, 2, 0)
+    else if (N == 128 && K == 384 && !hid) DG_WS_LAUNCH(4, 12, 2, 4, 0)
+    else if (N == 384 && K == 128) DG_WS_LAUNCH(12, 4, 4, 2, 1)
+    else if (N == 128 && K == 384) DG_WS_LAUNCH(4, 12, 2, 4, 2)
     else return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
 #undef DG_WS_LAUNCH
     return 0;
@@ -448,12 +575,13 @@ int flush_wgrad_stream(hipStream_t stream) {
     return launch(g_rider.p, g_rider.blocks, nullptr, 0, g_rider.N, g_rider.K, stream);
 }
 
-int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream, const float* dy1, const float* dy2, bool may_wait) {
+int launch_wgrad_stream(const void* dy, const void* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
+                        hipStream_t stream, const float* dy1, const float* dy2, bool may_wait, const float* hscale) {
     if ((dy1 || dy2) && (!dy1 || !dy2 || N != 384 || K != 128))
         return fail(DG_E_ARG, "wgrad_stream: three dy matrices need N = 384, K = 128");
     if (!wgrad_stream_supported(N, K)) return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
-    const ProbW p{dy, dy1, dy2, x, part_w, part_b, R};
+    if (hscale && N + K != 512) return fail(DG_E_SHAPE, "wgrad_stream: an fp16 operand needs N = 384 or K = 384");
+    const ProbW p{static_cast<const float*>(dy), dy1, dy2, static_cast<const float*>(x), hscale, part_w, part_b, R};
     if (may_wait && pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this shape
         g_rider.valid = true;
         g_rider.p = p;
@@ -464,7 +592,7 @@ int launch_wgrad_stream(const float* dy, const float* x, float* part_w, float* p
     }
     if (g_rider.valid) {
         g_rider.valid = false;
-        if (g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks <= 256)
+        if (g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks <= 256 && (g_rider.p.hscale != nullptr) == (hscale != nullptr))
             return launch(p, blocks, &g_rider.p, g_rider.blocks, N, K, stream);
         if (int st = launch(g_rider.p, g_rider.blocks, nullptr, 0, g_rider.N, g_rider.K, stream)) return st;
     }

@@ -37,9 +37,18 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 223            /* 0.2.6: + riding launches, paired feed-forward entries, float32 fused attention half (forward, backward part 1), discriminator head tail, node embedding */
+#define DG_VERSION 230            /* 0.3.0: + DG_DTYPE_F32_H16 (fp16 hidden tensors of the float32 feed-forward), dg_set_edge_rows */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
+/* float32 activations whose 384-wide feed-forward HIDDEN tensors (h = relu(fc1 x), dh, and their second-order twins:
+ * every [R,384] operand of dg_row_gemm / dg_linear_wgrad / dg_edge_ffn_ln_*) are stored as ONE fp16 plane: row r is
+ * multiplied by the power of two that puts its largest magnitude into [2^14, 2^15), rounded to nearest-even, and the
+ * inverse scale is kept per row.  Layout of such a buffer (dg_hidden_bytes(R, 384, dtype) bytes): [R][384] fp16, then --
+ * at byte offset dg_hidden_scale_offset(R, 384) -- [R] float32 inverse scales.  Element error <= 2^-11 relative (rms
+ * ~2e-4): inside the 1e-3 parity bar of the float32 configuration, and the two dominant kernels move 25-37 % fewer bytes.
+ * Every other activation ([R,128] rows, statistics) stays float32; accepted wherever a call has a 384-wide operand, treated
+ * as DG_DTYPE_F32 elsewhere.                                                                                          */
+#define DG_DTYPE_F32_H16 2
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */
@@ -49,6 +58,10 @@ typedef void* dg_stream_t;        /* hipStream_t */
 
 int         dg_version(void);
 const char* dg_last_error_string(void);
+/* bytes of a [R,H] hidden tensor of the feed-forward for activations of `dtype` (H = 384), and the byte offset of the
+ * inverse row scales inside a DG_DTYPE_F32_H16 buffer (0 for the other dtypes)                                         */
+size_t dg_hidden_bytes(int64_t R, int H, int dtype);
+size_t dg_hidden_scale_offset(int64_t R, int H);
 
 /* ---- graph attention core: src/model/layers.py:119-134 (MHA.forward) --------
  *   s[b,i,j,c] = alpha * q[b,i,c] * k[b,j,c] * (e^2 + e)[b,i,j,c]      (lines 119-125)

@@ -1280,3 +1280,120 @@ def test_node_embedding_all_orders(B, N, E, act):
     lib = _lib().load()
     assert lib.dg_embed_node_chain(zc.data_ptr(), None, None, l1.weight.data_ptr(), None, l2.weight.data_ptr(), None,
                                    out.data_ptr(), out.data_ptr(), 1, 17, 0, torch.cuda.current_stream().cuda_stream) != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# DG_DTYPE_F32_H16: the [R,384] hidden tensors of the float32 feed-forward as one fp16 plane + one inverse scale per row
+# ---------------------------------------------------------------------------------------------------------------------------
+def _h16_chain(R, seed=300, row_scales=None):
+    from druggen_amd import _lib as L, functional as dgf
+    C, H = 128, 384
+    x = _gen((R, C), seed).float().cuda()
+    if row_scales is not None:
+        x = x * row_scales[:, None].cuda()
+    w1 = (_gen((H, C), seed + 1) * 0.1).float().cuda()
+    b1 = (_gen((H,), seed + 2) * (0.0 if row_scales is not None else 1.0)).float().cuda()
+    w2 = (_gen((C, H), seed + 3) * 0.1).float().cuda()
+    b2 = _gen((C,), seed + 4).float().cuda()
+    g, be = (_gen((C,), seed + 5) * 0.1 + 1).float().cuda(), _gen((C,), seed + 6).float().cuda()
+    dz = (_gen((R, C), seed + 7) * 1e-3).float().cuda()
+    pw = lambda w, m: dgf.packed_weight(w, m, torch.float32)
+    return L, dgf, dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, g=g, be=be, dz=dz, pw=pw, C=C, H=H)
+
+
+@pytest.mark.parametrize("R", [1, 15, 16, 17, 33, 1000, 4097, 70000])
+def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R):
+    """128 -> 384 row GEMM writing DG_DTYPE_F32_H16, 384 -> 128 row GEMM and both weight-gradient shapes reading it
+    (reference layers.py:50-53 forward / backward).  (a) every decoded element is within half an fp16 ulp of the float32
+    kernel's value (<= 2^-11 relative, + the denormal floor 2^-25 of the row maximum) and the ReLU bit masks are identical;
+    (b) GIVEN the decoded operand, the readers are float32-class: fp64 over the decoded values at TOL."""
+    L, dgf, t = _h16_chain(R)
+    x, dz, pw, C, H = t["x"], t["dz"], t["pw"], t["C"], t["H"]
+    h32, bits32 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True)
+    h16, bits16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True, code=L.F32_H16)
+    nw = (R + 31) // 32 * 512
+    assert torch.equal(bits32[:nw], bits16[:nw])
+    hd = dgf.hidden_to_float(h16, R)
+    bound = h32.abs() * 2.0 ** -11 + h32.abs().amax(1, keepdim=True) * 2.0 ** -25
+    assert bool(((hd - h32).abs() <= bound).all())
+    hd64 = hd.double().cpu()
+    # readers: the four 384 -> 128 epilogues
+    for res, ln in ((False, False), (True, False), (False, True), (True, True)):
+        out = dgf.row_gemm(h16, pw(t["w2"], 0), H, C, bias=t["b2"], residual=x if res else None,
+                           ln=(t["g"], t["be"], 1e-5) if ln else None, want_pre=ln, R=R)
+        want = hd64 @ t["w2"].double().cpu().t() + t["b2"].double().cpu() + (x.double().cpu() if res else 0.0)
+        if ln:
+            y, mean, rstd, pre = out
+            assert _rel(pre, want) < TOL
+            assert _rel(y, torch.nn.functional.layer_norm(want, (C,), t["g"].double().cpu(), t["be"].double().cpu(), 1e-5)) < TOL
+            assert _rel(mean, want.mean(1)) < TOL
+        else:
+            assert _rel(out, want) < TOL
+    # mask-in writer + dx reader
+    dh16 = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits16, code=L.F32_H16)
+    dh32 = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits32)
+    dhd = dgf.hidden_to_float(dh16, R)
+    assert bool(((dhd - dh32).abs() <= dh32.abs() * 2.0 ** -11 + dh32.abs().amax(1, keepdim=True) * 2.0 ** -25).all())
+    dx = dgf.row_gemm(dh16, pw(t["w1"], 1), H, C, residual=dz, R=R)
+    assert _rel(dx, dz.double().cpu() + dhd.double().cpu() @ t["w1"].double().cpu()) < TOL
+    # weight gradients: dW2 = dz^T h (x operand hidden), dW1 = dh^T x (dy operand hidden), with their bias sums
+    dw2, db2 = dgf._wgrad(dz, h16, True)
+    assert _rel(dw2, dz.double().cpu().t() @ hd64) < TOL and _rel(db2, dz.double().cpu().sum(0)) < TOL
+    dw1, db1 = dgf._wgrad(dh16, x, True)
+    assert _rel(dw1, dhd.double().cpu().t() @ x.double().cpu()) < TOL and _rel(db1, dhd.double().cpu().sum(0)) < TOL
+    # bit-reproducible
+    dw2b, _ = dgf._wgrad(dz, h16, True)
+    assert torch.equal(dw2, dw2b)
+
+
+def test_hidden_fp16_plane_row_scales_cover_the_float32_range():
+    """One power-of-two scale per ROW: rows 2^+-60 apart, an all-zero row and a row whose values span 2^20 keep the
+    per-element bound (relative 2^-11, floor 2^-25 of the row maximum); the 384 -> 128 reader un-scales exactly."""
+    R = 64
+    scales = torch.tensor([2.0 ** ((i * 7) % 121 - 60) for i in range(R)], dtype=torch.float64)
+    scales[5] = 0.0
+    L, dgf, t = _h16_chain(R, seed=340, row_scales=scales.float())
+    x, pw, C, H = t["x"], t["pw"], t["C"], t["H"]
+    x[9] = x[9] * torch.logspace(0, 6, C, base=10.0, device="cuda")       # a heavy-tailed row
+    h32 = dgf.row_gemm(x, pw(t["w1"], 0), C, H)
+    h16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, code=L.F32_H16)
+    hd = dgf.hidden_to_float(h16, R)
+    assert bool(torch.isfinite(hd).all()) and float(hd[5].abs().max()) == 0.0
+    assert bool(((hd - h32).abs() <= h32.abs() * 2.0 ** -11 + h32.abs().amax(1, keepdim=True) * 2.0 ** -25).all())
+    y = dgf.row_gemm(h16, pw(t["w2"], 0), H, C, R=R)
+    want = hd.double().cpu() @ t["w2"].double().cpu().t()
+    err = (y.double().cpu() - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-300)
+    assert float(err.max()) < TOL
+
+
+@pytest.mark.parametrize("Rn,Re", [(360, 70000), (33, 66000)])
+def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re):
+    """Riding launches (pair.h) with DG_DTYPE_F32_H16 operands: row GEMMs bit-identical to separate launches, weight
+    gradients equal to rounding; a float32 rider is never paired with an fp16-plane carrier (launched on its own, first)."""
+    from druggen_amd import _lib as L, functional as dgf
+    ts = [_h16_chain(R, seed=360 + 20 * i)[2] for i, R in enumerate((Rn, Re))]
+    Rs = (Rn, Re)
+
+    def chain(paired):
+        with dgf._pair_launches(ts[0]["x"], on=paired):
+            hs = [dgf.row_gemm(t["x"], t["pw"](t["w1"], 0), 128, 384, bias=t["b1"], relu=True, want_relu_bits=True, code=L.F32_H16) for t in ts]
+            ys = [dgf.row_gemm(h, t["pw"](t["w2"], 0), 384, 128, bias=t["b2"], residual=t["x"], ln=(t["g"], t["be"], 1e-5), want_pre=True,
+                               R=R) for (h, _), t, R in zip(hs, ts, Rs)]
+            dh = [dgf.row_gemm(t["dz"], t["pw"](t["w2"], 1), 128, 384, mask_bits=b, code=L.F32_H16) for (_, b), t in zip(hs, ts)]
+            dx = [dgf.row_gemm(d, t["pw"](t["w1"], 1), 384, 128, residual=t["dz"], R=R) for d, t, R in zip(dh, ts, Rs)]
+            wg = dgf._wgrad_many([(ts[0]["dz"], hs[0][0], True), (ts[1]["dz"], hs[1][0], True), (dh[0], ts[0]["x"], True), (dh[1], ts[1]["x"], True)])
+        return [[hs[i][0], *ys[i], dh[i], dx[i]] for i in range(2)], wg
+
+    sep, wsep = chain(False)
+    par, wpar = chain(True)
+    for a, b in zip(sep, par):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    for (dw, db), (ew, eb) in zip(wsep, wpar):
+        assert _rel(ew, dw.double().cpu()) < 2e-6 and _rel(eb, db.double().cpu()) < 2e-6
+    # mixed storage inside one region: the float32 rider leaves on its own before the fp16-plane launch
+    with dgf._pair_launches(ts[0]["x"]):
+        hn = dgf.row_gemm(ts[0]["x"], ts[0]["pw"](ts[0]["w1"], 0), 128, 384, bias=ts[0]["b1"])
+        he = dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=L.F32_H16)
+    assert torch.equal(hn, dgf.row_gemm(ts[0]["x"], ts[0]["pw"](ts[0]["w1"], 0), 128, 384, bias=ts[0]["b1"]))
+    assert torch.equal(he, dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=L.F32_H16))
