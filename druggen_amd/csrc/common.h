@@ -38,6 +38,21 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- DG_DTYPE_F32_H24: the top 24 bits of a float32 (1 + 8 + 15: 16 significant bits, round half up), 3 bytes per element ----
+// four consecutive elements = 12 bytes = three dwords, little endian
+typedef unsigned dg_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ dg_u32x3 pack_f24x4(float a, float b, float c, float d) {
+    const unsigned ua = __float_as_uint(a) + 0x80u, ub = __float_as_uint(b) + 0x80u, uc = __float_as_uint(c) + 0x80u,
+                   ud = __float_as_uint(d) + 0x80u;
+    // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first
+    return dg_u32x3{__builtin_amdgcn_perm(ub, ua, 0x05030201u), __builtin_amdgcn_perm(uc, ub, 0x06050302u),
+                    __builtin_amdgcn_perm(ud, uc, 0x07060503u)};
+}
+__device__ __forceinline__ float4 unpack_f24x4(dg_u32x3 w) {
+    return make_float4(__uint_as_float(w[0] << 8), __uint_as_float(__builtin_amdgcn_perm(w[1], w[0], 0x0504030Cu)),
+                       __uint_as_float(__builtin_amdgcn_perm(w[2], w[1], 0x0403020Cu)), __uint_as_float(w[2] & 0xFFFFFF00u));
+}
+
 // ---- edge-level threshold (dg_set_edge_rows; runtime.hip) ---------------------
 int64_t edge_rows();
 

@@ -67,30 +67,31 @@ extern "C" int dg_edge_ffn_ln_bwd(const void* x, const void* h, const unsigned* 
     workspace = static_cast<char*>(workspace) + lnb;
     workspace_bytes -= lnb;
     // dh = (dz @ W2) masked by the forward's ReLU bits
+    const int dt_h = ffn_h_dtype(dtype), dt_dh = ffn_dh_dtype(dtype);      // storage of h / of dh (DG_DTYPE_F32_DH16 / _DH24 differ)
     st = dg_row_gemm(dz, w2_dgrad_packed, dh, R, C, H, nullptr, 0, nullptr, relu_bits, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, 0.f, dtype, stream);
+                     nullptr, nullptr, nullptr, 0.f, dt_dh, stream);
     if (!st && dx)   // dx = dz + dh @ W1 (residual path folded into the epilogue)
         st = dg_row_gemm(dh, w1_dgrad_packed, dx, R, H, C, nullptr, 0, nullptr, nullptr, dz, nullptr, nullptr,
-                         nullptr, nullptr, nullptr, 0.f, dtype, stream);
+                         nullptr, nullptr, nullptr, 0.f, dt_dh, stream);
     if (st) {
         if (batch) dg_linear_wgrad_batch_end(stream);
         return st;
     }
     if (batch) {      // two split-K kernels into separate parts of the workspace
         const size_t w2b = (dg_linear_wgrad_workspace_bytes(R, C, H) + 255) / 256 * 256;
-        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, w2b, R, C, H, dtype, stream);
+        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, w2b, R, C, H, dt_h, stream);
         if (!st)
             st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, static_cast<char*>(workspace) + w2b, workspace_bytes - w2b, R, H, C,
-                                 dtype, stream);
+                                 dt_dh, stream);
         const int st2 = dg_linear_wgrad_batch_end(stream);
         return st ? st : st2;
     }
     if (dw2) {
-        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, workspace_bytes, R, C, H, dtype, stream);
+        st = dg_linear_wgrad(dz, nullptr, h, dw2, db2, workspace, workspace_bytes, R, C, H, dt_h, stream);
         if (st) return st;
     }
     if (dw1) {
-        st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, workspace, workspace_bytes, R, H, C, dtype, stream);
+        st = dg_linear_wgrad(dh, nullptr, x, dw1, db1, workspace, workspace_bytes, R, H, C, dt_dh, stream);
         if (st) return st;
     }
     return 0;
@@ -119,18 +120,18 @@ int ffn_bwd_phase(const dg_ffn_bwd_args& a, int phase, int C, int H, int dtype, 
                                           lnb, R, C, act_dtype(dtype), stream);
         case 1:      // dh = (dz W2) masked by the forward's ReLU bits
             return dg_row_gemm(a.dz, a.w2_dgrad_packed, a.dh, R, C, H, nullptr, 0, nullptr, a.relu_bits, nullptr, nullptr,
-                               nullptr, nullptr, nullptr, nullptr, 0.f, dtype, stream);
+                               nullptr, nullptr, nullptr, nullptr, 0.f, ffn_dh_dtype(dtype), stream);
         case 2:      // dx = dz + dh W1
             if (!a.dx) return 0;
             return dg_row_gemm(a.dh, a.w1_dgrad_packed, a.dx, R, H, C, nullptr, 0, nullptr, nullptr, a.dz, nullptr, nullptr,
-                               nullptr, nullptr, nullptr, 0.f, dtype, stream);
+                               nullptr, nullptr, nullptr, 0.f, ffn_dh_dtype(dtype), stream);
         case 3:      // dW2, db2 = dz^T h, sum dz
             if (!a.dw2) return 0;
-            return dg_linear_wgrad(a.dz, nullptr, a.h, a.dw2, a.db2, ws + lnb, w2b, R, C, H, dtype, stream);
+            return dg_linear_wgrad(a.dz, nullptr, a.h, a.dw2, a.db2, ws + lnb, w2b, R, C, H, ffn_h_dtype(dtype), stream);
         default:     // dW1, db1 = dh^T x, sum dh
             if (!a.dw1) return 0;
-            return dg_linear_wgrad(a.dh, nullptr, a.x, a.dw1, a.db1, ws + lnb + w2b, a.workspace_bytes - lnb - w2b, R, H, C, dtype,
-                                   stream);
+            return dg_linear_wgrad(a.dh, nullptr, a.x, a.dw1, a.db1, ws + lnb + w2b, a.workspace_bytes - lnb - w2b, R, H, C,
+                                   ffn_dh_dtype(dtype), stream);
     }
 }
 

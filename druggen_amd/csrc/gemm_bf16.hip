@@ -42,7 +42,7 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
                  unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
                  const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream,
-                 const float* ascale = nullptr, float* yscale = nullptr);
+                 const float* ascale = nullptr, float* yscale = nullptr, int afmt = 0, int yfmt = 0);
 
 namespace {
 
@@ -347,7 +347,7 @@ extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R
         return row_gemm_bf16(static_cast<const bf16_t*>(a), packed, static_cast<bf16_t*>(y), R, K, N, bias, relu,
                              relu_bits_out, mask_bits, static_cast<const bf16_t*>(residual), gamma, beta, mean, rstd,
                              static_cast<bf16_t*>(pre_ln), eps, static_cast<hipStream_t>(stream_));
-    if (dtype != DG_DTYPE_F32 && dtype != DG_DTYPE_F32_H16) return fail(DG_E_ARG, "dg_row_gemm: unknown dtype %d", dtype);
+    if (act_dtype(dtype) != DG_DTYPE_F32) return fail(DG_E_ARG, "dg_row_gemm: unknown dtype %d", dtype);
     // DG_DTYPE_F32_H16: the 384-wide operand (a for K = 384, y for N = 384) is an fp16 plane + inverse row scales
     const float* ascale = nullptr;
     float* yscale = nullptr;
@@ -356,7 +356,8 @@ extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R
     if (dtype == DG_DTYPE_F32_H16 && N == 384) yscale = reinterpret_cast<float*>(static_cast<char*>(y) + hidden_scale_offset(R, 384));
     return row_gemm_f32(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y), R, K, N,
                         bias, relu, relu_bits_out, mask_bits, static_cast<const float*>(residual), gamma, beta, mean, rstd,
-                        static_cast<float*>(pre_ln), eps, stream_, ascale, yscale);
+                        static_cast<float*>(pre_ln), eps, stream_, ascale, yscale, K == 384 ? hidden_fmt(dtype) : 0,
+                        N == 384 ? hidden_fmt(dtype) : 0);
 }
 
 extern "C" size_t dg_hidden_scale_offset(int64_t R, int H) { return R < 0 || H < 1 ? 0 : hidden_scale_offset(R, H); }
@@ -364,6 +365,7 @@ extern "C" size_t dg_hidden_scale_offset(int64_t R, int H) { return R < 0 || H <
 extern "C" size_t dg_hidden_bytes(int64_t R, int H, int dtype) {
     if (R < 0 || H < 1) return 0;
     if (dtype == DG_DTYPE_F32_H16) return hidden_scale_offset(R, H) + static_cast<size_t>(R) * 4;
+    if (dtype == DG_DTYPE_F32_H24) return static_cast<size_t>(R) * H * 3;
     return static_cast<size_t>(R) * H * dtype_size(dtype);
 }
 

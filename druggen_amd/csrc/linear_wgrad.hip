@@ -787,10 +787,12 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     if (!dy_ || !x_ || !dw || !workspace) return fail(DG_E_ARG, "dg_linear_wgrad: null pointer");
     // DG_DTYPE_F32_H16: the 384-wide operand (dy for N = 384, x for K = 384) is an fp16 plane + inverse row scales
     const float* hscale = nullptr;
-    if (dtype == DG_DTYPE_F32_H16) {
-        if (N == 384 && K == 128) hscale = reinterpret_cast<const float*>(static_cast<const char*>(dy_) + hidden_scale_offset(R, 384));
-        if (N == 128 && K == 384) hscale = reinterpret_cast<const float*>(static_cast<const char*>(x_) + hidden_scale_offset(R, 384));
-        if (hscale && dy_mask_) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask cannot be combined with DG_DTYPE_F32_H16");
+    int hfmt = 0;
+    if (dtype == DG_DTYPE_F32_H16 || dtype == DG_DTYPE_F32_H24) {
+        const bool narrow = (N == 384 && K == 128) || (N == 128 && K == 384);
+        if (narrow) hfmt = hidden_fmt(dtype);
+        if (hfmt == 1) hscale = reinterpret_cast<const float*>(static_cast<const char*>(N == 384 ? dy_ : x_) + hidden_scale_offset(R, 384));
+        if (hfmt && dy_mask_) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask cannot be combined with DG_DTYPE_F32_H16 / _H24");
         dtype = DG_DTYPE_F32;
     }
     if (!dtype_ok(dtype)) return fail(DG_E_ARG, "dg_linear_wgrad: unknown dtype %d", dtype);
@@ -818,8 +820,8 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
         return !(e && strcmp(e, "sym") == 0);
     }();
     const bool use_stream = !bf && split == 2 && stream_kernel && !dy_mask_ && wgrad_stream_supported(N, K);
-    if (hscale && !use_stream)
-        return fail(DG_E_ARG, "dg_linear_wgrad: DG_DTYPE_F32_H16 needs the producer / consumer weight-gradient kernel (DG_WGRAD selects another)");
+    if (hfmt && !use_stream)
+        return fail(DG_E_ARG, "dg_linear_wgrad: DG_DTYPE_F32_H16 / _H24 needs the producer / consumer weight-gradient kernel (DG_WGRAD selects another)");
     int tpb;
     const bool may_wait = g_batch_on && g_batch_n < 8;      // (a launch may only wait for a carrier when its reduce is deferred too)
     const int S = use_stream ? wgrad_stream_blocks(R, N, K, may_wait)
@@ -830,7 +832,7 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     ProfScope prof(wgrad_prof_key(R, N, K), stream);
     note_forward(R);
     if (use_stream) {
-        if (int st = launch_wgrad_stream(dy_, x_, part_w, part_b, R, N, K, S, stream, nullptr, nullptr, may_wait, hscale))
+        if (int st = launch_wgrad_stream(dy_, x_, part_w, part_b, R, N, K, S, stream, nullptr, nullptr, may_wait, hscale, hfmt))
             return st;
     } else {
 #define LAUNCH_X(T, NT_, KT_, WN_, WK_, TR_, M_, X_)                                                              \

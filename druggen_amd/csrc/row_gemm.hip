@@ -1654,9 +1654,9 @@ size_t row_gemm_f32_mask_words(int64_t R, int K, int N) {
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias,
                            int relu, unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual,
                            const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
-                           float eps, dg_stream_t stream_, const float* ascale, float* yscale) {
+                           float eps, dg_stream_t stream_, const float* ascale, float* yscale, int afmt, int yfmt) {
     if (!a || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm: null pointer");
-    if ((ascale && K != 384) || (yscale && N != 384)) return fail(DG_E_ARG, "dg_row_gemm: fp16 hidden operands are the 384-wide ones");
+    if ((afmt && K != 384) || (yfmt && N != 384)) return fail(DG_E_ARG, "dg_row_gemm: narrow hidden operands are the 384-wide ones");
     if (R < 0 || !((K == 128 && (N == 128 || N == 384)) || (K == 384 && N == 128)))
         return fail(DG_E_SHAPE, "dg_row_gemm: unsupported K=%d N=%d (supported: 128x128, 128x384, 384x128)", K, N);
     if (gamma && (N != 128 || !beta || !mean || !rstd))
@@ -1691,19 +1691,19 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         // kernels (A/B measurements).  The three write their ReLU bit masks in layouts of their own: a process uses one.
         static const bool pc_n = !getenv("DG_GEMM_N384") || strcmp(getenv("DG_GEMM_N384"), "pc") == 0;
         if (K == 128 && N == 384 && pc_n) {
-            if (int st = launch_row_gemm_n384(a, packed, y, yscale, R, bias, relu, relu_bits_out, mask_bits, stream)) return st;
+            if (int st = launch_row_gemm_n384(a, packed, y, yscale, R, bias, relu, relu_bits_out, mask_bits, stream, yfmt)) return st;
             return check_launch("dg_row_gemm");
         }
         // 384 -> 128: producer / consumer kernel (row_gemm_k384.hip) by default; DG_GEMM_K384=paired selects the round-2/3
         // kernel (two tiles per B set, epilogue in the mover waves) for A/B measurements
         static const bool pc_k = !getenv("DG_GEMM_K384") || strcmp(getenv("DG_GEMM_K384"), "pc") == 0;
         if (K == 384 && pc_k) {
-            if (int st = launch_row_gemm_k384(a, ascale, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream))
+            if (int st = launch_row_gemm_k384(a, ascale, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream, afmt))
                 return st;
             return check_launch("dg_row_gemm");
         }
-        if (ascale || yscale)
-            return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 needs the producer / consumer 384-wide kernels (DG_GEMM_N384 / DG_GEMM_K384 select older ones)");
+        if (afmt || yfmt)
+            return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 / _H24 needs the producer / consumer 384-wide kernels (DG_GEMM_N384 / DG_GEMM_K384 select older ones)");
         if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)
             constexpr int lds6 = kH3Lds + 6 * 32 * 32 * 4;
             DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), lds6);
@@ -1732,7 +1732,7 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
 #undef LAUNCH6
         return check_launch("dg_row_gemm");
     }
-    if (ascale || yscale) return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 needs the fp16 hi + lo row GEMMs (DG_ROW_GEMM=mfma32 is set)");
+    if (afmt || yfmt) return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 / _H24 needs the fp16 hi + lo row GEMMs (DG_ROW_GEMM=mfma32 is set)");
 #define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_) LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, false)
 #define LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, XP_)                                               \
     {                                                                                                              \

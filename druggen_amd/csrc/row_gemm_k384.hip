@@ -104,16 +104,18 @@ struct EpiK {
 // One problem of a launch; workgroups [0, nb0) run problem 0, the others problem 1 (a node-level GEMM riding in the
 // edge-level launch of the same kernel: pair.h, row_gemm_n384.hip).
 struct ProbK {
-    const float* a;           // [R,384] float32, or (H16) [R,384] fp16
+    const float* a;           // [R,384] float32, or (H16) [R,384] fp16, or (afmt 2) [R,384] 3-byte elements (DG_DTYPE_F32_H24)
     const float* ascale;      // H16: inverse row scales [R]
+    int afmt;                 // 0 float32, 1 H16, 2 H24
     const f16x8* packed;
     float* y;
     int64_t R;
     EpiK ep;
 };
 
-template <bool RES, bool LN, bool H16>
+template <bool RES, bool LN, int FMT>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const ProbK p0, const ProbK p1, const int nb0) {
+    constexpr bool H16 = FMT == 1, H24 = FMT == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
@@ -179,6 +181,20 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
                 return;
             }
             const int64_t r0 = stage_of(t) * kSR;
+            if (H24) {      // 12 bytes per lane and piece: four 3-byte elements, unpacked in split()
+                const int64_t left = (R - r0) * 1152;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<char*>(const_cast<float*>(a)) + r0 * 1152, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)),
+                    0x00020000);
+                if (K3_DBG & 8) return;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const dg_u32x3 w = __builtin_amdgcn_raw_buffer_load_b96(rsrc, static_cast<unsigned>(hw) * 2304u + static_cast<unsigned>(l32) * 12u,
+                                                                             i * 384, 0);
+                    set[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), 0.f);
+                }
+                return;
+            }
             const int64_t left = (R - r0) * 1536;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
@@ -212,6 +228,13 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
                     *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__float_as_uint(set[i].z), __float_as_uint(set[i].w)};
                 }
                 return;
+            }
+            if (H24) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    asm volatile("" : "+v"(set[i].x), "+v"(set[i].y), "+v"(set[i].z));      // first use behind the previous barrier
+                    set[i] = unpack_f24x4(dg_u32x3{__float_as_uint(set[i].x), __float_as_uint(set[i].y), __float_as_uint(set[i].z)});
+                }
             }
             unsigned m[6];
 #pragma unroll
@@ -450,7 +473,7 @@ struct Pending {
 thread_local Pending g_rider;
 
 // the kernel variant a problem needs: residual and LayerNorm epilogues are template parameters
-int variant(const ProbK& p) { return (p.ep.residual ? 1 : 0) + (p.ep.gamma ? 2 : 0) + (p.ascale ? 4 : 0); }
+int variant(const ProbK& p) { return (p.ep.residual ? 1 : 0) + (p.ep.gamma ? 2 : 0) + 4 * p.afmt; }
 
 int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
     const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
@@ -464,14 +487,18 @@ int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
                            q1, nb0);                                                                               \
     }
     switch (variant(p0)) {
-        case 3: DG_K384_LAUNCH(true, true, false) break;
-        case 1: DG_K384_LAUNCH(true, false, false) break;
-        case 2: DG_K384_LAUNCH(false, true, false) break;
-        case 7: DG_K384_LAUNCH(true, true, true) break;
-        case 5: DG_K384_LAUNCH(true, false, true) break;
-        case 6: DG_K384_LAUNCH(false, true, true) break;
-        case 4: DG_K384_LAUNCH(false, false, true) break;
-        default: DG_K384_LAUNCH(false, false, false) break;
+        case 3: DG_K384_LAUNCH(true, true, 0) break;
+        case 1: DG_K384_LAUNCH(true, false, 0) break;
+        case 2: DG_K384_LAUNCH(false, true, 0) break;
+        case 7: DG_K384_LAUNCH(true, true, 1) break;
+        case 5: DG_K384_LAUNCH(true, false, 1) break;
+        case 6: DG_K384_LAUNCH(false, true, 1) break;
+        case 4: DG_K384_LAUNCH(false, false, 1) break;
+        case 11: DG_K384_LAUNCH(true, true, 2) break;
+        case 9: DG_K384_LAUNCH(true, false, 2) break;
+        case 10: DG_K384_LAUNCH(false, true, 2) break;
+        case 8: DG_K384_LAUNCH(false, false, 2) break;
+        default: DG_K384_LAUNCH(false, false, 0) break;
     }
 #undef DG_K384_LAUNCH
     return 0;
@@ -486,8 +513,9 @@ int flush_row_gemm_k384(hipStream_t stream) {
 
 int launch_row_gemm_k384(const void* a, const float* ascale, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
-                         float* pre_ln, float eps, hipStream_t stream) {
-    const ProbK p{static_cast<const float*>(a), ascale, static_cast<const f16x8*>(packed), y, R,
+                         float* pre_ln, float eps, hipStream_t stream, int afmt) {
+    if ((afmt == 1) != (ascale != nullptr)) return fail(DG_E_ARG, "row_gemm_k384: row scales go with the fp16 plane (afmt 1)");
+    const ProbK p{static_cast<const float*>(a), ascale, afmt, static_cast<const f16x8*>(packed), y, R,
                   EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;

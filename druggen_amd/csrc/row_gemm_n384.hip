@@ -83,8 +83,9 @@ struct Epi {
 struct Prob {
     const float* a;
     const f16x8* packed;
-    float* y;             // [R,384] float32, or (H16) [R,384] fp16
+    float* y;             // [R,384] float32, or (H16) [R,384] fp16, or (yfmt 2) [R,384] 3-byte elements
     float* yscale;        // H16: inverse row scales [R]
+    int yfmt;             // 0 float32, 1 H16, 2 H24 (DG_DTYPE_F32_H24: top 24 bits of every float32)
     int64_t R;
     Epi ep;
 };
@@ -93,8 +94,9 @@ struct Prob {
 // bits out, no mask in; 2 its twin in the backward -- mask in only (dh = (dz W2) * m).  The generic form spends ~8 vector
 // instructions per element on selects whose conditions are launch constants (and a wait state per v_cmp -> v_cndmask pair); the
 // two hot forms need 3 and 2.
-template <bool H16, int MODE>
+template <int FMT, int MODE>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
+    constexpr bool H16 = FMT == 1, H24 = FMT == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
@@ -271,6 +273,24 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                 for (int mm = 0; mm < 6; ++mm) __builtin_amdgcn_raw_buffer_store_b128(hq[mm], rsrc, hoff, mm * 128, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(inv, rsc, so, 0, 0);
                 asm volatile("s_nop 15" ::: "memory");
+            } else if (H24) {
+                // three bytes per element: the float32 path with 12-byte stores (all packed vectors first: see the note above)
+                const int64_t left = (R - r0) * 1152;
+                const int bytes = ok ? static_cast<int>(left < kSR * 1152 ? left : kSR * 1152) : 0;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(y) + r0 * 1152, 0, bytes, 0x00020000);
+                const unsigned g24 = static_cast<unsigned>(hw) * 1152u + static_cast<unsigned>(l32 ^ hw) * 12u;
+                dg_u32x3 pk[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const int k = i / 3, qq = i % 3;
+                    const float4 v = *reinterpret_cast<const float4*>(ot + ooff + k * 8 * 1536 + qq * 512);
+                    pk[i] = pack_f24x4(v.x, v.y, v.z, v.w);
+                }
+                asm volatile("" : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]),
+                             "+v"(pk[8]), "+v"(pk[9]), "+v"(pk[10]), "+v"(pk[11]));
+#pragma unroll
+                for (int i = 0; i < 12; ++i) __builtin_amdgcn_raw_buffer_store_b96(pk[i], rsrc, g24, (i / 3) * 8 * 1152 + (i % 3) * 384, 0);
+                asm volatile("s_nop 15" ::: "memory");
             } else {
                 const int64_t left = (R - r0) * 1536;
                 const int bytes = ok ? static_cast<int>(left < kSR * 1536 ? left : kSR * 1536) : 0;      // 0: every store is dropped
@@ -426,27 +446,31 @@ int mode_of(const Prob& p) {
     if (!p.ep.relu && p.ep.mask_bits && !p.ep.relu_bits && !p.ep.bias) return 2;
     return 0;
 }
-bool same_kernel(const Prob& a, const Prob& b) { return (a.yscale != nullptr) == (b.yscale != nullptr) && mode_of(a) == mode_of(b); }
+bool same_kernel(const Prob& a, const Prob& b) { return a.yfmt == b.yfmt && mode_of(a) == mode_of(b); }
 
 int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
     const int64_t st0 = (p0.R + kSR - 1) / kSR, st1 = p1 ? (p1->R + kSR - 1) / kSR : 0;
     int nb0, nb1;
     pair_split(st0, st1, 256, &nb0, &nb1);
     const int mode = mode_of(p0);
-#define DG_N384_LAUNCH(H16_, MODE_)                                                                                      \
+#define DG_N384_LAUNCH(H16_, MODE_)                                                                                     \
     {                                                                                                                    \
         DG_OPT_IN_LDS((&row_gemm_n384_kernel<H16_, MODE_>), kLds);                                                       \
         hipLaunchKernelGGL((row_gemm_n384_kernel<H16_, MODE_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
                            p1 ? *p1 : p0, nb0);                                                                          \
     }
-    if (p0.yscale) {
-        if (mode == 1) DG_N384_LAUNCH(true, 1)
-        else if (mode == 2) DG_N384_LAUNCH(true, 2)
-        else DG_N384_LAUNCH(true, 0)
+    if (p0.yfmt == 1) {
+        if (mode == 1) DG_N384_LAUNCH(1, 1)
+        else if (mode == 2) DG_N384_LAUNCH(1, 2)
+        else DG_N384_LAUNCH(1, 0)
+    } else if (p0.yfmt == 2) {
+        if (mode == 1) DG_N384_LAUNCH(2, 1)
+        else if (mode == 2) DG_N384_LAUNCH(2, 2)
+        else DG_N384_LAUNCH(2, 0)
     } else {
-        if (mode == 1) DG_N384_LAUNCH(false, 1)
-        else if (mode == 2) DG_N384_LAUNCH(false, 2)
-        else DG_N384_LAUNCH(false, 0)
+        if (mode == 1) DG_N384_LAUNCH(0, 1)
+        else if (mode == 2) DG_N384_LAUNCH(0, 2)
+        else DG_N384_LAUNCH(0, 0)
     }
 #undef DG_N384_LAUNCH
     return 0;
@@ -460,8 +484,9 @@ int flush_row_gemm_n384(hipStream_t stream) {
 }
 
 int launch_row_gemm_n384(const float* a, const void* packed, void* y, float* yscale, int64_t R, const float* bias, int relu,
-                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream) {
-    const Prob p{a, static_cast<const f16x8*>(packed), static_cast<float*>(y), yscale, R,
+                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream, int yfmt) {
+    if ((yfmt == 1) != (yscale != nullptr)) return fail(DG_E_ARG, "row_gemm_n384: row scales go with the fp16 plane (yfmt 1)");
+    const Prob p{a, static_cast<const f16x8*>(packed), static_cast<float*>(y), yscale, yfmt, R,
                  Epi{bias, mask_bits, relu_bits, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;

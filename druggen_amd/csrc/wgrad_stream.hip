@@ -88,7 +88,8 @@ struct ProbW {
     const float* dy1;
     const float* dy2;
     const float* x;
-    const float* hscale;      // HID != 0: inverse row scales [R] of the fp16 operand
+    const float* hscale;      // hfmt 1: inverse row scales [R] of the fp16 operand
+    int hfmt;                 // storage of the 384-wide operand: 0 float32, 1 fp16 plane + row scales, 2 three-byte elements
     float* part_w;
     float* part_b;
     int64_t R;
@@ -114,8 +115,12 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
     constexpr int SR = 8 * RG, SUB = SR / 16;      // rows per stage, 16-row MFMA sub-steps per stage
     static_assert(CN * CK == kConsumers && NT % CN == 0 && KT % CK == 0, "consumer grid");
     static_assert(SR * COLS * 4 == kStageBytes && (LPR == 32 || LPR == 16) && N % CW == 0, "stage geometry");
-    static_assert(HID == 0 || (CW == 128 && ((HID == 1 && N == 384) || (HID == 2 && K == 384))), "fp16 operand: the 384-wide one");
-    constexpr int DEPTH_ALL = HID ? 2 * kDepth : kDepth;      // iterations are padded to whole groups of this
+    // HID 3 / 4 (DG_DTYPE_F32_H24): dy / x holds the top 24 bits of every float32 (3 bytes per element): the producers of those
+    // columns fetch 12 bytes per row instead of 16 and unpack; everything else is the float32 kernel
+    static_assert(HID == 0 || (CW == 128 && (((HID == 1 || HID == 3) && N == 384) || ((HID == 2 || HID == 4) && K == 384))),
+                  "narrow operand: the 384-wide one");
+    constexpr bool HS = HID == 1 || HID == 2;                 // fp16 plane + row scales
+    constexpr int DEPTH_ALL = HS ? 2 * kDepth : kDepth;       // iterations are padded to whole groups of this
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* const tags = reinterpret_cast<unsigned*>(smem + kHdr);                       // [2][4]
     float* const ratios = reinterpret_cast<float*>(smem + kHdr + 64);                     // [2][COLS]
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         __builtin_amdgcn_s_setprio(3);
         const int p = w - kConsumers;
         const bool is_dy = p * CW < N;
-        if (HID != 0 && is_dy == (HID == 1)) {
+        if (HS && is_dy == (HID == 1)) {
             // ---- a 128-column chunk of the fp16 operand: transpose into fragment order, nothing else
             const _Float16* hsrc = reinterpret_cast<const _Float16*>(is_dy ? dy : x);
             const int coff = is_dy ? p * CW : p * CW - N;
@@ -232,8 +237,9 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         const int LD = three ? 128 : (is_dy ? N : K);
         const int coff = three ? 0 : (is_dy ? p * CW : p * CW - N);
         const int cq = lane % LPR, rg = lane / LPR;
-        const unsigned voff0 = static_cast<unsigned>((8 * rg) * LD + coff + 4 * cq) * 4u;
-        const int rowb = LD * 4;
+        const bool f24 = (HID == 3 && is_dy) || (HID == 4 && !is_dy);      // this producer's columns are 3-byte elements
+        const unsigned voff0 = static_cast<unsigned>((8 * rg) * LD + coff + 4 * cq) * (f24 ? 3u : 4u);
+        const int rowb = LD * (f24 ? 3 : 4);
         // LDS byte offsets of this lane's four columns inside a stage (hi plane; lo plane = + 1024)
         unsigned wa[4];
         {
@@ -260,10 +266,19 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         auto fetch = [&](float4 (&set)[8], float& sv, int t) {
             if (t > T - 1) t = T - 1;
             const int64_t r0 = (s_lo + t) * SR;
-            const int64_t left = (R - r0) * LD * 4;      // bytes from the stage's first row to the end of the matrix
+            const int64_t left = (R - r0) * rowb;      // bytes from the stage's first row to the end of the matrix
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(src) + r0 * LD, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)), 0x00020000);
-            if (HID != 0) {      // (in front of the data loads: loads return in order)
+                reinterpret_cast<char*>(const_cast<float*>(src)) + r0 * rowb, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)),
+                0x00020000);
+            if (HID >= 3 && f24) {      // (wave-uniform) 12 bytes per row: unpacked in process()
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const dg_u32x3 w = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff0, i * rowb, 0);
+                    set[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), 0.f);
+                }
+                return;
+            }
+            if (HS) {      // (in front of the data loads: loads return in order)
                 const int64_t lefts = (R - r0) * 4;
                 const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(hscale) + r0, 0, static_cast<int>(lefts < SR * 4 ? lefts : SR * 4), 0x00020000);
@@ -277,7 +292,14 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
         };
         auto process = [&](float4 (&set)[8], float sv, int t) {
             const bool live = t < T;
-            if (HID != 0) {
+            if (HID >= 3 && f24) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    asm volatile("" : "+v"(set[i].x), "+v"(set[i].y), "+v"(set[i].z));
+                    set[i] = unpack_f24x4(dg_u32x3{__float_as_uint(set[i].x), __float_as_uint(set[i].y), __float_as_uint(set[i].z)});
+                }
+            }
+            if (HS) {
                 // the column sums of dy are sums of the UNSCALED rows; then the rows take the fp16 operand's row scales
                 if (part_b && is_dy && live) {
 #pragma unroll
@@ -344,7 +366,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                     *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
                 }
             }
-            if (HID == 0 && part_b && is_dy && live) {
+            if (!HS && part_b && is_dy && live) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bsum += set[i];
             }
@@ -539,13 +561,15 @@ int launch(const ProbW& p0, int nb0, const ProbW* p1, int nb1, int N, int K, hip
         hipLaunchKernelGGL((wgrad_stream_kernel<NT_, KT_, CN_, CK_, HID_>), dim3(nb0 + nb1), dim3(64 * (kConsumers + kProducers)), \
                            lds, stream, p0, q1, nb0);                                                            \
     }
-    const bool hid = p0.hscale != nullptr;
-    if (hid && p0.dy1) return fail(DG_E_ARG, "wgrad_stream: three dy matrices cannot be combined with an fp16 operand");
-    if (N == 128 && K == 128 && !hid) DG_WS_LAUNCH(4, 4, 4, 2, 0)
-    else if (N == 384 && K == 128 && !hid) DG_WS_LAUNCH(12, 4, 4, 2, 0)
-    else if (N == 128 && K == 384 && !hid) DG_WS_LAUNCH(4, 12, 2, 4, 0)
-    else if (N == 384 && K == 128) DG_WS_LAUNCH(12, 4, 4, 2, 1)
-    else if (N == 128 && K == 384) DG_WS_LAUNCH(4, 12, 2, 4, 2)
+    const int fmt = p0.hfmt;      // 0 float32, 1 fp16 plane + row scales, 2 three-byte elements: the 384-wide operand
+    if (fmt && p0.dy1) return fail(DG_E_ARG, "wgrad_stream: three dy matrices cannot be combined with a narrow operand");
+    if (N == 128 && K == 128 && !fmt) DG_WS_LAUNCH(4, 4, 4, 2, 0)
+    else if (N == 384 && K == 128 && !fmt) DG_WS_LAUNCH(12, 4, 4, 2, 0)
+    else if (N == 128 && K == 384 && !fmt) DG_WS_LAUNCH(4, 12, 2, 4, 0)
+    else if (N == 384 && K == 128 && fmt == 1) DG_WS_LAUNCH(12, 4, 4, 2, 1)
+    else if (N == 128 && K == 384 && fmt == 1) DG_WS_LAUNCH(4, 12, 2, 4, 2)
+    else if (N == 384 && K == 128 && fmt == 2) DG_WS_LAUNCH(12, 4, 4, 2, 3)
+    else if (N == 128 && K == 384 && fmt == 2) DG_WS_LAUNCH(4, 12, 2, 4, 4)
     else return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
 #undef DG_WS_LAUNCH
     return 0;
@@ -576,12 +600,13 @@ int flush_wgrad_stream(hipStream_t stream) {
 }
 
 int launch_wgrad_stream(const void* dy, const void* x, float* part_w, float* part_b, int64_t R, int N, int K, int blocks,
-                        hipStream_t stream, const float* dy1, const float* dy2, bool may_wait, const float* hscale) {
+                        hipStream_t stream, const float* dy1, const float* dy2, bool may_wait, const float* hscale, int hfmt) {
     if ((dy1 || dy2) && (!dy1 || !dy2 || N != 384 || K != 128))
         return fail(DG_E_ARG, "wgrad_stream: three dy matrices need N = 384, K = 128");
     if (!wgrad_stream_supported(N, K)) return fail(DG_E_SHAPE, "wgrad_stream: unsupported shape N=%d K=%d", N, K);
-    if (hscale && N + K != 512) return fail(DG_E_SHAPE, "wgrad_stream: an fp16 operand needs N = 384 or K = 384");
-    const ProbW p{static_cast<const float*>(dy), dy1, dy2, static_cast<const float*>(x), hscale, part_w, part_b, R};
+    if (hfmt && N + K != 512) return fail(DG_E_SHAPE, "wgrad_stream: a narrow operand needs N = 384 or K = 384");
+    if ((hfmt == 1) != (hscale != nullptr)) return fail(DG_E_ARG, "wgrad_stream: row scales go with the fp16 plane (hfmt 1)");
+    const ProbW p{static_cast<const float*>(dy), dy1, dy2, static_cast<const float*>(x), hscale, hfmt, part_w, part_b, R};
     if (may_wait && pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this shape
         g_rider.valid = true;
         g_rider.p = p;
@@ -592,7 +617,7 @@ int launch_wgrad_stream(const void* dy, const void* x, float* part_w, float* par
     }
     if (g_rider.valid) {
         g_rider.valid = false;
-        if (g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks <= 256 && (g_rider.p.hscale != nullptr) == (hscale != nullptr))
+        if (g_rider.N == N && g_rider.K == K && blocks + g_rider.blocks <= 256 && g_rider.p.hfmt == hfmt)
             return launch(p, blocks, &g_rider.p, g_rider.blocks, N, K, stream);
         if (int st = launch(g_rider.p, g_rider.blocks, nullptr, 0, g_rider.N, g_rider.K, stream)) return st;
     }

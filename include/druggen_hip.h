@@ -49,6 +49,18 @@ extern "C" {
  * Every other activation ([R,128] rows, statistics) stays float32; accepted wherever a call has a 384-wide operand, treated
  * as DG_DTYPE_F32 elsewhere.                                                                                          */
 #define DG_DTYPE_F32_H16 2
+/* float32 activations whose [R,384] hidden tensors keep the TOP 24 BITS of every float32 (sign, exponent, 15 mantissa bits:
+ * 16 significant bits, round half up), three bytes per element, no scales: dg_hidden_bytes(R, 384, dtype) = 1152 R bytes, rows
+ * contiguous, four elements = 12 bytes little endian.  Element error <= 2^-17 relative -- two orders inside the 1e-3 parity
+ * bar -- for 25 % fewer bytes per hidden tensor.  Same calls and rules as DG_DTYPE_F32_H16.                              */
+#define DG_DTYPE_F32_H24 3
+/* dg_edge_ffn_ln_bwd / _bwd_pair only: the forward's hidden tensor `h` is plain float32, the BACKWARD's hidden tensor `dh` is
+ * stored as DG_DTYPE_F32_H16 (4) / _H24 (5).  Rounding h perturbs the forward pass, and a perturbed forward flips ReLU masks in
+ * the layers behind it -- gradient errors of the order of the SQUARE ROOT of the perturbation on small batches (measured: 1.4e-3
+ * to 4e-3 per tensor on the two-molecule goldens even with the 2^-17 of _H24).  dh only travels through linear maps (dx = dz +
+ * dh W1, dW1 = dh^T x): its rounding stays a rounding.                                                                   */
+#define DG_DTYPE_F32_DH16 4
+#define DG_DTYPE_F32_DH24 5
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */

@@ -1009,12 +1009,16 @@ def test_packed_weight_cache_tracks_inplace_updates():
     assert p2 is not p1 and not torch.equal(p1, p2)
 
 
+@pytest.mark.parametrize("hidden", ["f32", "dh16"])
 @pytest.mark.parametrize("shape", [(2, 9, 9), (3, 50), (1, 45, 45)])
-def test_fused_ffn_ln_matches_composite_all_orders(shape):
+def test_fused_ffn_ln_matches_composite_all_orders(shape, hidden, monkeypatch):
     """dgf.linear_relu / dgf.linear_ln (first-order fast path and the create_graph
-    fallback) against plain torch ops."""
+    fallback) against plain torch ops.  DG_HIDDEN=f32: float32-class throughout; dh16 (the default: dh and its second-order
+    twin as one fp16 plane + row scales, h float32): the forward is untouched, gradients carry dh's 2^-11 rounding."""
     import torch.nn.functional as F
     from druggen_amd import functional as dgf
+    monkeypatch.setenv("DG_HIDDEN", hidden)
+    GT = 5 * TOL if hidden == "f32" else 5e-4
     C, H = 128, 384
     f = lambda t: t.float().cuda().requires_grad_(True)
     x = f(_gen(shape + (C,), 1))
@@ -1036,21 +1040,21 @@ def test_fused_ffn_ln_matches_composite_all_orders(shape):
     g_f = torch.autograd.grad(y_f, params, dy)
     g_p = torch.autograd.grad(y_p, params, dy)
     for a, b in zip(g_f, g_p):
-        assert _rel(a, b.double().cpu()) < 5 * TOL
+        assert _rel(a, b.double().cpu()) < GT
     # second order through the fused ops (reference loss.py usage without our context flag)
     gx_f = torch.autograd.grad(fused(), x, dy, create_graph=True)[0]
     gx_p = torch.autograd.grad(plain(), x, dy, create_graph=True)[0]
     s_f = torch.autograd.grad((gx_f * tx).sum(), [w1, w2, gamma])
     s_p = torch.autograd.grad((gx_p * tx).sum(), [w1, w2, gamma])
     for a, b in zip(s_f, s_p):
-        assert _rel(a, b.double().cpu()) < 5 * TOL
+        assert _rel(a, b.double().cpu()) < GT
     # and with the flag (composite ops chosen at forward time)
     with dgf.second_order_forward():
         y_c = fused()
     gx_c = torch.autograd.grad(y_c, x, dy, create_graph=True)[0]
     s_c = torch.autograd.grad((gx_c * tx).sum(), [w1, w2, gamma])
     for a, b in zip(s_c, s_p):
-        assert _rel(a, b.double().cpu()) < 5 * TOL
+        assert _rel(a, b.double().cpu()) < GT
 
 
 @pytest.mark.parametrize("shape", [(2, 9, 9), (7, 45)])
@@ -1301,21 +1305,34 @@ def _h16_chain(R, seed=300, row_scales=None):
     return L, dgf, dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, g=g, be=be, dz=dz, pw=pw, C=C, H=H)
 
 
+def _hidden_bound(ref, fmt):
+    """Per-element bound of a narrow hidden storage against the float32 kernel's value: fp16 plane -- half an fp16 ulp (2^-11
+    relative) + the denormal floor 2^-25 of the row maximum; three-byte elements -- half a unit of the 16th significant bit."""
+    if fmt == "f24":
+        return ref.abs() * 2.0 ** -16
+    return ref.abs() * 2.0 ** -11 + ref.abs().amax(1, keepdim=True) * 2.0 ** -25
+
+
+def _hidden_code(L, fmt):
+    return L.F32_H24 if fmt == "f24" else L.F32_H16
+
+
+@pytest.mark.parametrize("fmt", ["f24", "f16"])
 @pytest.mark.parametrize("R", [1, 15, 16, 17, 33, 1000, 4097, 70000])
-def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R):
-    """128 -> 384 row GEMM writing DG_DTYPE_F32_H16, 384 -> 128 row GEMM and both weight-gradient shapes reading it
-    (reference layers.py:50-53 forward / backward).  (a) every decoded element is within half an fp16 ulp of the float32
-    kernel's value (<= 2^-11 relative, + the denormal floor 2^-25 of the row maximum) and the ReLU bit masks are identical;
-    (b) GIVEN the decoded operand, the readers are float32-class: fp64 over the decoded values at TOL."""
+def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt):
+    """128 -> 384 row GEMM writing DG_DTYPE_F32_H24 / _H16, 384 -> 128 row GEMM and both weight-gradient shapes reading it
+    (reference layers.py:50-53 forward / backward).  (a) every decoded element is within the storage's rounding of the
+    float32 kernel's value (``_hidden_bound``) and the ReLU bit masks are identical; (b) GIVEN the decoded operand, the
+    readers are float32-class: fp64 over the decoded values at TOL."""
     L, dgf, t = _h16_chain(R)
+    CODE = _hidden_code(L, fmt)
     x, dz, pw, C, H = t["x"], t["dz"], t["pw"], t["C"], t["H"]
     h32, bits32 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True)
-    h16, bits16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True, code=L.F32_H16)
+    h16, bits16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True, code=CODE)
     nw = (R + 31) // 32 * 512
     assert torch.equal(bits32[:nw], bits16[:nw])
     hd = dgf.hidden_to_float(h16, R)
-    bound = h32.abs() * 2.0 ** -11 + h32.abs().amax(1, keepdim=True) * 2.0 ** -25
-    assert bool(((hd - h32).abs() <= bound).all())
+    assert bool(((hd - h32).abs() <= _hidden_bound(h32, fmt)).all())
     hd64 = hd.double().cpu()
     # readers: the four 384 -> 128 epilogues
     for res, ln in ((False, False), (True, False), (False, True), (True, True)):
@@ -1330,10 +1347,10 @@ def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R):
         else:
             assert _rel(out, want) < TOL
     # mask-in writer + dx reader
-    dh16 = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits16, code=L.F32_H16)
+    dh16 = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits16, code=CODE)
     dh32 = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits32)
     dhd = dgf.hidden_to_float(dh16, R)
-    assert bool(((dhd - dh32).abs() <= dh32.abs() * 2.0 ** -11 + dh32.abs().amax(1, keepdim=True) * 2.0 ** -25).all())
+    assert bool(((dhd - dh32).abs() <= _hidden_bound(dh32, fmt)).all())
     dx = dgf.row_gemm(dh16, pw(t["w1"], 1), H, C, residual=dz, R=R)
     assert _rel(dx, dz.double().cpu() + dhd.double().cpu() @ t["w1"].double().cpu()) < TOL
     # weight gradients: dW2 = dz^T h (x operand hidden), dW1 = dh^T x (dy operand hidden), with their bias sums
@@ -1346,9 +1363,11 @@ def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R):
     assert torch.equal(dw2, dw2b)
 
 
-def test_hidden_fp16_plane_row_scales_cover_the_float32_range():
-    """One power-of-two scale per ROW: rows 2^+-60 apart, an all-zero row and a row whose values span 2^20 keep the
-    per-element bound (relative 2^-11, floor 2^-25 of the row maximum); the 384 -> 128 reader un-scales exactly."""
+@pytest.mark.parametrize("fmt", ["f24", "f16"])
+def test_hidden_fp16_plane_row_scales_cover_the_float32_range(fmt):
+    """One power-of-two scale per ROW (fp16 plane) / the float32 exponent of every element (three-byte elements): rows 2^+-60
+    apart, an all-zero row and a row whose values span 2^20 keep the per-element bound; the 384 -> 128 reader un-scales
+    exactly."""
     R = 64
     scales = torch.tensor([2.0 ** ((i * 7) % 121 - 60) for i in range(R)], dtype=torch.float64)
     scales[5] = 0.0
@@ -1356,30 +1375,32 @@ def test_hidden_fp16_plane_row_scales_cover_the_float32_range():
     x, pw, C, H = t["x"], t["pw"], t["C"], t["H"]
     x[9] = x[9] * torch.logspace(0, 6, C, base=10.0, device="cuda")       # a heavy-tailed row
     h32 = dgf.row_gemm(x, pw(t["w1"], 0), C, H)
-    h16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, code=L.F32_H16)
+    h16 = dgf.row_gemm(x, pw(t["w1"], 0), C, H, code=_hidden_code(L, fmt))
     hd = dgf.hidden_to_float(h16, R)
     assert bool(torch.isfinite(hd).all()) and float(hd[5].abs().max()) == 0.0
-    assert bool(((hd - h32).abs() <= h32.abs() * 2.0 ** -11 + h32.abs().amax(1, keepdim=True) * 2.0 ** -25).all())
+    assert bool(((hd - h32).abs() <= _hidden_bound(h32, fmt)).all())
     y = dgf.row_gemm(h16, pw(t["w2"], 0), H, C, R=R)
     want = hd.double().cpu() @ t["w2"].double().cpu().t()
     err = (y.double().cpu() - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-300)
     assert float(err.max()) < TOL
 
 
+@pytest.mark.parametrize("fmt", ["f24", "f16"])
 @pytest.mark.parametrize("Rn,Re", [(360, 70000), (33, 66000)])
-def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re):
+def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re, fmt):
     """Riding launches (pair.h) with DG_DTYPE_F32_H16 operands: row GEMMs bit-identical to separate launches, weight
     gradients equal to rounding; a float32 rider is never paired with an fp16-plane carrier (launched on its own, first)."""
     from druggen_amd import _lib as L, functional as dgf
     ts = [_h16_chain(R, seed=360 + 20 * i)[2] for i, R in enumerate((Rn, Re))]
     Rs = (Rn, Re)
+    CODE = _hidden_code(L, fmt)
 
     def chain(paired):
         with dgf._pair_launches(ts[0]["x"], on=paired):
-            hs = [dgf.row_gemm(t["x"], t["pw"](t["w1"], 0), 128, 384, bias=t["b1"], relu=True, want_relu_bits=True, code=L.F32_H16) for t in ts]
+            hs = [dgf.row_gemm(t["x"], t["pw"](t["w1"], 0), 128, 384, bias=t["b1"], relu=True, want_relu_bits=True, code=CODE) for t in ts]
             ys = [dgf.row_gemm(h, t["pw"](t["w2"], 0), 384, 128, bias=t["b2"], residual=t["x"], ln=(t["g"], t["be"], 1e-5), want_pre=True,
                                R=R) for (h, _), t, R in zip(hs, ts, Rs)]
-            dh = [dgf.row_gemm(t["dz"], t["pw"](t["w2"], 1), 128, 384, mask_bits=b, code=L.F32_H16) for (_, b), t in zip(hs, ts)]
+            dh = [dgf.row_gemm(t["dz"], t["pw"](t["w2"], 1), 128, 384, mask_bits=b, code=CODE) for (_, b), t in zip(hs, ts)]
             dx = [dgf.row_gemm(d, t["pw"](t["w1"], 1), 384, 128, residual=t["dz"], R=R) for d, t, R in zip(dh, ts, Rs)]
             wg = dgf._wgrad_many([(ts[0]["dz"], hs[0][0], True), (ts[1]["dz"], hs[1][0], True), (dh[0], ts[0]["x"], True), (dh[1], ts[1]["x"], True)])
         return [[hs[i][0], *ys[i], dh[i], dx[i]] for i in range(2)], wg
@@ -1394,6 +1415,6 @@ def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re):
     # mixed storage inside one region: the float32 rider leaves on its own before the fp16-plane launch
     with dgf._pair_launches(ts[0]["x"]):
         hn = dgf.row_gemm(ts[0]["x"], ts[0]["pw"](ts[0]["w1"], 0), 128, 384, bias=ts[0]["b1"])
-        he = dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=L.F32_H16)
+        he = dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=CODE)
     assert torch.equal(hn, dgf.row_gemm(ts[0]["x"], ts[0]["pw"](ts[0]["w1"], 0), 128, 384, bias=ts[0]["b1"]))
-    assert torch.equal(he, dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=L.F32_H16))
+    assert torch.equal(he, dgf.row_gemm(ts[1]["x"], ts[1]["pw"](ts[1]["w1"], 0), 128, 384, bias=ts[1]["b1"], code=CODE))

@@ -242,7 +242,7 @@ def _step_against_fp64_oracle(cfg, B, seed, with_g_step, scale=1.7):
     if with_g_step:
         for net in (D, G):
             net.zero_grad(set_to_none=True)
-        for p in OD.flat + OG.flat:
+        for p in list(OD.flat) + list(OG.flat):
             p.grad = None
         g_loss = generator_loss(G, D, t32(a), t32(x), B)[0]
         g_loss.backward()
@@ -292,17 +292,18 @@ def test_forced_fused_attention_half_backward_matches_golden_and_the_two_launch_
         assert num <= (1e-4 ** 2) * den, (grp, num, den)
 
 
-def test_fp16_hidden_plane_mode_is_a_labelled_3e_3_method_at_batch_32(monkeypatch):
-    """DG_HIDDEN=f16 (DG_DTYPE_F32_H16: the [R,384] feed-forward hidden tensors as one fp16 plane + row scales) is an opt-in
-    mode OUTSIDE the 1e-3 bar: at the headline model, B = 32, its losses stay within 1e-3 and every gradient tensor within
-    3e-3 of the fp64 oracle (measured worst 1.4e-3); the default storage holds 1e-3 (the test above)."""
+def test_fp16_hidden_plane_mode_is_a_labelled_1e_2_method_at_batch_32(monkeypatch):
+    """DG_HIDDEN=f16 (the FORWARD's hidden tensor h as one fp16 plane + row scales too) is an opt-in mode OUTSIDE the 1e-3
+    bar: rounding h perturbs the forward and flips ReLU masks behind it.  At the headline model, B = 32, its losses stay
+    within 1e-3 and every gradient tensor within 1e-2 of the fp64 oracle (measured worst 4.0e-3); the default (dh16: only the
+    backward's hidden tensors) holds 1e-3 (the test above)."""
     from druggen_amd import functional as dgf
     monkeypatch.setenv("DG_HIDDEN", "f16")
     assert dgf.hidden_storage() == "f16"
     cfg = orc.NetConfig(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
     global TOL_GRAD
     keep = TOL_GRAD
-    TOL_GRAD = 3e-3
+    TOL_GRAD = 1e-2
     try:
         worst = _step_against_fp64_oracle(cfg, 32, 411, with_g_step=True)
     finally:

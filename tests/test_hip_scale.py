@@ -134,6 +134,9 @@ sl = slice(rank * per, (rank + 1) * per)
 st = GANStep(G, D, g_lr=1e-3, d_lr=1e-3, lambda_gp=case["lambda_gp"])       # FlatAdamW: the flat bucket IS the all-reduce buffer
 grads = []
 for it in range(3):
+    if os.environ.get("DG_TEST_SLOW_RANK") == str(rank):      # uneven arrival at the all-reduces
+        import time
+        time.sleep(0.3 * (it + 1))
     st.step(inp["disc_edge"][sl], inp["disc_node"][sl], inp["gen_edge"][sl], inp["gen_node"][sl],
             eps=(inp["eps_edge"][sl], inp["eps_node"][sl]))
     if it == 0:      # the rank-averaged gradient buckets of the first iteration (same weights in every run)
@@ -147,14 +150,14 @@ if world > 1:
 """
 
 
-def _launch(world, out_dir, port):
+def _launch(world, out_dir, port, **extra_env):
     script = os.path.join(out_dir, "worker.py")
     with open(script, "w") as f:
         f.write(f"ROOT = {ROOT!r}\n" + _WORKER)
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         procs.append(subprocess.Popen([sys.executable, script, out_dir], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=600)
@@ -192,6 +195,25 @@ def test_two_process_hip_data_parallel_step_equals_single_process(tmp_path):
     n_g = len(gp)
     untouched = [k for k, a, s in zip(names, r0["D"], start[n_g:]) if torch.equal(a, s)]
     assert len(untouched) == 10 and all(".attn.out_e." in k or ".ln4." in k or ".mlp2." in k or ".ln6." in k for k in untouched)
+
+
+def test_four_ranks_with_a_late_rank_stay_bit_identical(tmp_path):
+    """Four processes on cuda:0 (gloo), one molecule each, rank 2 arriving 0.3 - 0.9 s late at every iteration's all-reduces:
+    the two flat-bucket collectives per step are the only synchronisation points, so a late rank may delay the others but
+    never changes what they compute -- all four ranks end on bit-identical parameters, equal to the two-rank run's to the
+    rounding of another summation order."""
+    out = str(tmp_path)
+    _launch(4, out, _free_port(), DG_TEST_SLOW_RANK="2")
+    ranks = [torch.load(os.path.join(out, f"w4_r{r}.pt")) for r in range(4)]
+    for other in ranks[1:]:
+        for a, b in zip(ranks[0]["G"] + ranks[0]["D"], other["G"] + other["D"]):
+            assert torch.equal(a, b), "ranks diverged"
+        for a, b in zip(ranks[0]["grads"], other["grads"]):
+            assert torch.equal(a, b)
+    _launch(2, out, _free_port())
+    two = torch.load(os.path.join(out, "w2_r0.pt"))
+    for gb, gf in zip(ranks[0]["grads"], two["grads"]):
+        assert float((gb - gf).norm() / gf.norm()) < 1e-3
 
 
 _NCCL_WORKER = r"""
