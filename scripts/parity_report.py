@@ -1,0 +1,47 @@
+"""Worst per-tensor gradient error of one GAN step (HIP float32 path vs the fp64 oracle / the reference goldens) per hidden-tensor
+storage mode (DG_HIDDEN): the numbers behind README "Tolerances".
+    python scripts/parity_report.py [modes...]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r"""
+import os, sys, json, torch
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+import cases, harness
+import test_hip_model as T
+from oracle import druggen_oracle as orc
+out = {}
+T.TOL_GRAD = 1.0
+for name in cases.CASES:
+    case = cases.CASES[name]
+    fx = harness.load_fixture(name)
+    cfg, G, D = T._build(case)
+    inp = harness.torch_inputs(case, torch.float32, "cuda")
+    res = harness.run_step(G, D, T._d_loss, T._g_loss, inp, case["lambda_gp"])
+    w = max(harness.grad_table_errors(case, fx, "ref64", g, res[g])[0] for g in ("D.grad", "G.grad"))
+    out["golden " + name] = [round(w[0], 6), w[1]]
+mk = lambda L: orc.NetConfig(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=L, heads=8, mlp_ratio=3)
+w = T._step_against_fp64_oracle(mk(1), 256, 401, with_g_step=False)
+out["B=256 L=1 D step"] = [round(w["D"][0], 6), w["D"][1]]
+w = T._step_against_fp64_oracle(mk(4), 32, 411, with_g_step=True)
+out["B=32 L=4 D step"] = [round(w["D"][0], 6), w["D"][1]]
+out["B=32 L=4 G step"] = [round(w["G"][0], 6), w["G"][1]]
+print("REPORT " + json.dumps(out))
+"""
+modes = sys.argv[1:] or ["f32", "dh24", "dh16", "f24", "f16"]
+for m in modes:
+    env = dict(os.environ, DG_HIDDEN=m)
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("REPORT ")]
+    if not line:
+        print(m, "FAILED", p.stderr.decode()[-1500:])
+        continue
+    import json
+    rep = json.loads(line[0][7:])
+    print(f"== DG_HIDDEN={m}")
+    for k, (e, t) in rep.items():
+        print(f"   {k:28s} {e:.3e}  {t}")
