@@ -25,6 +25,8 @@
 // conflict-free for the writes of 16 consecutive lanes and for the fragment reads of 16 rows), 12 KiB per stage, six stages in
 // flight.  The consumers run TWO products per k-step (x . w_hi, x . w_lo) on six independent chains and fold once.
 #include "common.h"
+
+#include <cstdlib>
 #include "row_gemm_k384.h"
 #include "pair.h"
 #include "traversal.h"
@@ -113,9 +115,11 @@ struct ProbK {
     EpiK ep;
 };
 
-template <bool RES, bool LN, int FMT>
+// NP (fp16-plane operand only): 2 products per k-step (x . w_hi + x . w_lo); 1 (x . w_hi) is the DG_DH_PRODUCTS=1 experiment.
+template <bool RES, bool LN, int FMT, int NP = 2>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const ProbK p0, const ProbK p1, const int nb0) {
     constexpr bool H16 = FMT == 1, H24 = FMT == 2;
+    static_assert(NP == 2 || (NP == 1 && FMT == 1 && !LN), "single-product arithmetic: the backward's fp16-plane operand only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
@@ -363,14 +367,14 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
     const int n = lane & 15, kq = lane >> 4;
     // weight fragments from the packed operand (32-column slabs x 16-deep k-steps, lane = (column, k half)): channel
     // 16 w + n, k = 32 ks + 8 kq .. + 7  ->  slab (16 w + n) >> 5, k-step 2 ks + (kq >> 1), lane (kq & 1) * 32 + column
-    f16x8 wf[12][2];
+    f16x8 wf[12][NP == 1 ? 1 : 2];
     {
         const int ch = 16 * w + n;
         const int tslab = ch >> 5, col = ch & 31;
 #pragma unroll
         for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < (NP == 1 ? 1 : 2); ++p)
                 wf[ks][p] = packed[(static_cast<size_t>(tslab * 24 + 2 * ks + (kq >> 1)) * 2 + p) * 64 + (kq & 1) * 32 + col];
     }
     const float* inv_cs = reinterpret_cast<const float*>(packed + static_cast<size_t>(4) * 24 * 2 * 64);
@@ -397,15 +401,16 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
 #pragma unroll
                     for (int kc = 0; kc < 3; ++kc) {
                         const f16x8 xh = (K3_DBG & 16) ? wf[ks][0] : *reinterpret_cast<const f16x8*>(pl + kc * 256 + xo_h[ks]);
-                        const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][1];
+                        const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][NP == 1 ? 0 : 1];
                         if (K3_DBG & 1) {
                             if (ks == 0) pl0[kc] = ph0[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
                             pl0[kc][0] += static_cast<float>(xh[0]) * static_cast<float>(wl[0]);
                         } else if (ks == 0) {
-                            mfma16_first(pl0[kc], wl, xh);
+                            if (NP == 2) mfma16_first(pl0[kc], wl, xh);
+                            else pl0[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
                             mfma16_first(ph0[kc], wh, xh);
                         } else {
-                            mfma16(pl0[kc], wl, xh);
+                            if (NP == 2) mfma16(pl0[kc], wl, xh);
                             mfma16(ph0[kc], wh, xh);
                         }
                     }
@@ -427,12 +432,12 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
                     f16x8 xh, xl;
                     if (K3_DBG & 16) {
                         xh = wf[ks][0];
-                        xl = wf[ks][1];
+                        xl = wf[ks][NP == 1 ? 0 : 1];
                     } else {
                         xh = *reinterpret_cast<const f16x8*>(q0);
                         xl = *reinterpret_cast<const f16x8*>(q0 + kPlane);
                     }
-                    const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][1];
+                    const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][NP == 1 ? 0 : 1];
                     if (K3_DBG & 1) {
                         if (ks == 0) p0 = p1 = p2 = f32x4{0.f, 0.f, 0.f, 0.f};
                         p0[0] += static_cast<float>(xh[0]) * static_cast<float>(wl[0]);
@@ -485,6 +490,19 @@ int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
         DG_OPT_IN_LDS((&row_gemm_k384_kernel<RES_, LN_, H16_>), kLds);                                             \
         hipLaunchKernelGGL((row_gemm_k384_kernel<RES_, LN_, H16_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
                            q1, nb0);                                                                               \
+    }
+    // DG_DH_PRODUCTS=1: only the hi plane of the weights for the backward's fp16-plane operand (measured outside the parity bar:
+    // the weights' rounding is the same for every row; kept for A/B runs)
+    const bool dh_single = getenv("DG_DH_PRODUCTS") && atoi(getenv("DG_DH_PRODUCTS")) == 1;      // (read per launch: A/B runs)
+    if (dh_single && (variant(p0) == 5 || variant(p0) == 4)) {      // fp16-plane operand, no LayerNorm: dx = dz + dh W1, t + vbar W2^T
+        if (variant(p0) == 5) {
+            DG_OPT_IN_LDS((&row_gemm_k384_kernel<true, false, 1, 1>), kLds);
+            hipLaunchKernelGGL((row_gemm_k384_kernel<true, false, 1, 1>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, q1, nb0);
+        } else {
+            DG_OPT_IN_LDS((&row_gemm_k384_kernel<false, false, 1, 1>), kLds);
+            hipLaunchKernelGGL((row_gemm_k384_kernel<false, false, 1, 1>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, q1, nb0);
+        }
+        return 0;
     }
     switch (variant(p0)) {
         case 3: DG_K384_LAUNCH(true, true, 0) break;

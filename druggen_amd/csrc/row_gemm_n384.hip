@@ -25,10 +25,15 @@
 // bytes per row instead of 1536).  The producers do it on the way out of the output tile: a half-wave owns a whole row there,
 // so the row maximum is the same four DPP steps + one v_permlane16_swap as on the way in.
 #include "common.h"
+
+#include <cstdlib>
 #include "row_gemm_n384.h"
 #include "pair.h"
 #include "traversal.h"
 
+#ifndef N3_SCHED
+#define N3_SCHED 1    // consumers: fragment reads one k-step ahead, per row block (0: hipcc's order, A/B builds)
+#endif
 #ifndef N3_DBG
 #define N3_DBG 0      // ablation builds (scripts/build_variant.sh, scripts/n384_variants.sh): 1 no MFMAs, 2 no epilogue arithmetic
 #endif                // (raw accumulators to the tile), 4 no output stores, 8 no global fetch of A
@@ -94,9 +99,15 @@ struct Prob {
 // bits out, no mask in; 2 its twin in the backward -- mask in only (dh = (dz W2) * m).  The generic form spends ~8 vector
 // instructions per element on selects whose conditions are launch constants (and a wait state per v_cmp -> v_cndmask pair); the
 // two hot forms need 3 and 2.
-template <int FMT, int MODE>
+// NP: MFMA products per k-step.  3: w_hi.x_hi + w_lo.x_hi + w_hi.x_lo (float32 class).  2: without w_hi.x_lo -- the activation rows
+// enter as ONE fp16 plane (2^-12 rounding per element, independent from element to element) -- for results that leave as an fp16
+// plane anyway (FMT 1) in the BACKWARD (dh = (dz W2) * m and its second-order twin), which only travel through linear maps
+// (DESIGN 3.16).  The weights keep both planes: their rounding would be the SAME for every row (measured with a single product:
+// 1.15e-3 on the chembl_b4 golden, outside the bar; DG_DH_PRODUCTS=1 selects it for the record).
+template <int FMT, int MODE, int NP = 3>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
     constexpr bool H16 = FMT == 1, H24 = FMT == 2;
+    static_assert(NP == 3 || ((NP == 1 || NP == 2) && FMT == 1 && MODE == 2), "reduced products: fp16-plane results of the backward only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
     const int lane = threadIdx.x & 63;
@@ -198,7 +209,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                 const int row = hw + 8 * i;
                 const unsigned off = wbase + static_cast<unsigned>((row ^ (blk & 7)) * 16);
                 *reinterpret_cast<u32x2*>(pl + off) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-                *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+                if (NP == 3)
+                    *reinterpret_cast<u32x2*>(pl + kPlane + off) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
             }
             if (l32 == 0) {
 #pragma unroll
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
     const int n = lane & 15, kq = lane >> 4;
     // weight fragments from the packed operand (32-column slabs x 16-deep k-steps, lane = (column, k half)): channel
     // 48 w + 16 cb + n, k = 32 ks + 8 kq .. + 7  ->  slab t, k-step 2 ks + (kq >> 1), lane (kq & 1) * 32 + column
-    f16x8 wf[3][4][2];
+    f16x8 wf[3][4][NP == 1 ? 1 : 2];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
         const int ch = 48 * w + 16 * cb + n;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < (NP == 1 ? 1 : 2); ++p)
                 wf[cb][ks][p] = packed[(static_cast<size_t>(tslab * 8 + 2 * ks + (kq >> 1)) * 2 + p) * 64 + (kq & 1) * 32 + col];
     }
     // activation fragment of lane (row n, quarter kq) in k-step ks: block 4 ks + kq, position (16 rb + n) ^ ((4 ks + kq) & 7)
@@ -360,28 +372,47 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
             const char* pl = smem + (t & 1) * kStage;
             const unsigned bits = *reinterpret_cast<const unsigned*>(smem + kOffBitsIn + (t & 1) * 2048 + (w * 64 + lane) * 4);
             f32x4 acc[2][3];
+            // Fragment reads run one k-step AHEAD, per row block: the fragments of (k-step ks + 1, row block rb) are requested
+            // right behind the MFMAs of (ks, rb) -- into the same registers, the MFMAs have read them at issue -- and arrive
+            // while the other row block's MFMAs run.  (hipcc's own order was 4 reads, wait, 18 MFMAs, 4 reads, wait ...: every
+            // k-step exposed one LDS round trip with the matrix pipe idle; N3_SCHED=0 keeps that order for A/B builds.)
+            f16x8 xh[2], xl[2];
+            auto read_frags = [&](int ks, int rb) {
+                const char* p0 = pl + ks * 2048 + rb * 256 + ((ks & 1) ? xo_o : xo_e);
+                xh[rb] = *reinterpret_cast<const f16x8*>(p0);
+                if (NP == 3) xl[rb] = *reinterpret_cast<const f16x8*>(p0 + kPlane);
+            };
+            read_frags(0, 0);
+            read_frags(0, 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                f16x8 xh[2], xl[2];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    const char* p0 = pl + ks * 2048 + rb * 256 + ((ks & 1) ? xo_o : xo_e);
-                    xh[rb] = *reinterpret_cast<const f16x8*>(p0);
-                    xl[rb] = *reinterpret_cast<const f16x8*>(p0 + kPlane);
-                }
-                // lo.hi, hi.lo, hi.hi: smallest terms first; consecutive MFMAs hit different accumulators
+                    // w_lo.x_hi, w_hi.x_lo, w_hi.x_hi: smallest terms first; three accumulators in rotation
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int term = (NP == 1 ? 2 : 0); term < 3; ++term)
 #pragma unroll
                         for (int cb = 0; cb < 3; ++cb) {
+                            if (NP != 3 && term == 1) continue;
+                            constexpr int LO = NP == 1 ? 0 : 1;      // (index of the weights' lo plane; never read when NP == 1)
+                            constexpr int FIRST = NP == 1 ? 2 : 0;
                             if (N3_DBG & 1) {
-                                if (ks == 0 && term == 0) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                if (ks == 0 && term == FIRST) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
                                 acc[rb][cb][0] += static_cast<float>(xh[rb][0]) * static_cast<float>(wf[cb][ks][0][0]);
-                            } else if (ks == 0 && term == 0) mfma16_first(acc[rb][cb], wf[cb][ks][1], xh[rb]);
-                            else mfma16(acc[rb][cb], wf[cb][ks][term == 0 ? 1 : 0], term == 1 ? xl[rb] : xh[rb]);
+                            } else if (ks == 0 && term == FIRST) mfma16_first(acc[rb][cb], wf[cb][ks][term == 0 ? LO : 0], xh[rb]);
+                            else mfma16(acc[rb][cb], wf[cb][ks][term == 0 ? LO : 0], term == 1 ? xl[rb] : xh[rb]);
                         }
+#if N3_SCHED
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks < 3) read_frags(ks + 1, rb);
+                    __builtin_amdgcn_sched_barrier(0);
+#else
+                    if (ks < 3 && rb == 1) {
+                        read_frags(ks + 1, 0);
+                        read_frags(ks + 1, 1);
+                    }
+#endif
+                }
             }
             mfma_results_ready();
             // epilogue: lane (row n of block rb, channel group kq) holds channels 48 w + 16 cb + 4 kq + i of its row
@@ -459,9 +490,19 @@ int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
         hipLaunchKernelGGL((row_gemm_n384_kernel<H16_, MODE_>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0, \
                            p1 ? *p1 : p0, nb0);                                                                          \
     }
+    // DG_DH_PRODUCTS=3: full three-product arithmetic for the backward's fp16-plane results too, =1: a single product (A/B, tests)
+    const int dh_products = getenv("DG_DH_PRODUCTS") ? atoi(getenv("DG_DH_PRODUCTS")) : 2;      // (read per launch: tests switch it)
     if (p0.yfmt == 1) {
         if (mode == 1) DG_N384_LAUNCH(1, 1)
-        else if (mode == 2) DG_N384_LAUNCH(1, 2)
+        else if (mode == 2 && dh_products == 2) {
+            DG_OPT_IN_LDS((&row_gemm_n384_kernel<1, 2, 2>), kLds);
+            hipLaunchKernelGGL((row_gemm_n384_kernel<1, 2, 2>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0,
+                               p1 ? *p1 : p0, nb0);
+        } else if (mode == 2 && dh_products == 1) {
+            DG_OPT_IN_LDS((&row_gemm_n384_kernel<1, 2, 1>), kLds);
+            hipLaunchKernelGGL((row_gemm_n384_kernel<1, 2, 1>), dim3(nb0 + nb1), dim3(64 * (kCons + kProd)), kLds, stream, p0,
+                               p1 ? *p1 : p0, nb0);
+        } else if (mode == 2) DG_N384_LAUNCH(1, 2)
         else DG_N384_LAUNCH(1, 0)
     } else if (p0.yfmt == 2) {
         if (mode == 1) DG_N384_LAUNCH(2, 1)

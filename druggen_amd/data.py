@@ -14,10 +14,29 @@ import torch
 from . import _lib
 from .functional import _dev, attach_one_hot_labels
 
-__all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot"]
+__all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot", "raise_deferred_checks"]
 
 
-def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check: bool = True):
+_pending_checks = []      # (bad-label counter on the device, b_dim, recorded event) of batches densified with check="deferred"
+
+
+def raise_deferred_checks(wait: bool = False) -> None:
+    """Raise for batches densified with ``check="deferred"`` whose bond labels were out of range.  Only counters whose kernel
+    has already finished are read (``wait=True``: all of them): no stall of the launch queue."""
+    keep = []
+    for bad, b_dim, ev in _pending_checks:
+        if not wait and not ev.query():
+            keep.append((bad, b_dim, ev))
+            continue
+        n_bad = int(bad.item())
+        if n_bad:
+            _pending_checks[:] = []
+            raise RuntimeError(f"{n_bad} adjacency entries of an EARLIER batch had a bond label outside [0, {b_dim}) "
+                               f"(densified with check='deferred': their rows were embedded as class 0)")
+    _pending_checks[:] = keep
+
+
+def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check=True):
     """``label2onehot(to_dense_adj(edge_index, batch, edge_attr, max_num_nodes=N), b_dim)`` for a
     batch whose graphs are all padded to ``vertexes`` nodes (utils.py:130-137).
 
@@ -25,7 +44,10 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
     ``scatter_`` does (one 4-byte device->host read per batch; the reference's loader syncs per
     batch anyway) and attaches the int32 labels to the result, so that Generator / Discriminator take the
     table-gather edge embedding without re-validating the tensor.  Pass ``check=False`` on a path that must
-    not synchronise (the result then carries no labels: it is not known to be one-hot).
+    not synchronise (the result then carries no labels: it is not known to be one-hot), or ``check="deferred"`` in a
+    training loop: no host synchronisation at all -- the labels are clamped into range on the device (so the table gather
+    stays memory-safe), attached, and the counter of out-of-range labels is read at a LATER call, once its kernel has
+    finished (``raise_deferred_checks``): an invalid batch raises one or two batches late instead of stalling every batch.
     An edge whose endpoints lie in different graphs lands in the SOURCE graph's matrix at column
     ``dst mod N`` -- what ``to_dense_adj`` does with ``dst - ptr[batch[dst]]``."""
     if not edge_index.is_cuda:
@@ -42,7 +64,14 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
         _lib.check(lib.dg_densify(src.data_ptr(), dst.data_ptr(), attr.data_ptr(), src.numel(), batch_size, vertexes,
                                   b_dim, labels.data_ptr(), a.data_ptr(), bad.data_ptr(), _lib.stream_of(a)),
                    "dg_densify")
-    if check:
+    if check == "deferred":
+        raise_deferred_checks()      # counters of earlier batches that are complete by now
+        ev = torch.cuda.Event()
+        ev.record()
+        _pending_checks.append((bad, b_dim, ev))
+        labels.clamp_(0, b_dim - 1)
+        attach_one_hot_labels(a, labels)
+    elif check:
         n_bad = int(bad.item())
         if n_bad:
             raise RuntimeError(f"{n_bad} adjacency entries have a bond label outside [0, {b_dim})")
@@ -59,11 +88,12 @@ def label2onehot(labels, dim, device=None):
     return out.float()
 
 
-def load_molecules(data=None, b_dim=32, m_dim=32, device=None, batch_size=32):
-    """Reference utils.py:128-142 -> (real_graphs, a_tensor, x_tensor)."""
+def load_molecules(data=None, b_dim=32, m_dim=32, device=None, batch_size=32, check=True):
+    """Reference utils.py:128-142 -> (real_graphs, a_tensor, x_tensor).  ``check``: see ``dense_one_hot_adjacency``
+    ("deferred" = no host synchronisation per batch)."""
     data = data.to(device) if hasattr(data, "to") and device is not None else data
     vertexes = int(data.batch.shape[0] / batch_size)
-    a_tensor = dense_one_hot_adjacency(data.edge_index, data.edge_attr, batch_size, vertexes, b_dim)
+    a_tensor = dense_one_hot_adjacency(data.edge_index, data.edge_attr, batch_size, vertexes, b_dim, check=check)
     x_tensor = data.x.view(batch_size, vertexes, -1)
     real_graphs = torch.concat((x_tensor.reshape(batch_size, -1), a_tensor.reshape(batch_size, -1)), dim=-1)
     return real_graphs, a_tensor, x_tensor

@@ -62,6 +62,25 @@ def test_densify_edge_cases():
     assert np.array_equal(a.cpu().numpy(), ref) and a[0, 1, 2, 2] == 1 and a[1, 3, 0, 1] == 1
 
 
+def test_densify_deferred_check_never_syncs_and_raises_later():
+    """check="deferred": the labels are attached without a device->host read (out-of-range labels are clamped to a valid class
+    on the device, so the table gather stays memory-safe) and the error surfaces at a LATER call, once the counter's kernel
+    has finished."""
+    from druggen_amd import data, functional as dgf
+    data.raise_deferred_checks(wait=True)
+    ei = torch.tensor([[0, 0, 5], [1, 1, 6]], device="cuda")
+    good = data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3, check="deferred")
+    assert dgf.one_hot_labels(good) is not None
+    assert torch.equal(good, data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3))
+    bad = data.dense_one_hot_adjacency(ei, torch.tensor([2, 2, 2], device="cuda"), 2, 4, 3, check="deferred")      # 2 + 2 = label 4
+    lab = dgf.one_hot_labels(bad)
+    assert lab is not None and int(lab.max()) <= 2 and int(lab.min()) >= 0
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="EARLIER batch"):
+        data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3, check="deferred")
+    data.raise_deferred_checks(wait=True)      # the queue is clean again
+
+
 def test_loader_attaches_labels_and_the_model_takes_the_table_path_without_a_sync():
     """data.dense_one_hot_adjacency hands its int32 labels to the model: Generator / Discriminator then embed the batch
     by table gather with NO validation pass (as_one_hot synced once per new tensor, i.e. every step with a

@@ -1319,11 +1319,12 @@ def _hidden_code(L, fmt):
 
 @pytest.mark.parametrize("fmt", ["f24", "f16"])
 @pytest.mark.parametrize("R", [1, 15, 16, 17, 33, 1000, 4097, 70000])
-def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt):
+def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt, monkeypatch):
     """128 -> 384 row GEMM writing DG_DTYPE_F32_H24 / _H16, 384 -> 128 row GEMM and both weight-gradient shapes reading it
     (reference layers.py:50-53 forward / backward).  (a) every decoded element is within the storage's rounding of the
     float32 kernel's value (``_hidden_bound``) and the ReLU bit masks are identical; (b) GIVEN the decoded operand, the
     readers are float32-class: fp64 over the decoded values at TOL."""
+    monkeypatch.setenv("DG_DH_PRODUCTS", "3")      # (the exact arithmetic; the backward's single-product form: the test below)
     L, dgf, t = _h16_chain(R)
     CODE = _hidden_code(L, fmt)
     x, dz, pw, C, H = t["x"], t["dz"], t["pw"], t["C"], t["H"]
@@ -1363,6 +1364,34 @@ def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt):
     assert torch.equal(dw2, dw2b)
 
 
+@pytest.mark.parametrize("R", [17, 1000, 70000])
+def test_backward_fp16_plane_two_product_arithmetic(R, monkeypatch):
+    """The default arithmetic of the BACKWARD's fp16-plane writer: dh = (dz W2) * m with the activation rows as ONE fp16 plane
+    (products w_hi.x_hi + w_lo.x_hi; the result carries a 2^-11 rounding anyway).  Against fp64: relative L2 error of dh below
+    3.5e-4 (2.1e-4 with all three products); DG_DH_PRODUCTS=3 restores the float32-class products (bit-identical to the exact
+    test above), =1 the single-product experiment that measured outside the parity bar; the ReLU mask still zeroes exactly."""
+    L, dgf, t = _h16_chain(R)
+    x, dz, pw, C, H = t["x"], t["dz"], t["pw"], t["C"], t["H"]
+    _, bits = dgf.row_gemm(x, pw(t["w1"], 0), C, H, bias=t["b1"], relu=True, want_relu_bits=True)
+    h64 = torch.relu(x.double().cpu() @ t["w1"].double().cpu().t() + t["b1"].double().cpu())
+    dh64 = (dz.double().cpu() @ t["w2"].double().cpu()) * (h64 > 0)
+    out = {}
+    for products, bound in (("3", 2.5e-4), ("2", 3.5e-4), ("1", 6e-4)):
+        monkeypatch.setenv("DG_DH_PRODUCTS", products)
+        dh = dgf.row_gemm(dz, pw(t["w2"], 1), C, H, mask_bits=bits, code=L.F32_H16)
+        dhd = dgf.hidden_to_float(dh, R)
+        out[products] = dhd
+        # (mask flips between the float32 kernel's mask and fp64's are excluded: compare where both agree)
+        keep = ((dhd != 0).cpu() == (dh64 != 0))
+        e_dh = ((dhd.double().cpu() - dh64) * keep).norm() / dh64.norm()
+        assert float(e_dh) < bound, (products, float(e_dh))
+        assert bool(((dhd == 0) | (dh64.cuda() != 0) | ~keep.cuda()).all())
+        dx = dgf.row_gemm(dh, pw(t["w1"], 1), H, C, residual=dz, R=R)
+        e_dx = (dx.double().cpu() - (dz.double().cpu() + dhd.double().cpu() @ t["w1"].double().cpu())).norm() / dx.double().norm().cpu()
+        assert float(e_dx) < (TOL if products != "1" else 3e-4), (products, float(e_dx))
+    assert not torch.equal(out["3"], out["2"])
+
+
 @pytest.mark.parametrize("fmt", ["f24", "f16"])
 def test_hidden_fp16_plane_row_scales_cover_the_float32_range(fmt):
     """One power-of-two scale per ROW (fp16 plane) / the float32 exponent of every element (three-byte elements): rows 2^+-60
@@ -1387,7 +1416,7 @@ def test_hidden_fp16_plane_row_scales_cover_the_float32_range(fmt):
 
 @pytest.mark.parametrize("fmt", ["f24", "f16"])
 @pytest.mark.parametrize("Rn,Re", [(360, 70000), (33, 66000)])
-def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re, fmt):
+def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re, fmt, monkeypatch):
     """Riding launches (pair.h) with DG_DTYPE_F32_H16 operands: row GEMMs bit-identical to separate launches, weight
     gradients equal to rounding; a float32 rider is never paired with an fp16-plane carrier (launched on its own, first)."""
     from druggen_amd import _lib as L, functional as dgf
