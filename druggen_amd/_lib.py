@@ -179,8 +179,10 @@ def check(status: int, what: str) -> None:
 DTYPES = {torch.float32: 0, torch.bfloat16: 1}     # DG_DTYPE_F32 / DG_DTYPE_BF16 of include/druggen_hip.h
 F32_H16 = 2      # DG_DTYPE_F32_H16: float32 activations, the [R,384] feed-forward hidden tensors as one scaled fp16 plane
 F32_H24 = 3      # DG_DTYPE_F32_H24: ... as the top 24 bits of every float32 (three bytes per element)
-HIDDEN_CODES = (F32_H16, F32_H24)
 F32_DH16, F32_DH24 = 4, 5      # dg_edge_ffn_ln_bwd(_pair) only: h float32, dh stored as F32_H16 / F32_H24
+F32_H32 = 6      # DG_DTYPE_F32_H32: the forward's h as pre-split hi + lo fp16 planes under one row scale (float32 class)
+F32_H32_DH16 = 7      # dg_edge_ffn_ln_bwd(_pair) only: h as F32_H32, dh as F32_H16
+HIDDEN_CODES = (F32_H16, F32_H24, F32_H32)
 
 
 def dt(t) -> int:

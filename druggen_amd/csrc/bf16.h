@@ -66,12 +66,18 @@ __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = static_cast<__bf1
 
 inline bool dtype_ok(int dtype) { return dtype == DG_DTYPE_F32 || dtype == DG_DTYPE_BF16; }
 // DG_DTYPE_F32_H16 is float32 everywhere except the 384-wide hidden operands
-inline int act_dtype(int dtype) { return (dtype >= DG_DTYPE_F32_H16 && dtype <= DG_DTYPE_F32_DH24) ? DG_DTYPE_F32 : dtype; }
+inline int act_dtype(int dtype) { return (dtype >= DG_DTYPE_F32_H16 && dtype <= DG_DTYPE_F32_H32_DH16) ? DG_DTYPE_F32 : dtype; }
 // dg_edge_ffn_ln_bwd: the dtype its launches over `h` / over `dh` take (DG_DTYPE_F32_DH16 / _DH24: h float32, dh narrow)
-inline int ffn_h_dtype(int dtype) { return (dtype == DG_DTYPE_F32_DH16 || dtype == DG_DTYPE_F32_DH24) ? DG_DTYPE_F32 : dtype; }
-inline int ffn_dh_dtype(int dtype) { return dtype == DG_DTYPE_F32_DH16 ? DG_DTYPE_F32_H16 : (dtype == DG_DTYPE_F32_DH24 ? DG_DTYPE_F32_H24 : dtype); }
+inline int ffn_h_dtype(int dtype) {
+    if (dtype == DG_DTYPE_F32_H32_DH16) return DG_DTYPE_F32_H32;
+    return (dtype == DG_DTYPE_F32_DH16 || dtype == DG_DTYPE_F32_DH24) ? DG_DTYPE_F32 : dtype;
+}
+inline int ffn_dh_dtype(int dtype) {
+    if (dtype == DG_DTYPE_F32_DH16 || dtype == DG_DTYPE_F32_H32_DH16) return DG_DTYPE_F32_H16;
+    return dtype == DG_DTYPE_F32_DH24 ? DG_DTYPE_F32_H24 : dtype;
+}
 // storage of a 384-wide hidden operand inside the producer / consumer kernels: 0 float32, 1 fp16 plane + row scales, 2 three-byte elements
-inline int hidden_fmt(int dtype) { return dtype == DG_DTYPE_F32_H16 ? 1 : (dtype == DG_DTYPE_F32_H24 ? 2 : 0); }
+inline int hidden_fmt(int dtype) { return dtype == DG_DTYPE_F32_H16 ? 1 : (dtype == DG_DTYPE_F32_H24 ? 2 : (dtype == DG_DTYPE_F32_H32 ? 3 : 0)); }
 inline size_t hidden_scale_offset(int64_t R, int H) { return (static_cast<size_t>(R) * H * 2 + 255) / 256 * 256; }
 inline size_t dtype_size(int dtype) { return dtype == DG_DTYPE_BF16 ? 2 : 4; }
 

@@ -42,7 +42,8 @@ int row_gemm_f32_ln_in(const float* dy, const float* pre, const float* mean, con
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias, int relu,
                  unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual, const float* gamma,
                  const float* beta, float* mean, float* rstd, float* pre_ln, float eps, dg_stream_t stream,
-                 const float* ascale = nullptr, float* yscale = nullptr, int afmt = 0, int yfmt = 0);
+                 const float* ascale = nullptr, float* yscale = nullptr, int afmt = 0, int yfmt = 0, const void* alo = nullptr,
+                 void* ylo = nullptr);
 
 namespace {
 
@@ -351,13 +352,23 @@ extern "C" int dg_row_gemm(const void* a, const void* packed, void* y, int64_t R
     // DG_DTYPE_F32_H16: the 384-wide operand (a for K = 384, y for N = 384) is an fp16 plane + inverse row scales
     const float* ascale = nullptr;
     float* yscale = nullptr;
-    if (dtype == DG_DTYPE_F32_H16 && K == 384)
-        ascale = reinterpret_cast<const float*>(static_cast<const char*>(a) + hidden_scale_offset(R, 384));
-    if (dtype == DG_DTYPE_F32_H16 && N == 384) yscale = reinterpret_cast<float*>(static_cast<char*>(y) + hidden_scale_offset(R, 384));
+    const void* alo = nullptr;
+    void* ylo = nullptr;
+    const size_t hoff = hidden_scale_offset(R, 384);
+    if (dtype == DG_DTYPE_F32_H16 && K == 384) ascale = reinterpret_cast<const float*>(static_cast<const char*>(a) + hoff);
+    if (dtype == DG_DTYPE_F32_H16 && N == 384) yscale = reinterpret_cast<float*>(static_cast<char*>(y) + hoff);
+    if (dtype == DG_DTYPE_F32_H32 && K == 384) {      // hi plane | lo plane | inverse row scales
+        alo = static_cast<const char*>(a) + hoff;
+        ascale = reinterpret_cast<const float*>(static_cast<const char*>(a) + 2 * hoff);
+    }
+    if (dtype == DG_DTYPE_F32_H32 && N == 384) {
+        ylo = static_cast<char*>(y) + hoff;
+        yscale = reinterpret_cast<float*>(static_cast<char*>(y) + 2 * hoff);
+    }
     return row_gemm_f32(static_cast<const float*>(a), static_cast<const float*>(packed), static_cast<float*>(y), R, K, N,
                         bias, relu, relu_bits_out, mask_bits, static_cast<const float*>(residual), gamma, beta, mean, rstd,
                         static_cast<float*>(pre_ln), eps, stream_, ascale, yscale, K == 384 ? hidden_fmt(dtype) : 0,
-                        N == 384 ? hidden_fmt(dtype) : 0);
+                        N == 384 ? hidden_fmt(dtype) : 0, alo, ylo);
 }
 
 extern "C" size_t dg_hidden_scale_offset(int64_t R, int H) { return R < 0 || H < 1 ? 0 : hidden_scale_offset(R, H); }
@@ -366,6 +377,7 @@ extern "C" size_t dg_hidden_bytes(int64_t R, int H, int dtype) {
     if (R < 0 || H < 1) return 0;
     if (dtype == DG_DTYPE_F32_H16) return hidden_scale_offset(R, H) + static_cast<size_t>(R) * 4;
     if (dtype == DG_DTYPE_F32_H24) return static_cast<size_t>(R) * H * 3;
+    if (dtype == DG_DTYPE_F32_H32) return 2 * hidden_scale_offset(R, H) + static_cast<size_t>(R) * 4;
     return static_cast<size_t>(R) * H * dtype_size(dtype);
 }
 

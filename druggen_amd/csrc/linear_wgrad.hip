@@ -788,10 +788,13 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     // DG_DTYPE_F32_H16: the 384-wide operand (dy for N = 384, x for K = 384) is an fp16 plane + inverse row scales
     const float* hscale = nullptr;
     int hfmt = 0;
-    if (dtype == DG_DTYPE_F32_H16 || dtype == DG_DTYPE_F32_H24) {
+    if (dtype == DG_DTYPE_F32_H16 || dtype == DG_DTYPE_F32_H24 || dtype == DG_DTYPE_F32_H32) {
         const bool narrow = (N == 384 && K == 128) || (N == 128 && K == 384);
         if (narrow) hfmt = hidden_fmt(dtype);
-        if (hfmt == 1) hscale = reinterpret_cast<const float*>(static_cast<const char*>(N == 384 ? dy_ : x_) + hidden_scale_offset(R, 384));
+        // H32 (hi | lo | scales): the weight gradient reads the hi plane only -- an fp16 plane whose scales sit behind the lo plane
+        const size_t soff = (hfmt == 3 ? 2 : 1) * hidden_scale_offset(R, 384);
+        if (hfmt == 3) hfmt = 1;
+        if (hfmt == 1) hscale = reinterpret_cast<const float*>(static_cast<const char*>(N == 384 ? dy_ : x_) + soff);
         if (hfmt && dy_mask_) return fail(DG_E_ARG, "dg_linear_wgrad: dy_mask cannot be combined with DG_DTYPE_F32_H16 / _H24");
         dtype = DG_DTYPE_F32;
     }

@@ -1654,7 +1654,8 @@ size_t row_gemm_f32_mask_words(int64_t R, int K, int N) {
 int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K, int N, const float* bias,
                            int relu, unsigned* relu_bits_out, const unsigned* mask_bits, const float* residual,
                            const float* gamma, const float* beta, float* mean, float* rstd, float* pre_ln,
-                           float eps, dg_stream_t stream_, const float* ascale, float* yscale, int afmt, int yfmt) {
+                           float eps, dg_stream_t stream_, const float* ascale, float* yscale, int afmt, int yfmt,
+                           const void* alo, void* ylo) {
     if (!a || !packed || !y) return fail(DG_E_ARG, "dg_row_gemm: null pointer");
     if ((afmt && K != 384) || (yfmt && N != 384)) return fail(DG_E_ARG, "dg_row_gemm: narrow hidden operands are the 384-wide ones");
     if (R < 0 || !((K == 128 && (N == 128 || N == 384)) || (K == 384 && N == 128)))
@@ -1691,14 +1692,14 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         // kernels (A/B measurements).  The three write their ReLU bit masks in layouts of their own: a process uses one.
         static const bool pc_n = !getenv("DG_GEMM_N384") || strcmp(getenv("DG_GEMM_N384"), "pc") == 0;
         if (K == 128 && N == 384 && pc_n) {
-            if (int st = launch_row_gemm_n384(a, packed, y, yscale, R, bias, relu, relu_bits_out, mask_bits, stream, yfmt)) return st;
+            if (int st = launch_row_gemm_n384(a, packed, y, yscale, R, bias, relu, relu_bits_out, mask_bits, stream, yfmt, ylo)) return st;
             return check_launch("dg_row_gemm");
         }
         // 384 -> 128: producer / consumer kernel (row_gemm_k384.hip) by default; DG_GEMM_K384=paired selects the round-2/3
         // kernel (two tiles per B set, epilogue in the mover waves) for A/B measurements
         static const bool pc_k = !getenv("DG_GEMM_K384") || strcmp(getenv("DG_GEMM_K384"), "pc") == 0;
         if (K == 384 && pc_k) {
-            if (int st = launch_row_gemm_k384(a, ascale, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream, afmt))
+            if (int st = launch_row_gemm_k384(a, ascale, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream, afmt, alo))
                 return st;
             return check_launch("dg_row_gemm");
         }

@@ -107,8 +107,9 @@ struct EpiK {
 // edge-level launch of the same kernel: pair.h, row_gemm_n384.hip).
 struct ProbK {
     const float* a;           // [R,384] float32, or (H16) [R,384] fp16, or (afmt 2) [R,384] 3-byte elements (DG_DTYPE_F32_H24)
-    const float* ascale;      // H16: inverse row scales [R]
-    int afmt;                 // 0 float32, 1 H16, 2 H24
+    const float* ascale;      // H16 / H32: inverse row scales [R]
+    const void* alo;          // H32: the lo plane [R,384] fp16
+    int afmt;                 // 0 float32, 1 H16, 2 H24, 3 H32 (DG_DTYPE_F32_H32: hi + lo fp16 planes under one row scale)
     const f16x8* packed;
     float* y;
     int64_t R;
@@ -118,7 +119,9 @@ struct ProbK {
 // NP (fp16-plane operand only): 2 products per k-step (x . w_hi + x . w_lo); 1 (x . w_hi) is the DG_DH_PRODUCTS=1 experiment.
 template <bool RES, bool LN, int FMT, int NP = 2>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(const ProbK p0, const ProbK p1, const int nb0) {
-    constexpr bool H16 = FMT == 1, H24 = FMT == 2;
+    // H16: the operand arrives as fp16 plane(s) + row scales and is only MOVED by the producers; TWO: with its lo plane (H32: the
+    // float32-class split done once by the writer instead of by every reader)
+    constexpr bool H16 = FMT == 1 || FMT == 3, TWO = FMT == 3, H24 = FMT == 2;
     static_assert(NP == 2 || (NP == 1 && FMT == 1 && !LN), "single-product arithmetic: the backward's fp16-plane operand only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
     const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
     const float* __restrict__ const a = second ? p1.a : p0.a;
     const float* __restrict__ const ascale = second ? p1.ascale : p0.ascale;
+    const void* __restrict__ const alo = second ? p1.alo : p0.alo;
     const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
     float* __restrict__ const y = second ? p1.y : p0.y;
     const int64_t R = second ? p1.R : p0.R;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         const int64_t st = bidx + static_cast<int64_t>(t) * nblk;
         return ep.reverse ? total - 1 - st : st;
     };
-    constexpr int DEPTH = H16 ? 2 * kDepth : kDepth;      // stages in flight (H16 stages are half the bytes: twice as many)
+    constexpr int DEPTH = (H16 && !TWO) ? 2 * kDepth : kDepth;      // stages in flight (H16 stages are half the bytes: twice as many)
     const int TP = (T + DEPTH - 1) / DEPTH * DEPTH;
 
     if (w >= kCons) {
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             tab[pt] = ep.gamma[pt];
             tab[128 + pt] = ep.beta[pt];
         }
-        float4 pf[DEPTH][H16 ? 4 : 6];      // (H16: three pieces + the stage's inverse row scales, kept in .x of the fourth)
+        constexpr int NPF = TWO ? 7 : (H16 ? 4 : 6);
+        float4 pf[DEPTH][NPF];      // (H16: three pieces (+ three of the lo plane) + the stage's inverse row scales, kept in .x of the last)
         // half-wave hw streams rows 2 hw, 2 hw + 1 of the stage: six consecutive 512-byte pieces (row-major, chunk minor)
         const unsigned voff = static_cast<unsigned>(hw) * 3072u + static_cast<unsigned>(l32) * 16u;
         // H16: thread pt moves the 16-byte pieces pt, pt + 256, pt + 512 of the stage's 768 (= 16 rows x 48); piece q is slot
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
             const int q = pt + 256 * i, row = q / 48, slot = q % 48;
             hdst[i] = static_cast<unsigned>(row * 768 + ((slot & ~15) | ((slot & 15) ^ row)) * 16);
         }
-        auto fetch = [&](float4 (&set)[H16 ? 4 : 6], int t) {
+        auto fetch = [&](float4 (&set)[NPF], int t) {
             if (t > T - 1) t = T - 1;
             if (H16) {
                 const int64_t r0 = stage_of(t) * kSR;
@@ -180,8 +185,16 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
                     set[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<unsigned>(pt) * 16u, i * 4096, 0));
+                if (TWO) {
+                    const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(
+                        reinterpret_cast<_Float16*>(const_cast<void*>(alo)) + r0 * 384, 0, static_cast<int>(left < (1 << 30) ? left : (1 << 30)),
+                        0x00020000);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        set[3 + i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rlo, static_cast<unsigned>(pt) * 16u, i * 4096, 0));
+                }
                 // threads 0..15: the inverse scale of row pt (rows past the end read as 0: their products are never stored)
-                set[3].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, pt < 16 ? static_cast<unsigned>(pt) * 4u : 0x7FFFFFF0u, 0, 0));
+                set[NPF - 1].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, pt < 16 ? static_cast<unsigned>(pt) * 4u : 0x7FFFFFF0u, 0, 0));
                 return;
             }
             const int64_t r0 = stage_of(t) * kSR;
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         // piece i of the thread: row 2 hw + i / 3, chunk i % 3; float4 column c = l32 of the chunk covers k = 4c .. 4c + 3:
         // block (chunk, c >> 1), half c & 1; row r of a block sits at position r ^ (block & 7)
         const int blk = l32 >> 1;
-        auto split = [&](float4 (&set)[H16 ? 4 : 6], int t) {      // stage t -> planes[t & 1]
+        auto split = [&](float4 (&set)[NPF], int t) {      // stage t -> planes[t & 1]
             char* const pl = smem + (t & 1) * kStage;
             if (H16) {
 #pragma unroll
@@ -218,8 +231,9 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
                     // (volatile: the first use of the loads stays behind the previous iteration's barrier)
                     asm volatile("" : "+v"(set[i].x), "+v"(set[i].y), "+v"(set[i].z), "+v"(set[i].w));
                     *reinterpret_cast<float4*>(pl + hdst[i]) = set[i];
+                    if (TWO) *reinterpret_cast<float4*>(pl + kPlane + hdst[i]) = set[3 + i];
                 }
-                if (pt < 16) *reinterpret_cast<float*>(pl + 2 * kPlane + pt * 4) = set[3].x;
+                if (pt < 16) *reinterpret_cast<float*>(pl + 2 * kPlane + pt * 4) = set[NPF - 1].x;
                 return;
             }
             if (K3_DBG & 2) {
@@ -393,7 +407,32 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_k384_kernel(con
         if (t < T) {
             const char* pl = smem + (t & 1) * kStage;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (H16) {
+            if (TWO) {
+                // float32 class: three products per k-step on three chains over the whole contraction, one fold (one scale per row)
+                f32x4 q0, q1, q2;
+#pragma unroll
+                for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const f16x8 xh = *reinterpret_cast<const f16x8*>(pl + kc * 256 + xo_h[ks]);
+                        const f16x8 xl = *reinterpret_cast<const f16x8*>(pl + kPlane + kc * 256 + xo_h[ks]);
+                        const f16x8 wh = wf[4 * kc + ks][0], wl = wf[4 * kc + ks][NP == 1 ? 0 : 1];
+                        if (kc == 0 && ks == 0) {
+                            mfma16_first(q0, wl, xh);
+                            mfma16_first(q1, wh, xl);
+                            mfma16_first(q2, wh, xh);
+                        } else {
+                            mfma16(q0, wl, xh);
+                            mfma16(q1, wh, xl);
+                            mfma16(q2, wh, xh);
+                        }
+                    }
+                const float rs = *reinterpret_cast<const float*>(pl + 2 * kPlane + n * 4);
+                mfma_results_ready();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = ((q0[i] + q1[i]) + q2[i]) * (rs * (i == 0 ? cs.x : i == 1 ? cs.y : i == 2 ? cs.z : cs.w));
+            } else if (H16) {
                 // two products per k-step, six independent chains (chunk x weight plane), one fold with the row's inverse scale
                 f32x4 pl0[3], ph0[3];
 #pragma unroll
@@ -516,6 +555,10 @@ int launch(const ProbK& p0, const ProbK* p1, hipStream_t stream) {
         case 9: DG_K384_LAUNCH(true, false, 2) break;
         case 10: DG_K384_LAUNCH(false, true, 2) break;
         case 8: DG_K384_LAUNCH(false, false, 2) break;
+        case 15: DG_K384_LAUNCH(true, true, 3) break;
+        case 13: DG_K384_LAUNCH(true, false, 3) break;
+        case 14: DG_K384_LAUNCH(false, true, 3) break;
+        case 12: DG_K384_LAUNCH(false, false, 3) break;
         default: DG_K384_LAUNCH(false, false, 0) break;
     }
 #undef DG_K384_LAUNCH
@@ -531,9 +574,10 @@ int flush_row_gemm_k384(hipStream_t stream) {
 
 int launch_row_gemm_k384(const void* a, const float* ascale, const void* packed, float* y, int64_t R, const float* bias, int relu,
                          const float* residual, const float* gamma, const float* beta, float* mean, float* rstd,
-                         float* pre_ln, float eps, hipStream_t stream, int afmt) {
-    if ((afmt == 1) != (ascale != nullptr)) return fail(DG_E_ARG, "row_gemm_k384: row scales go with the fp16 plane (afmt 1)");
-    const ProbK p{static_cast<const float*>(a), ascale, afmt, static_cast<const f16x8*>(packed), y, R,
+                         float* pre_ln, float eps, hipStream_t stream, int afmt, const void* alo) {
+    if ((afmt == 1 || afmt == 3) != (ascale != nullptr)) return fail(DG_E_ARG, "row_gemm_k384: row scales go with the fp16 planes (afmt 1, 3)");
+    if ((afmt == 3) != (alo != nullptr)) return fail(DG_E_ARG, "row_gemm_k384: the lo plane goes with afmt 3");
+    const ProbK p{static_cast<const float*>(a), ascale, alo, afmt, static_cast<const f16x8*>(packed), y, R,
                   EpiK{bias, residual, gamma, beta, mean, rstd, pre_ln, eps, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;

@@ -89,8 +89,9 @@ struct Prob {
     const float* a;
     const f16x8* packed;
     float* y;             // [R,384] float32, or (H16) [R,384] fp16, or (yfmt 2) [R,384] 3-byte elements
-    float* yscale;        // H16: inverse row scales [R]
-    int yfmt;             // 0 float32, 1 H16, 2 H24 (DG_DTYPE_F32_H24: top 24 bits of every float32)
+    float* yscale;        // H16 / H32: inverse row scales [R]
+    void* ylo;            // H32: the lo plane [R,384] fp16
+    int yfmt;             // 0 float32, 1 H16, 2 H24 (DG_DTYPE_F32_H24: top 24 bits of every float32), 3 H32 (hi + lo fp16 planes)
     int64_t R;
     Epi ep;
 };
@@ -106,7 +107,7 @@ struct Prob {
 // 1.15e-3 on the chembl_b4 golden, outside the bar; DG_DH_PRODUCTS=1 selects it for the record).
 template <int FMT, int MODE, int NP = 3>
 __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(const Prob p0, const Prob p1, const int nb0) {
-    constexpr bool H16 = FMT == 1, H24 = FMT == 2;
+    constexpr bool H16 = FMT == 1 || FMT == 3, TWO = FMT == 3, H24 = FMT == 2;      // TWO: the lo plane of the split leaves too (H32)
     static_assert(NP == 3 || ((NP == 1 || NP == 2) && FMT == 1 && MODE == 2), "reduced products: fp16-plane results of the backward only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
     const f16x8* __restrict__ const packed = second ? p1.packed : p0.packed;
     float* __restrict__ const y = second ? p1.y : p0.y;
     float* __restrict__ const yscale = second ? p1.yscale : p0.yscale;
+    void* __restrict__ const ylo = second ? p1.ylo : p0.ylo;
     const int64_t R = second ? p1.R : p0.R;
     const Epi ep = second ? p1.ep : p0.ep;
     const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<_Float16*>(y) + r0 * 384, 0, rows * 768, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(yscale + r0, 0, rows * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(
+                    TWO ? reinterpret_cast<_Float16*>(ylo) + r0 * 384 : reinterpret_cast<_Float16*>(y), 0, TWO ? rows * 768 : 0, 0x00020000);
                 const int g = pt >> 4, sub = (pt >> 3) & 1, l8 = pt & 7, row = 2 * g + sub;
                 const unsigned lo_off = static_cast<unsigned>(row * 1536 + l8 * 32 + sub * 16);
                 const unsigned hi_off = static_cast<unsigned>(row * 1536 + l8 * 32 + (1 - sub) * 16);
@@ -269,20 +273,35 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                 // its data registers over many cycles, and a VALU write into them right behind the store (hipcc reuses the
                 // registers of the previous vector; it only pads stores WITHOUT an SGPR offset) corrupted the second dword of
                 // lanes 12..15 of every DPP row (found by tests/test_hip_kernels.py::test_hidden_fp16_plane_*).
-                u32x4 hq[6];
+                u32x4 hq[6], lq[TWO ? 6 : 1];
 #pragma unroll
                 for (int mm = 0; mm < 6; ++mm) {
-                    const f32x2 x0 = f32x2{vl[mm].x, vl[mm].y} * sc, x1 = f32x2{vl[mm].z, vl[mm].w} * sc;
-                    const f32x2 x2 = f32x2{vh[mm].x, vh[mm].y} * sc, x3 = f32x2{vh[mm].z, vh[mm].w} * sc;
+                    f32x2 x0 = f32x2{vl[mm].x, vl[mm].y} * sc, x1 = f32x2{vl[mm].z, vl[mm].w} * sc;
+                    f32x2 x2 = f32x2{vh[mm].x, vh[mm].y} * sc, x3 = f32x2{vh[mm].z, vh[mm].w} * sc;
                     const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
                     const f16x2 h2 = __builtin_convertvector(x2, f16x2), h3 = __builtin_convertvector(x3, f16x2);
                     hq[mm] = u32x4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2),
                                    __builtin_bit_cast(unsigned, h3)};
+                    if (TWO) {      // lo = fp16(x s - hi): the residual is exact in float32 (the split of row_gemm.hip, done once here)
+                        x0 -= __builtin_convertvector(h0, f32x2);
+                        x1 -= __builtin_convertvector(h1, f32x2);
+                        x2 -= __builtin_convertvector(h2, f32x2);
+                        x3 -= __builtin_convertvector(h3, f32x2);
+                        const f16x2 l0 = __builtin_convertvector(x0, f16x2), l1 = __builtin_convertvector(x1, f16x2);
+                        const f16x2 l2 = __builtin_convertvector(x2, f16x2), l3 = __builtin_convertvector(x3, f16x2);
+                        lq[mm] = u32x4{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l2),
+                                       __builtin_bit_cast(unsigned, l3)};
+                    }
                 }
                 unsigned inv = (e - 14u) << 23, so = soff;
                 asm volatile("" : "+v"(hq[0]), "+v"(hq[1]), "+v"(hq[2]), "+v"(hq[3]), "+v"(hq[4]), "+v"(hq[5]), "+v"(inv), "+v"(so));
+                if (TWO) asm volatile("" : "+v"(lq[0]), "+v"(lq[1]), "+v"(lq[2]), "+v"(lq[3]), "+v"(lq[4]), "+v"(lq[5]));
 #pragma unroll
                 for (int mm = 0; mm < 6; ++mm) __builtin_amdgcn_raw_buffer_store_b128(hq[mm], rsrc, hoff, mm * 128, 0);
+                if (TWO) {
+#pragma unroll
+                    for (int mm = 0; mm < 6; ++mm) __builtin_amdgcn_raw_buffer_store_b128(lq[mm], rlo, hoff, mm * 128, 0);
+                }
                 __builtin_amdgcn_raw_buffer_store_b32(inv, rsc, so, 0, 0);
                 asm volatile("s_nop 15" ::: "memory");
             } else if (H24) {
@@ -504,6 +523,10 @@ int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
                                p1 ? *p1 : p0, nb0);
         } else if (mode == 2) DG_N384_LAUNCH(1, 2)
         else DG_N384_LAUNCH(1, 0)
+    } else if (p0.yfmt == 3) {
+        if (mode == 1) DG_N384_LAUNCH(3, 1)
+        else if (mode == 2) DG_N384_LAUNCH(3, 2)
+        else DG_N384_LAUNCH(3, 0)
     } else if (p0.yfmt == 2) {
         if (mode == 1) DG_N384_LAUNCH(2, 1)
         else if (mode == 2) DG_N384_LAUNCH(2, 2)
@@ -525,9 +548,10 @@ int flush_row_gemm_n384(hipStream_t stream) {
 }
 
 int launch_row_gemm_n384(const float* a, const void* packed, void* y, float* yscale, int64_t R, const float* bias, int relu,
-                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream, int yfmt) {
-    if ((yfmt == 1) != (yscale != nullptr)) return fail(DG_E_ARG, "row_gemm_n384: row scales go with the fp16 plane (yfmt 1)");
-    const Prob p{a, static_cast<const f16x8*>(packed), static_cast<float*>(y), yscale, yfmt, R,
+                         unsigned* relu_bits, const unsigned* mask_bits, hipStream_t stream, int yfmt, void* ylo) {
+    if ((yfmt == 1 || yfmt == 3) != (yscale != nullptr)) return fail(DG_E_ARG, "row_gemm_n384: row scales go with the fp16 planes (yfmt 1, 3)");
+    if ((yfmt == 3) != (ylo != nullptr)) return fail(DG_E_ARG, "row_gemm_n384: the lo plane goes with yfmt 3");
+    const Prob p{a, static_cast<const f16x8*>(packed), static_cast<float*>(y), yscale, ylo, yfmt, R,
                  Epi{bias, mask_bits, relu_bits, relu, take_direction(R)}};
     if (pair_mode() && !g_rider.valid && R <= kRiderMaxRows) {      // waits for the next launch of this kernel
         g_rider.valid = true;

@@ -23,7 +23,7 @@ from . import _lib
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops", "traffic_floor_bytes",
-           "set_activation_dtype", "activation_dtype", "hidden_storage", "hidden_to_float", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
+           "set_activation_dtype", "activation_dtype", "hidden_storage", "hidden_forward_storage", "hidden_to_float", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -115,12 +115,23 @@ def hidden_storage() -> str:
     return mode
 
 
+def hidden_forward_storage() -> str:
+    """Storage of the FORWARD's h = relu(fc1 x) in the default mode (DG_HIDDEN=dh16): "split" -- the float32-class hi / lo fp16
+    split under one row scale, done once by the launch that writes h (DG_DTYPE_F32_H32: fc2's launch only moves the planes, the
+    weight gradient dW2 = dz^T h reads the hi plane alone) -- or "f32" (DG_HIDDEN_FWD=f32; always with the other modes)."""
+    if hidden_storage() == "dh16" and os.environ.get("DG_HIDDEN_FWD", "split") != "f32":
+        return "split"
+    return "f32"
+
+
 def _hidden_code(adt) -> int:
     """ABI dtype code of the FORWARD's hidden tensor h for activations of ``adt``."""
     if adt == torch.float32:
         mode = hidden_storage()
         if mode in ("f16", "f24"):
             return _lib.F32_H16 if mode == "f16" else _lib.F32_H24
+        if hidden_forward_storage() == "split":
+            return _lib.F32_H32
     return _lib.DTYPES[adt]
 
 
@@ -140,6 +151,8 @@ def _ffn_bwd_codes(h, adt, R: int, H: int):
     ``_hidden_code_bwd`` says now -- equal, or (h float32, dh narrow) the DG_DTYPE_F32_DH16 / _DH24 pairs."""
     if _is_h16(h):
         code = _hidden_code_of(h, R, H)
+        if code == _lib.F32_H32:      # (h pre-split: dh is the fp16 plane of the default mode)
+            return _lib.F32_H32_DH16, _lib.F32_H16
         return code, code
     dh_code = _hidden_code_bwd(adt)
     if dh_code == _lib.F32_H16:
@@ -159,6 +172,8 @@ def _hidden_empty(R: int, H: int, adt, code: int, device):
 
 def _hrow_bytes(code: int, es: int, H: int) -> int:
     """Bytes per row of a hidden tensor (traffic accounting)."""
+    if code == _lib.F32_H32:
+        return 4 * H + 4
     return 2 * H + 4 if code == _lib.F32_H16 else (3 * H if code == _lib.F32_H24 else es * H)
 
 
@@ -173,7 +188,10 @@ def _hptr(t):
 
 def _hidden_code_of(buf, R: int, H: int = 384) -> int:
     """The ABI dtype code of a hidden buffer made by ``_hidden_empty`` (its size tells the storage)."""
-    return _lib.F32_H24 if buf.numel() == R * H * 3 else _lib.F32_H16
+    if buf.numel() == R * H * 3:
+        return _lib.F32_H24
+    plane = (R * H * 2 + 255) // 256 * 256
+    return _lib.F32_H32 if buf.numel() == 2 * plane + 4 * R else _lib.F32_H16
 
 
 def hidden_to_float(buf, R: int, H: int = 384):
@@ -183,9 +201,12 @@ def hidden_to_float(buf, R: int, H: int = 384):
         bits = (b[:, 0] << 8) | (b[:, 1] << 16) | (b[:, 2] << 24)
         return bits.view(torch.float32).view(R, H)
     off = int(_lib.load().dg_hidden_scale_offset(R, H))
-    half = buf[:R * H * 2].view(torch.float16).view(R, H)
+    half = buf[:R * H * 2].view(torch.float16).view(R, H).float()
+    if _hidden_code_of(buf, R, H) == _lib.F32_H32:      # hi plane | lo plane | scales
+        half = half + buf[off:off + R * H * 2].view(torch.float16).view(R, H).float()
+        off *= 2
     scale = buf[off:off + 4 * R].view(torch.float32)
-    return half.float() * scale[:, None]
+    return half * scale[:, None]
 
 
 # --------------------------------------------------------------------------
@@ -647,7 +668,7 @@ def _wgrad_h16(dy2, x2, want_bias, ws=None):
         _lib.check(lib.dg_linear_wgrad(_hptr(dy2), None, _hptr(x2), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr(), ws.numel(), R, N, K,
                                        code, _lib.stream_of(other)), "dg_linear_wgrad")
     _pair_hold(dy2, x2, dw, db, ws)
-    _account(_wgrad_key(R, N, K), R * (4 * 128 + _hrow_bytes(code, 4, 384)), 2 * R * N * K)
+    _account(_wgrad_key(R, N, K), R * (4 * 128 + _hrow_bytes(_lib.F32_H16 if code == _lib.F32_H32 else code, 4, 384)), 2 * R * N * K)
     return dw, db
 
 
@@ -1531,7 +1552,8 @@ class _FFNLNBwd(Function):
         if dx is not None:
             _account(_gemm_key(R, H, C), R * (dhb + es * 2 * C), 2 * R * C * H)
         if want_w:
-            _account(_wgrad_key(R, C, H), R * (es * C + hb), 2 * R * C * H)
+            # (a pre-split h: the weight gradient reads its hi plane only)
+            _account(_wgrad_key(R, C, H), R * (es * C + (2 * H + 4 if code == _lib.F32_H32_DH16 else hb)), 2 * R * C * H)
             _account(_wgrad_key(R, H, C), R * (es * C + dhb), 2 * R * C * H)
         ctx.save_for_backward(x, w1, w2, gamma, h, mean, rstd, pre, bits, dy2, dz, dh)
         ctx.had_add = dz_add is not None      # (includes the dy-None case: never differentiated again)
@@ -1715,7 +1737,7 @@ class _FFNLNPairBwd(Function):
             if p["dx"] is not None:
                 _account(_gemm_key(R, H, C), R * (dhb + es * 2 * C), 2 * R * C * H)
             if p["want_w"]:
-                _account(_wgrad_key(R, C, H), R * (es * C + hb), 2 * R * C * H)
+                _account(_wgrad_key(R, C, H), R * (es * C + (2 * H + 4 if code == _lib.F32_H32_DH16 else hb)), 2 * R * C * H)
                 _account(_wgrad_key(R, H, C), R * (es * C + dhb), 2 * R * C * H)
         saved, outs = [], []
         for p in probs:

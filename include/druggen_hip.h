@@ -61,6 +61,16 @@ extern "C" {
  * dh W1, dW1 = dh^T x): its rounding stays a rounding.                                                                   */
 #define DG_DTYPE_F32_DH16 4
 #define DG_DTYPE_F32_DH24 5
+/* The float32-class storage of the FORWARD's hidden tensor: the hi / lo fp16 split of csrc/row_gemm.hip under one power-of-two
+ * scale per row, done ONCE by the launch that writes h instead of by every launch that reads it.  Layout
+ * (dg_hidden_bytes(R, 384, dtype)): [R][384] fp16 hi plane, then at byte offset dg_hidden_scale_offset(R, 384) the [R][384] fp16
+ * lo plane, then at twice that offset the [R] float32 inverse scales -- 4 bytes per element like float32, hi + lo carries 22
+ * significand bits of every element within 2^-18 of its row maximum.  dg_row_gemm reads both planes (three products, float32
+ * class: nothing of the forward pass changes class); dg_linear_wgrad reads the hi plane only (the weight gradient is a backward
+ * tensor: dW2 = dz^T h_hi, half the bytes, two products).  DG_DTYPE_F32_H32_DH16 (7): dg_edge_ffn_ln_bwd(_pair) with such an h
+ * and dh as DG_DTYPE_F32_H16.                                                                                             */
+#define DG_DTYPE_F32_H32 6
+#define DG_DTYPE_F32_H32_DH16 7
 #define DG_E_SHAPE   (-1)         /* unsupported shape (wrapper must not continue) */
 #define DG_E_ARG     (-2)         /* null pointer / bad argument */
 #define DG_E_WORKSPACE (-3)       /* workspace too small */

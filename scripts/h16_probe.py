@@ -43,7 +43,7 @@ def timeit(fn, n=10):
 
 
 res = {}
-for name, code in (("f32", 0), ("h24", _lib.F32_H24), ("h16", _lib.F32_H16)):
+for name, code in (("f32", 0), ("h32", _lib.F32_H32), ("h24", _lib.F32_H24), ("h16", _lib.F32_H16)):
     # fc1: h = relu(x W1^T + b1)
     h, bits = dgf.row_gemm(x, pw(w1, 0), C, H, bias=b1, relu=True, want_relu_bits=True, code=code)
     hf = dgf.hidden_to_float(h, R) if code else h
@@ -76,7 +76,7 @@ dhd = (dzd @ w2.double()) * (hd > 0)
 dxd = dzd + dhd @ w1.double()
 nw = (R + 31) // 32 * 512      # words the kernel writes (the allocation is an upper bound over kernel variants)
 assert torch.equal(res["f32"]["bits"][:nw], res["h16"]["bits"][:nw]), "ReLU masks differ"
-for name in ("f32", "h24", "h16"):
+for name in ("f32", "h32", "h24", "h16"):
     r = res[name]
     print(name, "h", f"{rel(r['h'][:n], hd):.2e}", "pre", f"{rel(r['pre'][:n], pred):.2e}", "y", f"{rel(r['y'][:n], yd):.2e}",
           "dh", f"{rel(r['dh'][:n], dhd):.2e}", "dx", f"{rel(r['dx'][:n], dxd):.2e}")
@@ -91,7 +91,7 @@ for i in range(0, R, 65536):
     dw2d += dzs.t() @ hs
     dw1d += dhs.t() @ xs
     db1d += dhs.sum(0)
-for name in ("f32", "h24", "h16"):
+for name in ("f32", "h32", "h24", "h16"):
     r = res[name]
     print(name, "dW2", f"{rel(r['dw2'], dw2d):.2e}", "db2", f"{rel(r['db2'], dz.double().sum(0)):.2e}", "dW1", f"{rel(r['dw1'], dw1d):.2e}",
           "db1", f"{rel(r['db1'], db1d):.2e}")

@@ -1305,19 +1305,26 @@ def _h16_chain(R, seed=300, row_scales=None):
     return L, dgf, dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, g=g, be=be, dz=dz, pw=pw, C=C, H=H)
 
 
+def _hidden_bound_doc():
+    """f32s ("split", DG_DTYPE_F32_H32): hi + lo fp16 planes under one row scale: 22 significand bits of every element within
+    2^-18 of its row maximum -- bound 2^-21 relative + 2^-39 of the row maximum."""
+
+
 def _hidden_bound(ref, fmt):
     """Per-element bound of a narrow hidden storage against the float32 kernel's value: fp16 plane -- half an fp16 ulp (2^-11
     relative) + the denormal floor 2^-25 of the row maximum; three-byte elements -- half a unit of the 16th significant bit."""
     if fmt == "f24":
         return ref.abs() * 2.0 ** -16
+    if fmt == "f32s":
+        return ref.abs() * 2.0 ** -21 + ref.abs().amax(1, keepdim=True) * 2.0 ** -39
     return ref.abs() * 2.0 ** -11 + ref.abs().amax(1, keepdim=True) * 2.0 ** -25
 
 
 def _hidden_code(L, fmt):
-    return L.F32_H24 if fmt == "f24" else L.F32_H16
+    return {"f24": L.F32_H24, "f32s": L.F32_H32}.get(fmt, L.F32_H16)
 
 
-@pytest.mark.parametrize("fmt", ["f24", "f16"])
+@pytest.mark.parametrize("fmt", ["f24", "f16", "f32s"])
 @pytest.mark.parametrize("R", [1, 15, 16, 17, 33, 1000, 4097, 70000])
 def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt, monkeypatch):
     """128 -> 384 row GEMM writing DG_DTYPE_F32_H24 / _H16, 384 -> 128 row GEMM and both weight-gradient shapes reading it
@@ -1356,9 +1363,20 @@ def test_hidden_fp16_plane_writer_reader_and_weight_gradients(R, fmt, monkeypatc
     assert _rel(dx, dz.double().cpu() + dhd.double().cpu() @ t["w1"].double().cpu()) < TOL
     # weight gradients: dW2 = dz^T h (x operand hidden), dW1 = dh^T x (dy operand hidden), with their bias sums
     dw2, db2 = dgf._wgrad(dz, h16, True)
-    assert _rel(dw2, dz.double().cpu().t() @ hd64) < TOL and _rel(db2, dz.double().cpu().sum(0)) < TOL
+    if fmt == "f32s":      # (the weight gradient reads the hi plane of a pre-split tensor only)
+        off = int(L.load().dg_hidden_scale_offset(R, H))
+        hi64 = (h16[:R * H * 2].view(torch.float16).view(R, H).double() * h16[2 * off:2 * off + 4 * R].view(torch.float32).double()[:, None]).cpu()
+        assert _rel(dw2, dz.double().cpu().t() @ hi64) < TOL and _rel(dw2, dz.double().cpu().t() @ hd64) < 5e-4
+    else:
+        assert _rel(dw2, dz.double().cpu().t() @ hd64) < TOL
+    assert _rel(db2, dz.double().cpu().sum(0)) < TOL
     dw1, db1 = dgf._wgrad(dh16, x, True)
-    assert _rel(dw1, dhd.double().cpu().t() @ x.double().cpu()) < TOL and _rel(db1, dhd.double().cpu().sum(0)) < TOL
+    if fmt == "f32s":
+        off = int(L.load().dg_hidden_scale_offset(R, H))
+        dhi64 = (dh16[:R * H * 2].view(torch.float16).view(R, H).double() * dh16[2 * off:2 * off + 4 * R].view(torch.float32).double()[:, None]).cpu()
+        assert _rel(dw1, dhi64.t() @ x.double().cpu()) < TOL and _rel(db1, dhi64.sum(0)) < TOL
+    else:
+        assert _rel(dw1, dhd.double().cpu().t() @ x.double().cpu()) < TOL and _rel(db1, dhd.double().cpu().sum(0)) < TOL
     # bit-reproducible
     dw2b, _ = dgf._wgrad(dz, h16, True)
     assert torch.equal(dw2, dw2b)
@@ -1392,7 +1410,7 @@ def test_backward_fp16_plane_two_product_arithmetic(R, monkeypatch):
     assert not torch.equal(out["3"], out["2"])
 
 
-@pytest.mark.parametrize("fmt", ["f24", "f16"])
+@pytest.mark.parametrize("fmt", ["f24", "f16", "f32s"])
 def test_hidden_fp16_plane_row_scales_cover_the_float32_range(fmt):
     """One power-of-two scale per ROW (fp16 plane) / the float32 exponent of every element (three-byte elements): rows 2^+-60
     apart, an all-zero row and a row whose values span 2^20 keep the per-element bound; the 384 -> 128 reader un-scales
@@ -1414,7 +1432,7 @@ def test_hidden_fp16_plane_row_scales_cover_the_float32_range(fmt):
     assert float(err.max()) < TOL
 
 
-@pytest.mark.parametrize("fmt", ["f24", "f16"])
+@pytest.mark.parametrize("fmt", ["f24", "f16", "f32s"])
 @pytest.mark.parametrize("Rn,Re", [(360, 70000), (33, 66000)])
 def test_hidden_fp16_plane_riding_launches_equal_separate_launches(Rn, Re, fmt, monkeypatch):
     """Riding launches (pair.h) with DG_DTYPE_F32_H16 operands: row GEMMs bit-identical to separate launches, weight
