@@ -31,6 +31,8 @@
 // flight); the producer of the float32 operand multiplies its rows by s_r in front of its usual running-scale split; the
 // consumers run TWO products per tile pair (the fp16 operand has no lo plane).
 #include "bf16.h"
+
+#include <cstdlib>
 #include "wgrad_stream.h"
 #include "pair.h"
 
@@ -117,7 +119,11 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
     static_assert(SR * COLS * 4 == kStageBytes && (LPR == 32 || LPR == 16) && N % CW == 0, "stage geometry");
     // HID 3 / 4 (DG_DTYPE_F32_H24): dy / x holds the top 24 bits of every float32 (3 bytes per element): the producers of those
     // columns fetch 12 bytes per row instead of 16 and unpack; everything else is the float32 kernel
-    static_assert(HID == 0 || (CW == 128 && (((HID == 1 || HID == 3) && N == 384) || ((HID == 2 || HID == 4) && K == 384))),
+    // HID 5 (128 x 128 only): x is float32 in HBM but enters the products as ONE fp16 plane -- a weight gradient is a leaf of the
+    // backward, the 2^-12 rounding of its activation operand is independent from element to element and averages over the rows
+    // (the same arithmetic as dW2 = dz^T h_hi and dW1 = dh^T x of the feed-forward): two products, no lo plane of x
+    static_assert(HID == 0 || (HID == 5 && N == 128 && K == 128) ||
+                      (CW == 128 && (((HID == 1 || HID == 3) && N == 384) || ((HID == 2 || HID == 4) && K == 384))),
                   "narrow operand: the 384-wide one");
     constexpr bool HS = HID == 1 || HID == 2;                 // fp16 plane + row scales
     constexpr int DEPTH_ALL = HS ? 2 * kDepth : kDepth;       // iterations are padded to whole groups of this
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                     asm volatile("" ::"v"(hw), "v"(lw));
                 } else {
                     *reinterpret_cast<u32x4*>(st + wa[j]) = hw;
-                    *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
+                    if (!(HID == 5 && !is_dy)) *reinterpret_cast<u32x4*>(st + wa[j] + 1024) = lw;
                 }
             }
             if (!HS && part_b && is_dy && live) {
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
 #pragma unroll
                     for (int j = 0; j < TK; ++j) {
                         xh[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048);
-                        if (HID != 2) xl[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048 + 1024);
+                        if (HID != 2 && HID != 5) xl[j] = *reinterpret_cast<const f16x8*>(st + off_x + (u * NTILES + j) * 2048 + 1024);
                     }
                 };
                 // the stage's tags first, the first sub-step's fragments right behind them: the tag test then waits for
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(64 * (kConsumers + kProducers)) void wgrad_stream_k
                         for (int i = 0; i < TN; ++i)
 #pragma unroll
                             for (int j = 0; j < TK; ++j) {
-                                if ((HID == 1 && part == 0) || (HID == 2 && part == 1)) continue;      // no lo plane of the fp16 operand
+                                if ((HID == 1 && part == 0) || ((HID == 2 || HID == 5) && part == 1)) continue;      // no lo plane of the fp16 operand
                                 if (WS_DBG & 1) asm volatile("" ::"v"(yl[i]), "v"(yh[i]), "v"(xl[j]), "v"(xh[j]));
                                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? yl[i] : yh[i], part == 1 ? xl[j] : xh[j],
                                                                                        acc[i][j], 0, 0, 0);
@@ -563,7 +569,10 @@ int launch(const ProbW& p0, int nb0, const ProbW* p1, int nb1, int N, int K, hip
     }
     const int fmt = p0.hfmt;      // 0 float32, 1 fp16 plane + row scales, 2 three-byte elements: the 384-wide operand
     if (fmt && p0.dy1) return fail(DG_E_ARG, "wgrad_stream: three dy matrices cannot be combined with a narrow operand");
-    if (N == 128 && K == 128 && !fmt) DG_WS_LAUNCH(4, 4, 4, 2, 0)
+    // DG_WGRAD128_PRODUCTS=3: the activation operand of the 128 x 128 weight gradients with its lo plane (A/B, tests; read per launch)
+    const bool x_single = !(getenv("DG_WGRAD128_PRODUCTS") && atoi(getenv("DG_WGRAD128_PRODUCTS")) == 3);
+    if (N == 128 && K == 128 && !fmt && x_single) DG_WS_LAUNCH(4, 4, 4, 2, 5)
+    else if (N == 128 && K == 128 && !fmt) DG_WS_LAUNCH(4, 4, 4, 2, 0)
     else if (N == 384 && K == 128 && !fmt) DG_WS_LAUNCH(12, 4, 4, 2, 0)
     else if (N == 128 && K == 384 && !fmt) DG_WS_LAUNCH(4, 12, 2, 4, 0)
     else if (N == 384 && K == 128 && fmt == 1) DG_WS_LAUNCH(12, 4, 4, 2, 1)

@@ -2,16 +2,17 @@
 # Round-end evidence: bench lines of every BASELINE config, rocprofv3 kernel-trace summaries of the headline (c2, fp32)
 # and configs[2] (c3, bf16) steps, FETCH_SIZE / WRITE_SIZE passes of both (-> profiles/traffic.json).  Everything lands in
 # gpurun_out/<tag>/ ; copy what should be judged into profiles/.
-#   gpurun -- 'scripts/collect_profiles.sh r04 <commit>'
+#   gpurun -- 'scripts/collect_profiles.sh r05 <commit>'
 set -u
-tag=${1:-r04}; commit=${2:-unknown}
+tag=${1:-r05}; commit=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 # ---- bench lines
-$B --steps 10 --warmup 3 2>$O/bench_c2.err | tail -1 > $O/bench_c2.json
+$B --steps 20 --warmup 5 2>$O/bench_c2.err | tail -1 > $O/bench_c2.json
+cp $R/gpurun_out/bench_detail_c2_f32.json $O/bench_detail_c2_f32.json 2>/dev/null
 $B --config c3 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c3.json
 $B --config c4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4.json
 $B --config c5 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5.json
@@ -36,9 +37,10 @@ scripts/pmc_run.sh $tag/pmc_hb attn_half_bwd -- python $R/scripts/half_bwd_probe
 scripts/pmc_run.sh $tag/pmc_h32 attn_half_f32_fwd -- python $R/scripts/half_f32_probe.py > $O/pmc_attn_half_f32_fwd.txt 2>&1
 scripts/pmc_run.sh $tag/pmc_h32b attn_half_f32_bwd1 -- python $R/scripts/half_f32_bwd_check.py > $O/pmc_attn_half_f32_bwd1.txt 2>&1
 scripts/pmc_run.sh $tag/pmc_wg wgrad_stream -- python $R/scripts/wgrad_probe.py > $O/pmc_wgrad.txt 2>&1
-python scripts/wgrad_probe.py > $O/wgrad_probe_h3.txt 2>&1; DG_WGRAD=sym python scripts/wgrad_probe.py > $O/wgrad_probe_sym.txt 2>&1
+scripts/pmc_run.sh $tag/pmc_hid row_gemm -- python $R/scripts/h16_probe.py > $O/pmc_hidden_storage_gemms.txt 2>&1
+python scripts/h16_probe.py > $O/hidden_storage_probe.txt 2>&1
 python scripts/lnb_probe.py > $O/lnb_probe.txt 2>&1
-rm -rf $O/pmc_half $O/pmc_hb $O/pmc_h32 $O/pmc_h32b $O/pmc_wg $O/*.p[0-9].log
+rm -rf $O/pmc_half $O/pmc_hb $O/pmc_h32 $O/pmc_h32b $O/pmc_wg $O/pmc_hid $O/*.p[0-9].log
 cp profiles/traffic.json $O/traffic.json 2>/dev/null || echo '{"records": []}' > $O/traffic.json
 python scripts/pmc_traffic.py $(find $O/pmc_c2_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c2_WRITE_SIZE -name "*counter_collection.csv") c2 f32 256 $commit $O/traffic.json 150e6 > $O/traffic_c2.txt
 python scripts/pmc_traffic.py $(find $O/pmc_c3_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_c3_WRITE_SIZE -name "*counter_collection.csv") c3 bf16 2048 $commit $O/traffic.json 600e6 > $O/traffic_c3.txt
