@@ -75,6 +75,14 @@ __device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f
 }
 __device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
+// packed fp16 pair { fp16(s0 - hi.lo), fp16(s1 - hi.hi) }: the lo plane of two scaled values whose hi plane is `hpk`
+__device__ __forceinline__ unsigned lo_pair(unsigned hpk, float s0, float s1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hpk), "v"(s1));
+    return d;
+}
+
 struct Epi {
     const float* bias;            // [384] or null
     const unsigned* mask_bits;    // [stages][8][64] words written by a launch with relu_bits of the SAME geometry, or null
@@ -282,15 +290,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void row_gemm_n384_kernel(con
                     const f16x2 h2 = __builtin_convertvector(x2, f16x2), h3 = __builtin_convertvector(x3, f16x2);
                     hq[mm] = u32x4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2),
                                    __builtin_bit_cast(unsigned, h3)};
-                    if (TWO) {      // lo = fp16(x s - hi): the residual is exact in float32 (the split of row_gemm.hip, done once here)
-                        x0 -= __builtin_convertvector(h0, f32x2);
-                        x1 -= __builtin_convertvector(h1, f32x2);
-                        x2 -= __builtin_convertvector(h2, f32x2);
-                        x3 -= __builtin_convertvector(h3, f32x2);
-                        const f16x2 l0 = __builtin_convertvector(x0, f16x2), l1 = __builtin_convertvector(x1, f16x2);
-                        const f16x2 l2 = __builtin_convertvector(x2, f16x2), l3 = __builtin_convertvector(x3, f16x2);
-                        lq[mm] = u32x4{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l2),
-                                       __builtin_bit_cast(unsigned, l3)};
+                    if (TWO) {      // lo = fp16(x s - hi): the residual is exact in float32 (the split of row_gemm.hip, done once here);
+                        // one v_fma_mix per element: fma(hi as fp16 operand, -1, x s) rounded to fp16 in the same instruction
+                        lq[mm] = u32x4{lo_pair(__builtin_bit_cast(unsigned, h0), x0[0], x0[1]), lo_pair(__builtin_bit_cast(unsigned, h1), x1[0], x1[1]),
+                                       lo_pair(__builtin_bit_cast(unsigned, h2), x2[0], x2[1]), lo_pair(__builtin_bit_cast(unsigned, h3), x3[0], x3[1])};
                     }
                 }
                 unsigned inv = (e - 14u) << 23, so = soff;
