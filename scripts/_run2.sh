@@ -1,4 +1,3 @@
-python -m pytest tests/test_hip_kernels.py -m gpu -q -k "hidden or fused_ffn or paired" 2>&1 | tail -3
-timeout 300 python scripts/h16_probe.py 2>&1 | sed -n 2,3p
-for m in 1 2 3; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['ms_per_step'])"; done
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python -m pytest tests/test_hip_bf16.py tests/test_hip_kernels.py -m gpu -q -k "bf16 or ln_ or layernorm or LN" 2>&1 | tail -4
+python bench.py --config c3 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('c3', d['value'], d['ms_per_step'])"
+python bench.py --config c3 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('c3', d['value'], d['ms_per_step'])"
