@@ -372,7 +372,11 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
     float4 dgam = f4(0.f), dbet = f4(0.f), db2 = f4(0.f);
 
     // rows of this wave: 8 w + 2 it + half; operands of the NEXT tile are requested during this tile's MFMAs
+    // (the row statistics and the mask words too: loaded where they are used, each of the four row passes of a tile waited
+    // for its own mean / rstd with nothing else to do -- four exposed memory latencies per tile, 1 block per CU)
     u32x2_t dyN[4], prN[4];
+    float statN;      // lanes 0..7: mean of this wave's rows 8 w + lane, lanes 8..15: rstd of row 8 w + lane - 8
+    unsigned bitN[2];
     auto fetch = [&](int64_t t) {
         const int64_t r0 = t * kRowsPerTile;
 #pragma unroll
@@ -382,25 +386,35 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
             dyN[it] = *reinterpret_cast<const u32x2_t*>(dy + row * kC + 4 * col);
             prN[it] = *reinterpret_cast<const u32x2_t*>(pre + row * kC + 4 * col);
         }
+        {
+            int64_t row = r0 + 8 * w + (lane & 7);
+            if (row > R - 1) row = R - 1;
+            statN = (lane & 8 ? rstd : mean)[row];
+        }
+        const size_t bix = (static_cast<size_t>(t) * 512 + threadIdx.x) * 2;
+        bitN[0] = relu_bits[bix];
+        bitN[1] = relu_bits[bix + 1];
     };
     int64_t tix = blockIdx.x;
     if (tix < tiles) fetch(tix);
     for (; tix < tiles; tix += gridDim.x) {
         const int64_t r0 = tix * kRowsPerTile;
+        // per-iteration opaque copy of the lane id: every swizzled LDS offset below derives from it, so hipcc cannot keep
+        // the loop-invariant offsets of all four phases in registers for the whole kernel (it did: 256 VGPRs + scratch)
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int half = lo >> 5, col = lo & 31;
         __syncthreads();       // previous tile: dz tile and exchange tile fully consumed
-        unsigned long long bits;
-        {
-            const size_t bix = (static_cast<size_t>(tix) * 512 + threadIdx.x) * 2;
-            bits = static_cast<unsigned long long>(relu_bits[bix]) | (static_cast<unsigned long long>(relu_bits[bix + 1]) << 32);
-        }
+        const unsigned long long bits = static_cast<unsigned long long>(bitN[0]) | (static_cast<unsigned long long>(bitN[1]) << 32);
         // ---- LayerNorm backward of this wave's rows -> dz (HBM + LDS tile)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rr = 8 * w + 2 * it + half;
             const int64_t row = r0 + rr;
             const bool ok = row < R;
-            const int64_t rc = ok ? row : R - 1;
-            const float mu = mean[rc], rs = rstd[rc];
+            const int sti = __float_as_int(statN);
+            const float mu = __int_as_float(half ? __builtin_amdgcn_readlane(sti, 2 * it + 1) : __builtin_amdgcn_readlane(sti, 2 * it));
+            const float rs = __int_as_float(half ? __builtin_amdgcn_readlane(sti, 8 + 2 * it + 1) : __builtin_amdgcn_readlane(sti, 8 + 2 * it));
             float4 gy = unpack4_bf16(dyN[it]);
             if (!ok) gy = f4(0.f);
             const float4 xh = rs * (unpack4_bf16(prN[it]) - f4(mu));
@@ -419,14 +433,14 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
         if (!dx) continue;     // block-uniform
         __syncthreads();
         // ---- dh = (dz W2) * mask -> DH tile
-        gemm_up_tile<true, false>(dzt, wfa, lane, [&](int nb, const f32x4 (&acc)[3]) {
+        gemm_up_tile<true, false>(dzt, wfa, lo, [&](int nb, const f32x4 (&acc)[3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int g = nb * 3 + i;                     // layout written by the forward kernel (12 groups, 7 per word)
                 const unsigned t = g < 7 ? static_cast<unsigned>(bits) << (2 * g) : static_cast<unsigned>(bits >> 32) << (2 * (g - 7));
                 const float4 v = make_float4(t & 0x8000u ? acc[i][0] : 0.f, t & 0x80000000u ? acc[i][1] : 0.f,
                                              t & 0x4000u ? acc[i][2] : 0.f, t & 0x40000000u ? acc[i][3] : 0.f);
-                *reinterpret_cast<u32x2_t*>(dht + tile_off(16 * nb + (lane & 15), 48 * w + 16 * i + 4 * (lane >> 4), kH)) =
+                *reinterpret_cast<u32x2_t*>(dht + tile_off(16 * nb + (lo & 15), 48 * w + 16 * i + 4 * (lo >> 4), kH)) =
                     pack4_bf16(v);
             }
         });
@@ -434,8 +448,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_bf16_kernel(const bf16_t* _
         // ---- dx = dz + dh W1
 #pragma unroll 1
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4 a4 = gemm_down_block16(dht, nb, wfb, lane);
-            *reinterpret_cast<float4*>(xch + xch_off(16 * nb + (lane & 15), 16 * w + 4 * (lane >> 4), kC)) =
+            const f32x4 a4 = gemm_down_block16(dht, nb, wfb, lo);
+            *reinterpret_cast<float4*>(xch + xch_off(16 * nb + (lo & 15), 16 * w + 4 * (lo >> 4), kC)) =
                 make_float4(a4[0], a4[1], a4[2], a4[3]);
         }
         __syncthreads();

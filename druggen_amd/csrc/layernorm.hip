@@ -13,11 +13,23 @@
 namespace dg {
 namespace {
 
-// sum over the G lanes of a row group (G is a power of two <= 64)
+// sum over the G lanes of a row group (G is a power of two, 8 <= G <= 64), result in every lane: DPP inside the 16-lane rows
+// (quad_perm x 2, row_half_mirror, row_mirror), v_permlane16_swap / v_permlane32_swap across them -- no LDS round trip (a
+// __shfl_xor butterfly was 3 - 6 dependent ds_bpermute per sum, four sums per row in the second-order kernel)
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp_add(float x) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true);
+    return x + __int_as_float(moved);
+}
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, 64);
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "row group");
+    x = ln_dpp_add<0xB1>(x);       // quad_perm [1,0,3,2]
+    x = ln_dpp_add<0x4E>(x);       // quad_perm [2,3,0,1]
+    x = ln_dpp_add<0x141>(x);      // row_half_mirror: 8-lane totals
+    if (G >= 16) x = ln_dpp_add<0x140>(x);      // row_mirror: 16-lane totals
+    if (G >= 32) x = xor_step<false>(x, 16);
+    if (G >= 64) x = xor_step<false>(x, 32);
     return x;
 }
 
