@@ -18,6 +18,10 @@
 //                and four DPP steps per reduction.  k_j, v_j and q_i of the lane's rows / channels come from L2.
 //   three barriers per row group: e projection + scores | score tile -> planes | out_e ; everything else overlaps.
 // Arithmetic of both contractions as in row_gemm.hip (fp16 hi + lo, three products, fp32 accumulation, inverse scales).
+// 48 < N <= 96 (BASELINE configs[4], N = 90): a row group takes TWO stages, j in [0, 48) and [48, N) -- the e projection, the
+// scores, out_e and the LayerNorm are per edge row, only o_i couples the halves: an online softmax carries (max, sum, sum p v)
+// of the first half through a 1.5 KB LDS stash and the second half finishes o_i.  k_j / v_j are fetched per stage there
+// (two register sets do not fit next to the two weights' fragments).
 #include "common.h"
 #include "traversal.h"
 
@@ -42,7 +46,8 @@ constexpr int kOffPy = 0, kOffPs = kPlanes;
 constexpr int kOffTe = 2 * kPlanes, kOffTs = kOffTe + kTile, kOffTo = kOffTs + kTile;
 constexpr int kOffTab = kOffTo + kTile;                   // inv column scales + bias of both weights, gamma, beta: 6 x [128]
 constexpr int kOffO = kOffTab + 6 * 512;                  // o_i [128]
-constexpr int kLds = kOffO + 512;
+constexpr int kOffRun = kOffO + 512;                      // two-stage row groups: max, sum, sum p v of the first half [3][128]
+constexpr int kLds = kOffRun + 3 * 512;
 constexpr int kCons = 8, kProd = 4;
 constexpr float kNegBig = -3.0e38f;
 
@@ -113,6 +118,7 @@ struct HalfArgs {
     int cs, spl;          // row groups per chunk, chunks per molecule (a workgroup keeps k, v of a chunk's molecule)
 };
 
+template <int H>      // stages per row group: 1 (N <= 48) or 2 (48 < N <= 96)
 __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel(const HalfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + kOffTab);
@@ -125,17 +131,19 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
     // last chunk of a molecule may be short) and past the last chunk run empty.
     const int64_t total = static_cast<int64_t>(a.B) * a.spl;      // chunks
     const int bidx = blockIdx.x, nblk = gridDim.x;
-    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk) * a.cs;      // >= cs
+    const int T = static_cast<int>((total - bidx + nblk - 1) / nblk) * a.cs * H;      // stages (>= cs H)
     const int TP = (T + 2) / 3 * 3;
     struct Where {
         int64_t g;      // row group b N + i (clamped to a valid one)
         int b;
-        bool live, first;
+        bool live, first;      // first: the stage opens a chunk
+        int j0;         // first neighbour of the stage (0, or 48 in the second stage of a row group)
+        bool last;      // the stage completes its row group
     };
     // stage cursor: steps through the workgroup's stages with adds and compares only (one 32-bit division per chunk: three
     // 64-bit divisions per stage cost the consumer waves ~300 scalar instructions of the ~1 100 they issued per stage)
     struct Cursor {
-        int t, ii, j, b, i0;
+        int t, ii, jh, j, b, i0;
         int T, cs, spl, bidx, nblk, N, reverse, total;
         __device__ __forceinline__ void chunk() {
             int cid = bidx + j * nblk;
@@ -145,11 +153,15 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             i0 = (cid - b * spl) * cs;
         }
         __device__ __forceinline__ void start() {
-            t = ii = j = 0;
+            t = ii = jh = j = 0;
             chunk();
         }
         __device__ __forceinline__ void advance() {
             ++t;
+            if (H == 2) {
+                jh ^= 1;
+                if (jh) return;
+            }
             if (++ii == cs) {
                 ii = 0;
                 ++j;
@@ -160,10 +172,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             int i = i0 + ii;
             const bool live = t < T && i < N;
             if (i > N - 1) i = N - 1;
-            return Where{static_cast<int64_t>(b) * N + i, b, live, ii == 0};
+            return Where{static_cast<int64_t>(b) * N + i, b, live, ii == 0 && jh == 0, H == 2 ? kNP * jh : 0, H == 1 || jh == 1};
         }
     };
-    Cursor cur{0, 0, 0, 0, 0, T, a.cs, a.spl, bidx, nblk, N, a.reverse, static_cast<int>(total)};
+    Cursor cur{0, 0, 0, 0, 0, 0, T, a.cs, a.spl, bidx, nblk, N, a.reverse, static_cast<int>(total)};
     cur.start();
 
     if (w >= kCons) {
@@ -185,11 +197,12 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         }
         // rows hw + 8 i (i < 6) of the stage, float4 column l32 (channels / k = 4 l32 .. + 3)
         const unsigned voff = static_cast<unsigned>(hw) * 512u + static_cast<unsigned>(l32) * 16u;
-        const int rowbytes = N * 512;
+        // rows of a stage that exist: N (one stage per row group), or 48 / N - 48 (two)
+        auto stage_rows = [&](const Where& wh) { return H == 1 ? N : (wh.j0 ? N - kNP : kNP); };
         float4 ys[3][6];
         auto fetch = [&](float4 (&set)[6], const Where& wh) {
-            const int64_t g = wh.g;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + g * N * 128, 0, rowbytes,
+            const int64_t g = wh.g * N + wh.j0;      // first edge row of the stage
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + g * 128, 0, stage_rows(wh) * 512,
                                                                                   0x00020000);      // rows >= N read as zeros
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -270,11 +283,11 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         auto scores_store = [&](const Where& wh) {
             if (AH_DBG & 4) return;
             const bool ok = wh.live;
-            const int64_t g = wh.g;
-            const int bytes = ok ? rowbytes : 0;      // 0: every store is dropped
-            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.s ? a.s + g * N * 128 : a.y2, 0, a.s ? bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(a.e ? a.e + g * N * 128 : a.y2, 0, a.e ? bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(a.o + g * 128, 0, ok ? 512 : 0, 0x00020000);
+            const int64_t g = wh.g * N + wh.j0;
+            const int bytes = ok ? stage_rows(wh) * 512 : 0;      // 0: every store is dropped
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.s ? a.s + g * 128 : a.y2, 0, a.s ? bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(a.e ? a.e + g * 128 : a.y2, 0, a.e ? bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(a.o + wh.g * 128, 0, ok && wh.last ? 512 : 0, 0x00020000);
             unsigned trow = trow0;
             asm volatile("" : "+v"(trow));
 #pragma unroll
@@ -290,12 +303,13 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         auto finish = [&](const float4 (&res)[6], const Where& wh) {
             if (AH_DBG & 8) return;
             const bool ok = wh.live;
-            const int64_t g = wh.g;
-            const int bytes = ok ? rowbytes : 0;
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y2 + g * N * 128, 0, bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.pre ? a.pre + g * N * 128 : a.y2, 0, a.pre ? bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.mean + g * N, 0, ok ? N * 4 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.rstd + g * N, 0, ok ? N * 4 : 0, 0x00020000);
+            const int64_t g = wh.g * N + wh.j0;
+            const int nrows = stage_rows(wh);
+            const int bytes = ok ? nrows * 512 : 0;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y2 + g * 128, 0, bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.pre ? a.pre + g * 128 : a.y2, 0, a.pre ? bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.mean + g, 0, ok ? nrows * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.rstd + g, 0, ok ? nrows * 4 : 0, 0x00020000);
             const float4 gam = ld4(tab + 512 + 4 * l32), bet = ld4(tab + 640 + 4 * l32);
             unsigned trow = trow0;
             asm volatile("" : "+v"(trow));
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
         };
         // stages t - 1 (finish), t (stores), t + 1, t + 2 (fetch) of the iteration
         Where wq[4];
-        wq[0] = Where{0, 0, false, false};
+        wq[0] = Where{0, 0, false, false, 0, true};
         wq[1] = cur.here();
         cur.advance();
         wq[2] = cur.here();
@@ -427,10 +441,10 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
     auto request_qkv = [&](const Where& wh) {
         if (AH_DBG & 16) return;
         qa = ld4(a.q + wh.g * 128 + c0);
-        if (wh.first) {
+        if (wh.first || H == 2) {      // (two stages per row group: the halves' k_j / v_j alternate, from L2)
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
-                const int j = 16 * rb + n;
+                const int j = wh.j0 + 16 * rb + n;
                 const int64_t jr = (wh.b * N + (j < N ? j : 0)) * 128 + c0;
                 kk[rb] = ld4(a.k + jr);
                 vv[rb] = ld4(a.v + jr);
@@ -441,6 +455,8 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
     request_qkv(wc);
     for (int t = 0; t < TP; ++t) {
         const bool live = wc.live;
+        const int j0 = wc.j0;
+        const bool last = wc.last;
         cur.advance();
         wc = cur.here();
         if (live) {
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
                 const float rs = *reinterpret_cast<const float*>(smem + kOffPy + 2 * kPlane + row * 4);
                 const float4 ev = make_float4(fmaf(acc[rb][0], rs * cse.x, bev.x), fmaf(acc[rb][1], rs * cse.y, bev.y),
                                               fmaf(acc[rb][2], rs * cse.z, bev.z), fmaf(acc[rb][3], rs * cse.w, bev.w));
-                const bool valid = row < N;
+                const bool valid = j0 + row < N;
                 sc[rb] = valid ? (a.alpha * qa) * kk[rb] * fma4(ev, ev, ev) : f4(0.f);
                 if (valid) m = max4(m, sc[rb]);
                 const unsigned lo = static_cast<unsigned>(row * 512 + (((4 * w + kq) ^ (row & 7)) * 16));
@@ -466,13 +482,29 @@ __global__ __launch_bounds__(64 * (kCons + kProd)) void attn_half_f32_fwd_kernel
             float4 l = f4(0.f), av = f4(0.f);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
-                const float4 pe = (16 * rb + n < N) ? exp4(sc[rb] - m) : f4(0.f);
+                const float4 pe = (j0 + 16 * rb + n < N) ? exp4(sc[rb] - m) : f4(0.f);
                 l += pe;
                 av = fma4(pe, vv[rb], av);
             }
             l = make_float4(row16_sum(l.x), row16_sum(l.y), row16_sum(l.z), row16_sum(l.w));
             av = make_float4(row16_sum(av.x), row16_sum(av.y), row16_sum(av.z), row16_sum(av.w));
-            if (n == 0)      // (v_rcp_f32: 1 ulp; an IEEE division is a 10-instruction sequence per component)
+            if (H == 2) {      // online softmax over the two halves of the row group (the stash is this wave's own: no barrier)
+                float4* run = reinterpret_cast<float4*>(smem + kOffRun) + (c0 >> 2);
+                if (!last) {
+                    if (n == 0) {
+                        run[0] = m;
+                        run[32] = l;
+                        run[64] = av;
+                    }
+                } else {
+                    const float4 m0 = run[0], l0 = run[32], av0 = run[64];
+                    const float4 mm = max4(m, m0);
+                    const float4 f0 = exp4(m0 - mm), f1 = exp4(m - mm);
+                    l = fma4(l0, f0, l * f1);
+                    av = fma4(av0, f0, av * f1);
+                }
+            }
+            if (n == 0 && last)      // (v_rcp_f32: 1 ulp; an IEEE division is a 10-instruction sequence per component)
                 *reinterpret_cast<float4*>(smem + kOffO + c0 * 4) =
                     make_float4(av.x * __builtin_amdgcn_rcpf(l.x), av.y * __builtin_amdgcn_rcpf(l.y), av.z * __builtin_amdgcn_rcpf(l.z),
                                 av.w * __builtin_amdgcn_rcpf(l.w));
@@ -509,8 +541,8 @@ extern "C" int dg_attn_half_f32_fwd(const float* y, const float* q, const float*
                                     float* rstd, int B, int N, int C, float alpha, float eps, dg_stream_t stream_) {
     if (!y || !q || !k || !v || !we_packed || !woe_packed || !gamma || !beta || !o || !y2 || !mean || !rstd)
         return fail(DG_E_ARG, "dg_attn_half_f32_fwd: null pointer");
-    if (B < 0 || C != 128 || N < 1 || N > kNP)
-        return fail(DG_E_SHAPE, "dg_attn_half_f32_fwd: unsupported shape B=%d N=%d C=%d (C = 128, N <= 48)", B, N, C);
+    if (B < 0 || C != 128 || N < 1 || N > 2 * kNP)
+        return fail(DG_E_SHAPE, "dg_attn_half_f32_fwd: unsupported shape B=%d N=%d C=%d (C = 128, N <= 96)", B, N, C);
     if (B == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     // chunks of row groups: enough of them to fill the chip, as long as possible (k, v are fetched once per chunk)
@@ -523,7 +555,12 @@ extern "C" int dg_attn_half_f32_fwd(const float* y, const float* q, const float*
                e, s, o, y2, pre_ln, mean, rstd, B, N, alpha, eps, take_direction(rows), cs, spl};
     const int blocks = static_cast<int>(chunks < 256 ? chunks : 256);
     ProfScope prof(DG_K_ATTN_HALF_FWD, stream);
-    DG_OPT_IN_LDS((&attn_half_f32_fwd_kernel), kLds);
-    hipLaunchKernelGGL(attn_half_f32_fwd_kernel, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+    if (N <= kNP) {
+        DG_OPT_IN_LDS((&attn_half_f32_fwd_kernel<1>), kLds);
+        hipLaunchKernelGGL(attn_half_f32_fwd_kernel<1>, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+    } else {
+        DG_OPT_IN_LDS((&attn_half_f32_fwd_kernel<2>), kLds);
+        hipLaunchKernelGGL(attn_half_f32_fwd_kernel<2>, dim3(blocks), dim3(64 * (kCons + kProd)), kLds, stream, a);
+    }
     return check_launch("dg_attn_half_f32_fwd");
 }

@@ -2008,9 +2008,11 @@ def _composite_attn_block(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, 
 
 def attn_half_f32_supported(yf, N: int, C: int) -> bool:
     """dg_attn_half_f32_fwd (e projection + attention core + out_e + residual + ln4 as one float32 launch) serves C = 128 and
-    row groups of at most 48 neighbours; DG_ATTN_HALF_F32=off keeps the three launches (A/B measurements)."""
-    return (yf.is_cuda and yf.dtype == torch.float32 and C == 128 and N <= 48 and _h3_row_gemm()
-            and os.environ.get("DG_ATTN_HALF_F32", "fused") != "off")
+    row groups of at most 96 neighbours (above 48: two stages per row group, online softmax across them);
+    DG_ATTN_HALF_F32=off keeps the three launches, =n48 keeps them above 48 neighbours (A/B measurements)."""
+    mode = os.environ.get("DG_ATTN_HALF_F32", "fused")
+    return (yf.is_cuda and yf.dtype == torch.float32 and C == 128 and N <= (48 if mode == "n48" else 96) and _h3_row_gemm()
+            and mode != "off")
 
 
 def attn_half_f32_bwd1_supported(dy2f, B: int, N: int, C: int, graph: bool = False) -> bool:

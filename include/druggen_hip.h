@@ -141,7 +141,8 @@ int dg_attn_half_fwd(const void* y, const void* q, const void* k, const void* v,
  *   e = y We^T + be;  sc = alpha q_i k_j (e + 1) e;  o_i = sum_j softmax_j(sc) v_j;  y2 = LN(y + sc Woe^T + boe),
  * with everything the float32 backward reads written on the way: e, sc (`s`), the pre-LayerNorm sum (`pre_ln`), mean / rstd
  * -- e, s and pre_ln may be NULL when no backward will follow (their stores are then skipped).  we_packed / woe_packed:
- * dg_row_gemm_pack(e.weight / out_e.weight, 128, 128, mode 0) (fp16 hi + lo arithmetic of dg_row_gemm); C == 128, N <= 48
+ * dg_row_gemm_pack(e.weight / out_e.weight, 128, 128, mode 0) (fp16 hi + lo arithmetic of dg_row_gemm); C == 128, N <= 96
+ * -- above 48 neighbours a row group takes two passes of the 48-row stage, an online softmax joins them --
  * (others DG_E_SHAPE: the caller takes dg_row_gemm + dg_attn_core_fwd + dg_row_gemm).  HBM traffic: read y once, write e,
  * s, y2, pre_ln -- 5 x 4 R C bytes against 8 for the three launches.  Results are those of the unfused launches up to the
  * rounding of a different accumulation order.                                                                            */

@@ -331,12 +331,13 @@ def test_alternating_traversal_is_invisible_in_the_results(R):
         assert torch.equal(s_, outs[0][0]) and torch.equal(o, outs[0][1])
 
 
-@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45)])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45), (2, 49), (3, 90), (2, 96), (9, 64)])
 def test_fused_float32_attention_half_forward(B, N):
     """dg_attn_half_f32_fwd -- e = y We^T + be, sc = alpha q_i k_j (e + 1) e, o_i = sum_j softmax_j(sc) v_j,
     y2 = LN(y + sc Woe^T + boe) (reference layers.py:114-135, 186-188) as ONE launch -- against the fp64 closed form and
     against the three launches it replaces; with and without the outputs only a backward reads; repeated launches
-    (ascending / descending traversal) bit-identical."""
+    (ascending / descending traversal) bit-identical.  N > 48 (BASELINE configs[4]: N = 90): two stages per row group with an
+    online softmax across them."""
     from druggen_amd import functional as dgf
     lib = _lib().load()
     C, alpha, eps = 128, 0.25, 1e-5
@@ -388,7 +389,7 @@ def test_fused_float32_attention_half_forward(B, N):
                 assert torch.equal(a_, b_)
     assert lib.dg_attn_half_f32_fwd(y.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), pe.data_ptr(), be.data_ptr(),
                                     po.data_ptr(), boe.data_ptr(), g4.data_ptr(), b4.data_ptr(), None, None, o.data_ptr(),
-                                    y2.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), B, 49, C, alpha, eps, st) != 0
+                                    y2.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), B, 97, C, alpha, eps, st) != 0
 
 
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45), (300, 9)])
