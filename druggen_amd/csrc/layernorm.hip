@@ -178,10 +178,19 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const T* __restrict__ a,
             s2 += hsum(u[t] * xh[t]);
         }
         const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
-        float4 out[QPL];
-        if (dz_add) ld_slots<PAIR>(dz_add + m.row * C, coff, out);   // second gradient source of the pre-LN sum
+        float4 out[QPL], extra[QPL];
+        if (dz_add) ld_slots<PAIR>(dz_add + m.row * C, coff, extra);   // second gradient source of the pre-LN sum
 #pragma unroll
-        for (int t = 0; t < QPL; ++t) out[t] = rs * (u[t] - f4(c1) - c2 * xh[t]) + (dz_add ? out[t] : f4(0.f));
+        for (int t = 0; t < QPL; ++t) {
+            out[t] = rs * (u[t] - f4(c1) - c2 * xh[t]);
+            if (dz_add) {
+                // rounded product, THEN the add: the sum must carry the bits of "this kernel without dz_add, then one elementwise
+                // add" (what the autograd engine does with two gradient sources; tests/test_hip_step.py holds the two paths to
+                // bit equality) -- fused into an fma by the compiler it differed in the last place
+                asm volatile("" : "+v"(out[t].x), "+v"(out[t].y), "+v"(out[t].z), "+v"(out[t].w));
+                out[t] += extra[t];
+            }
+        }
         if (m.ok) st_slots<PAIR>(dz + m.row * C, coff, cok, out);
     }
     // block partial: sum over the RPB row groups in a fixed order
