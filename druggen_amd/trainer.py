@@ -138,6 +138,7 @@ class GANStep:
         # bench.py --gpus N: HIP events around the two gradient all-reduces of every step ((start, stop) pairs on the
         # launch stream; None = off)
         self.collective_events = None
+        self._reduce_hook = None      # set by GraphedGANStep while it captures a data-parallel step in segments
 
     def time_collectives(self, on: bool = True) -> None:
         """Start (or stop) recording a pair of HIP events around every gradient all-reduce."""
@@ -185,6 +186,22 @@ class GANStep:
         gp.backward()
         return (loss_fake.detach() + loss_real.detach() + gp.detach())
 
+    def _reduce_flat(self, flat: torch.Tensor, ws: int) -> None:
+        """Average the flat gradient bucket across ranks: ONE all-reduce (timed by a pair of HIP events when asked)."""
+        timed = self.collective_events is not None and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(ws)
+        if timed:
+            e1.record()
+            if len(self.collective_events) < 4096:      # bounded: timing left on for a long run keeps the first 4096
+                self.collective_events.append((e0, e1))
+
     def _update(self, opt, bucket: GradBucket) -> None:
         """Average gradients across ranks (one all-reduce) and apply AdamW."""
         if isinstance(opt, FlatAdamW):
@@ -192,20 +209,10 @@ class GANStep:
             if flat is None:
                 return
             ws = bucket.world_size()
-            if ws > 1:
-                timed = self.collective_events is not None and flat.is_cuda
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                if dist.get_backend(self.group) == "nccl":
-                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-                else:
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                    flat.div_(ws)
-                if timed:
-                    e1.record()
-                    if len(self.collective_events) < 4096:      # bounded: timing left on for a long run keeps the first 4096
-                        self.collective_events.append((e0, e1))
+            if self._reduce_hook is not None:      # GraphedGANStep's segmented capture: the collective stays outside the graphs
+                self._reduce_hook(flat, ws)
+            elif ws > 1:
+                self._reduce_flat(flat, ws)
             opt.step(packed=True)
         else:
             bucket.all_reduce_mean()
@@ -284,16 +291,31 @@ class GraphedGANStep:
     replayed.  For small molecules / batches the eager step is launch-bound (BASELINE configs[0]
     shape: 13.7 ms eager -> 3.3 ms replayed on MI355X); at configs[1] the GPU is already saturated.
 
-    Single-GPU only (the all-reduce is not captured).  New batches are copied into the static input
+    One process: ONE graph.  Under data parallelism (one process per GPU, world size > 1) a collective cannot sit in the
+    graph, so the iteration is captured as THREE graphs that share one memory pool, cut at the two gradient all-reduces
+    (the minimum the alternating updates allow) --
+        [G forward, D loss, its backward, flat D gradient bucket] all-reduce [AdamW(D), G loss, its backward, flat G bucket]
+        all-reduce [AdamW(G)]
+    -- and a replay runs graph, eager all-reduce, graph, eager all-reduce, graph: two collectives and three launches from
+    the host per step instead of ~750 (a rank whose Python is slow no longer delays the collective of all).  The autograd
+    graph of the shared generator forward is built during the first capture and consumed during the second: legal because
+    the captures share the pool and replay in capture order.  New batches are copied into the static input
     buffers; ``eps`` is drawn on the device inside the graph like the reference does.
 
     One-hot edge batches (dataset graphs) are embedded through their int32 LABELS (table gather): the
     captured kernels read static label buffers owned by this object, and ``step`` refreshes them together
     with the dense buffers -- a replay never sees the labels of an older batch."""
 
-    def __init__(self, stepper: GANStep, disc_edge, disc_node, gen_edge, gen_node, warmup: int = 3):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(stepper.group) > 1:
-            raise RuntimeError("GraphedGANStep is single-GPU: use GANStep under torchrun for data parallelism")
+    def __init__(self, stepper: GANStep, disc_edge, disc_node, gen_edge, gen_node, warmup: int = 3, eps=None, segmented=None):
+        # eps: (eps_edge [B,1,1,1], eps_node [B,1,1]) of the gradient penalty's interpolation as STATIC inputs (``step(eps=...)``
+        # refreshes them) instead of the uniform draw inside the graph -- reproducible runs, tests
+        # segmented: None = three graphs exactly when the process group has more than one rank; True forces them (a one-rank
+        # group then still issues its two all-reduces between the graphs: tests of the RCCL call sequence on one GPU)
+        self.static_eps = None if eps is None else tuple(t.clone() for t in eps)
+        self.world = (dist.get_world_size(stepper.group) if dist.is_available() and dist.is_initialized() else 1)
+        if self.world > 1 and not isinstance(stepper.d_optimizer, FlatAdamW):
+            raise RuntimeError("GraphedGANStep under data parallelism needs the flat optimizer (its gradient buffer is the "
+                               "all-reduce bucket the graphs are cut around)")
         self.stepper = stepper
         self.static = [t.clone() for t in (disc_edge, disc_node, gen_edge, gen_node)]
         # static label buffers of the two edge batches (index 0: D's real batch, 2: the generator input): validated
@@ -309,7 +331,7 @@ class GraphedGANStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up off the default stream: allocator pools, packed
             for _ in range(warmup):            # weights, flat optimizer state, hipFuncSetAttribute calls
-                stepper.step(*self.static)
+                stepper.step(*self.static, eps=self.static_eps)
         torch.cuda.current_stream().wait_stream(side)
         # Packed GEMM weights are cached per (tensor, version, epoch).  Without this bump the capture
         # below would hit the warm-up's packs for every weight that is not updated before its first
@@ -318,11 +340,45 @@ class GraphedGANStep:
         # so a replay re-packs from the live parameters exactly like an eager step.
         bump_weights_epoch()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.losses = stepper.step(*self.static)
+        self.segments = None
+        if self.world == 1 and not segmented:
+            with torch.cuda.graph(self.graph):
+                self.losses = stepper.step(*self.static, eps=self.static_eps)
+        else:
+            self._capture_segments()
         bump_weights_epoch()    # cache entries made during capture point into the graph's private pool
 
-    def step(self, disc_edge=None, disc_node=None, gen_edge=None, gen_node=None, check_one_hot: bool = True):
+    def _capture_segments(self):
+        """Capture one step as consecutive graphs, a new one starting wherever GANStep._update would all-reduce.  Nothing
+        runs during a capture, so no collective is issued here: every rank captures on its own."""
+        graphs, flats = [self.graph], []
+        pool = torch.cuda.graph_pool_handle()
+        stepper = self.stepper
+
+        def cut(flat, ws):      # called by GANStep._update between pack_grads() and the optimizer step
+            graphs[-1].capture_end()
+            flats.append(flat)
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        stepper._reduce_hook = cut
+        try:
+            with torch.cuda.stream(side):
+                # thread_local: the process group's watchdog thread polls events while this thread captures
+                graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+                try:
+                    self.losses = stepper.step(*self.static, eps=self.static_eps)
+                finally:
+                    graphs[-1].capture_end()
+        finally:
+            stepper._reduce_hook = None
+        torch.cuda.current_stream().wait_stream(side)
+        self.segments = (graphs, flats)
+
+    def step(self, disc_edge=None, disc_node=None, gen_edge=None, gen_node=None, check_one_hot: bool = True, eps=None):
         """Replay on a new batch (``None`` keeps the previous tensor).  Edge batches captured as one-hot must be one-hot
         again: labels attached by ``data.load_molecules`` are trusted, other tensors are validated by ``as_one_hot``
         (one device->host read per new tensor object; ``check_one_hot=False`` skips it and trusts ``argmax``)."""
@@ -341,12 +397,27 @@ class GraphedGANStep:
                                            "the new batch is not one-hot: capture a new graph for dense inputs")
                     lab = src.argmax(-1)
             todo.append((idx, dst, src, lab))
+        if eps is not None:
+            if self.static_eps is None:
+                raise RuntimeError("GraphedGANStep was captured with eps drawn inside the graph: pass eps=(...) to its constructor "
+                                   "to replay on given interpolation weights")
+            for dst, src in zip(self.static_eps, eps):
+                dst.copy_(src)
         for idx, dst, src, lab in todo:
             dst.copy_(src)
             if lab is not None:
                 self._labels[idx].copy_(lab)      # in place: the captured kernels read this buffer
                 attach_one_hot_labels(dst, self._labels[idx])
-        self.graph.replay()
+        if self.segments is None:
+            self.graph.replay()
+        else:
+            graphs, flats = self.segments
+            reduce = dist.is_available() and dist.is_initialized()
+            for g, flat in zip(graphs, flats):
+                g.replay()
+                if reduce:
+                    self.stepper._reduce_flat(flat, self.world)      # eager: D's bucket after the first graph, G's after the second
+            graphs[-1].replay()
         # the replay updated G and D in place without bumping tensor versions: an eager forward after
         # it must not reuse packs keyed on the old versions
         bump_weights_epoch()

@@ -133,17 +133,29 @@ per = case["batch"] // world
 sl = slice(rank * per, (rank + 1) * per)
 st = GANStep(G, D, g_lr=1e-3, d_lr=1e-3, lambda_gp=case["lambda_gp"])       # FlatAdamW: the flat bucket IS the all-reduce buffer
 grads = []
-for it in range(3):
-    if os.environ.get("DG_TEST_SLOW_RANK") == str(rank):      # uneven arrival at the all-reduces
-        import time
-        time.sleep(0.3 * (it + 1))
-    st.step(inp["disc_edge"][sl], inp["disc_node"][sl], inp["gen_edge"][sl], inp["gen_node"][sl],
-            eps=(inp["eps_edge"][sl], inp["eps_node"][sl]))
-    if it == 0:      # the rank-averaged gradient buckets of the first iteration (same weights in every run)
-        grads = [st.d_optimizer.flat_grad.detach().cpu().clone(), st.g_optimizer.flat_grad.detach().cpu().clone()]
+shard = (inp["disc_edge"][sl].contiguous(), inp["disc_node"][sl].contiguous(), inp["gen_edge"][sl].contiguous(),
+         inp["gen_node"][sl].contiguous())
+eps = (inp["eps_edge"][sl].contiguous(), inp["eps_node"][sl].contiguous())
+graphed = os.environ.get("DG_TEST_GRAPHED") == "1"
+tag = "g" if graphed else ""
+if graphed:      # the data-parallel step as three hipGraphs cut at the two all-reduces; its one warm-up step is iteration 0
+    from druggen_amd.trainer import GraphedGANStep
+    gst = GraphedGANStep(st, *shard, warmup=1, eps=eps)
+    assert gst.segments is not None and len(gst.segments[0]) == 3 and len(gst.segments[1]) == 2
+    grads = [st.d_optimizer.flat_grad.detach().cpu().clone(), st.g_optimizer.flat_grad.detach().cpu().clone()]
+    for it in range(1, 3):
+        gst.step(*[t.clone() for t in shard], eps=eps)
+else:
+    for it in range(3):
+        if os.environ.get("DG_TEST_SLOW_RANK") == str(rank):      # uneven arrival at the all-reduces
+            import time
+            time.sleep(0.3 * (it + 1))
+        st.step(*shard, eps=eps)
+        if it == 0:      # the rank-averaged gradient buckets of the first iteration (same weights in every run)
+            grads = [st.d_optimizer.flat_grad.detach().cpu().clone(), st.g_optimizer.flat_grad.detach().cpu().clone()]
 torch.cuda.synchronize()
 torch.save({"G": [p.detach().cpu() for p in G.parameters()], "D": [p.detach().cpu() for p in D.parameters()], "grads": grads},
-           os.path.join(out, f"w{world}_r{rank}.pt"))
+           os.path.join(out, f"w{world}{tag}_r{rank}.pt"))
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
@@ -197,6 +209,28 @@ def test_two_process_hip_data_parallel_step_equals_single_process(tmp_path):
     assert len(untouched) == 10 and all(".attn.out_e." in k or ".ln4." in k or ".mlp2." in k or ".ln6." in k for k in untouched)
 
 
+def test_two_ranks_replaying_the_step_as_three_graphs_follow_the_eager_ranks(tmp_path):
+    """Data parallelism without ~750 launches per step from every rank's Python: `GraphedGANStep` under a
+    process group captures the iteration as THREE hipGraphs cut at the two gradient all-reduces -- the shared generator
+    forward's autograd graph is built in the first capture and consumed in the second -- and replays graph, all-reduce,
+    graph, all-reduce, graph.  Two ranks on cuda:0 (gloo): the ranks stay bit-identical, and after one eager + two replayed
+    iterations on fixed interpolation weights they hold the parameters of the eagerly stepping pair."""
+    out = str(tmp_path)
+    _launch(2, out, _free_port(), DG_TEST_GRAPHED="1")
+    _launch(2, out, _free_port())
+    g0, g1, e0 = (torch.load(os.path.join(out, f)) for f in ("w2g_r0.pt", "w2g_r1.pt", "w2_r0.pt"))
+    for a, b in zip(g0["G"] + g0["D"], g1["G"] + g1["D"]):
+        assert torch.equal(a, b), "ranks diverged"
+    for a, b in zip(g0["grads"], e0["grads"]):
+        assert torch.equal(a, b)
+    import cases
+    gp, dp = cases.build_params(cases.CASES["c1_b4"])
+    start = [torch.from_numpy(v) for v in list(gp.values()) + list(dp.values())]
+    moved = torch.sqrt(sum(((a - s) ** 2).sum() for a, s in zip(e0["G"] + e0["D"], start)))
+    diff = torch.sqrt(sum(((a - b) ** 2).sum() for a, b in zip(g0["G"] + g0["D"], e0["G"] + e0["D"])))
+    assert moved > 0 and diff <= 1e-6 * moved, (float(diff), float(moved))
+
+
 def test_four_ranks_with_a_late_rank_stay_bit_identical(tmp_path):
     """Four processes on cuda:0 (gloo), one molecule each, rank 2 arriving 0.3 - 0.9 s late at every iteration's all-reduces:
     the two flat-bucket collectives per step are the only synchronisation points, so a late rank may delay the others but
@@ -247,6 +281,64 @@ def test_rccl_calls_of_the_multi_gpu_path_run_on_this_build(tmp_path):
     assert p.returncode == 0 and b"rccl ok" in p.stdout, p.stdout.decode()[-2000:]
 
 
+_NCCL_GRAPH_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+import cases, harness
+from druggen_amd.model import Discriminator, Generator
+from druggen_amd.trainer import GANStep, GraphedGANStep
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+case = cases.CASES["c1_b4"]
+cfg = cases.net_config(case)
+gp, dp = cases.build_params(case)
+args = (cfg.act, cfg.vertexes, cfg.edges, cfg.nodes, cfg.dropout)
+kw = dict(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, mlp_ratio=cfg.mlp_ratio)
+inp = harness.torch_inputs(case, torch.float32, "cuda")
+batch = (inp["disc_edge"], inp["disc_node"], inp["gen_edge"], inp["gen_node"])
+eps = (inp["eps_edge"], inp["eps_node"])
+ends = []
+for graphed in (False, True):
+    G, D = Generator(*args, **kw), Discriminator(*args, **kw)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in gp.items()})
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+    G, D = G.cuda(), D.cuda()
+    st = GANStep(G, D, g_lr=1e-3, d_lr=1e-3, lambda_gp=case["lambda_gp"])
+    if graphed:
+        gst = GraphedGANStep(st, *batch, warmup=1, eps=eps, segmented=True)
+        assert len(gst.segments[0]) == 3
+        st.time_collectives(True)
+        for _ in range(3):
+            gst.step(*[t.clone() for t in batch], eps=eps)
+        n, ms = st.collective_ms()
+        assert n == 6, n          # two RCCL all-reduces per replayed step, between the graphs
+    else:
+        for _ in range(4):
+            st.step(*batch, eps=eps)
+    torch.cuda.synchronize()
+    ends.append(torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).cpu())
+start = torch.cat([torch.from_numpy(v).reshape(-1) for v in list(gp.values()) + list(dp.values())])
+moved, diff = float((ends[0] - start).norm()), float((ends[0] - ends[1]).norm())
+assert moved > 0 and diff <= 1e-6 * moved, (diff, moved)
+dist.destroy_process_group()
+print("rccl graphs ok")
+"""
+
+
+def test_three_graph_step_with_rccl_all_reduces_between_the_graphs(tmp_path):
+    """The N > 1 replay sequence -- graph, RCCL all-reduce, graph, RCCL all-reduce, graph -- on this build's RCCL with a
+    one-rank `nccl` group (the capture runs while the process group's watchdog thread is alive; the collectives are real
+    ncclAllReduce calls on the flat buckets): three replayed steps end on the parameters of four eager steps."""
+    script = os.path.join(str(tmp_path), "nccl_graph_worker.py")
+    with open(script, "w") as f:
+        f.write(f"ROOT = {ROOT!r}\n" + _NCCL_GRAPH_WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"rccl graphs ok" in p.stdout, p.stdout.decode()[-3000:]
+
+
 def test_two_gpu_rccl_bench_keeps_replicas_identical(tmp_path):
     """On a box with >= 2 GPUs (the driver's 8-GPU scaling node; skipped on the 1-GPU test boxes): bench.py under
     torch.distributed.run with the `nccl` backend, one rank per GPU, two timed steps; every rank must end on the same
@@ -267,21 +359,22 @@ def test_two_gpu_rccl_bench_keeps_replicas_identical(tmp_path):
     assert out["config"]["global_batch"] == 128
 
 
-def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(tmp_path):
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(tmp_path, graph):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
     cuda:0 and the `gloo` backend (DG_DIST_BACKEND: the functional twin of the RCCL run, which needs two GPUs): the line
     must carry n_gpus = 2, the per-rank time of the two gradient all-reduces per step and replicas_identical = true
-    without any extra flag."""
+    without any extra flag.  `--graph`: every rank replays its step as three hipGraphs cut at the two all-reduces."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DG_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-extra", "--batch", "8", "--vertexes", "9", "--depth", "1"]
+           "--no-cpu-baseline", "--no-extra", "--batch", "8", "--vertexes", "9", "--depth", "1"] + (["--graph"] if graph else [])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
-    assert out["replicas_identical"] is True
+    assert out["replicas_identical"] is True and out["config"]["hip_graph_replay"] is graph
     ar = out["allreduce"]
     assert len(ar["per_rank_ms_per_step"]) == 2 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
 
