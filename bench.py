@@ -282,6 +282,10 @@ def main():
     sync()
     detail_elapsed = time.perf_counter() - t1
     _lib.prof_enable(False)
+    # (functional._account keeps counting bytes whenever a step is traced in Python: read the two instrumented steps' totals
+    # before the graph region below warms up and captures)
+    detail_traffic = {name: (dgf.traffic_bytes(name), dgf.traffic_floor_bytes(name), dgf.traffic_flops(name))
+                      for name in _lib.KERNEL_IDS}
     # ---- the headline's timed region: the same K steps replayed from a captured hipGraph (trainer.GraphedGANStep).  A step is
     # ~750 launches issued from Python: 30-40 ms of host work against ~52 ms of GPU work at configs[1] -- on a box with a slower
     # or busier CPU the eager loop measured the host (54.6 vs 52.3 ms replayed, the same box and process).  The eager region
@@ -353,8 +357,7 @@ def main():
         step_bytes = step_floor = 0.0
         for name in _lib.KERNEL_IDS:
             n, ms = _lib.prof_read(name)
-            nbytes = dgf.traffic_bytes(name)
-            floor = dgf.traffic_floor_bytes(name)
+            nbytes, floor, _ = detail_traffic[name]
             step_bytes += float(nbytes)
             step_floor += float(floor)
             if n:
@@ -364,7 +367,7 @@ def main():
                                  "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                                  "frac_of_floor": (floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0,
                                  "share_of_step": ms * 1e-3 / detail_elapsed}
-                fl = dgf.traffic_flops(name)
+                fl = detail_traffic[name][2]
                 if fl:          # GEMM-shaped kernels: flop rate against the MFMA ceiling of their arithmetic
                     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                     peak, how = gemm_peak, gemm_how

@@ -19,7 +19,7 @@ $B --config c5 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O
 $B --config c5 --dtype bf16 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_bf16.json
 # ---- kernel traces
 for cfg in c2 c3; do
-  rocprofv3 --kernel-trace --stats -d $O/trace_$cfg -o t -- $B --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/trace_$cfg.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/trace_$cfg -o t -- $B --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-extra --eager > $O/trace_$cfg.log 2>&1
   python $R/scripts/rocprof_summary.py $(find $O/trace_$cfg -name "*.db" | head -1) 60 > $O/${cfg}_kernel_stats.txt
   # (the traced command runs 5 + 2 steps and bench.py's instrumented pre-pass of 3: 10 steps)
   [ $cfg = c2 ] && python $R/scripts/step_timeline.py $(find $O/trace_$cfg -name "*.db" | head -1) 10 > $O/small_launches_c2.txt
@@ -27,7 +27,7 @@ done
 # ---- HBM traffic (separate passes per counter)
 for cfg in c2 c3; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_${cfg}_$ctr -o p --output-format csv -- $B --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_${cfg}_$ctr.log 2>&1
+    rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_${cfg}_$ctr -o p --output-format csv -- $B --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extra --eager > $O/pmc_${cfg}_$ctr.log 2>&1
   done
 done
 cd $R
