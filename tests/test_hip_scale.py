@@ -400,6 +400,12 @@ def test_bench_line_is_one_short_parseable_record(tmp_path):
     assert 0 < rf["frac_of_floor"] <= rf["frac"] < 1.0
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
     assert "kernels" not in out and "roofline_all" not in out
+    # the headline configuration times the eager launches AND the hipGraph replay, K steps each; `value` is the faster mode
+    eager, graph = out["eager_same_step"], out["hip_graph_replay_same_step"]
+    assert eager["steps"] == graph["steps"] == 2 and eager["value"] > 0 and graph["value"] > 0
+    assert out["value"] == max(eager["value"], graph["value"])
+    assert out["config"]["hip_graph_replay"] is (graph["value"] > eager["value"])
+    assert all(v == v for v in graph["losses"])
 
 
 def test_dataparallel_replicas_on_one_device_run_the_gradient_penalty():
