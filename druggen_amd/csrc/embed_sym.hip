@@ -162,6 +162,16 @@ __device__ __forceinline__ f32x16 mfma6(const Planes& a, const Planes& b, f32x16
     for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[t]], b.p[TB[t]], c, 0, 0, 0);
     return c;
 }
+// The gradient stages (dW2 += dpre2^T h1, dh = dpre2 W2) are backward-only: their roundings travel through linear maps and stay
+// roundings, so they take the three leading cross products (m h', h m', h h': 2^-16 of a product left out) -- half
+// the MFMAs of a stage.  The layer-2 RECOMPUTATION keeps all six: its signs are the ReLU mask of the forward, which must not flip
+// (all three stages on three products: 1.4e-3 .. 4e-3 on the goldens, the square-root law of a perturbed forward).
+__device__ __forceinline__ f32x16 mfma_bwd(const Planes& a, const Planes& b, f32x16 c) {
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // smallest terms first
+#pragma unroll
+    for (int t = 0; t < 3; ++t) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[TA[t]], b.p[TB[t]], c, 0, 0, 0);
+    return c;
+}
 // eight consecutive k (chunks c, c + 1 of four floats) of row `row` of an XOR-swizzled fp32 tile with `pitch` floats
 __device__ __forceinline__ Planes frag_row(const float* tile, int row, int c, int pitch) {
     const float4 a = ld4(tile + row * pitch + ((c ^ (row & 15)) << 2));
@@ -278,8 +288,8 @@ __device__ __forceinline__ void aw2_stage(const float* d2, const float* hq, int 
             b1v[j] = hq[r * kHid + ((((32 + col) >> 2) ^ (r & 15)) << 2) + (col & 3)];
         }
         const Planes pa = split8(av);
-        aw2[0] = mfma6(pa, split8(b0), aw2[0]);
-        aw2[1] = mfma6(pa, split8(b1v), aw2[1]);
+        aw2[0] = mfma_bwd(pa, split8(b0), aw2[0]);
+        aw2[1] = mfma_bwd(pa, split8(b1v), aw2[1]);
     }
 }
 // dh1 = P W2 for one (32-row block, 32-unit tile): K = 128 channels = eight k-steps, two accumulator chains
@@ -289,8 +299,8 @@ __device__ __forceinline__ f32x16 dh_stage(const float* d2, const bf16x8* w2g, i
     for (int i = 0; i < 16; ++i) d0[i] = d1v[i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ks += 2) {
-        d0 = mfma6(frag_row(d2, row, 4 * ks + 2 * half, kC), load_planes(w2g + ks * 3 * 64), d0);
-        d1v = mfma6(frag_row(d2, row, 4 * (ks + 1) + 2 * half, kC), load_planes(w2g + (ks + 1) * 3 * 64), d1v);
+        d0 = mfma_bwd(frag_row(d2, row, 4 * ks + 2 * half, kC), load_planes(w2g + ks * 3 * 64), d0);
+        d1v = mfma_bwd(frag_row(d2, row, 4 * (ks + 1) + 2 * half, kC), load_planes(w2g + (ks + 1) * 3 * 64), d1v);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) d0[i] += d1v[i];
