@@ -289,7 +289,9 @@ def test_onehot_embedding_matches_the_dense_kernel(B, N, E, act, dtype):
     gd = torch.autograd.grad(dense, ps, up)
     gf = torch.autograd.grad(fast, ps, up)
     for x, y in zip(gf, gd):
-        assert float((x.double() - y.double()).norm() / y.double().norm()) < (2e-5 if dtype == torch.float32 else 6e-3)      # bf16: the dense backward is csrc/embed_bf16.hip (bf16 MFMA products)
+        # float32: the dense kernel's two gradient stages leave out the 2^-16-sized cross products (measured 3e-5 here);
+        # bf16: the dense backward is csrc/embed_bf16.hip (bf16 MFMA products)
+        assert float((x.double() - y.double()).norm() / y.double().norm()) < (1e-4 if dtype == torch.float32 else 6e-3)
     soft = torch.softmax(torch.randn(B, N, N, E, generator=g), -1).cuda()
     assert dgf.one_hot_labels(dgf.as_one_hot(soft)) is None
     # a batch buffer that is refilled in place must not keep its old labels: the cache is tied to the version counter
