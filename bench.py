@@ -293,16 +293,25 @@ def main():
     # handling the eager stream does not pay).  A user picks the mode that is faster on the machine at hand, so `value` is the
     # FASTER of the two regions -- each exactly K steps between synchronisations -- named in `timed_region`, both numbers in
     # the line.  The eager region carries the HIP events of the roofline blocks: events cannot be timed inside a replayed graph
-    # (hipEventElapsedTime: hipErrorInvalidHandle).  N > 1 runs eagerly (--graph: three graphs per step).
+    # (hipEventElapsedTime: hipErrorInvalidHandle).  N > 1: the same two regions, the replayed one as three graphs per step cut at
+    # the two gradient all-reduces (trainer.GraphedGANStep under a process group) -- the N = 1 and the N > 1 lines are measured
+    # the same way, and a rank whose host is slow does not hold up the collectives of all.
     graph_region = None
-    want_graph = (world == 1 and not args.graph and not args.eager and args.config == "c2" and act_dtype == "f32"
+    want_graph = (not args.graph and not args.eager and args.config == "c2" and act_dtype == "f32"
                   and not stepper._low_memory(gen_edge))
     if want_graph:
-        try:
+        graphed, err = None, None
+        try:      # (the capture issues no collective: a rank that fails here cannot leave the others waiting)
             graphed = GraphedGANStep(stepper, disc_edge, disc_node, gen_edge, gen_node, warmup=1)
             # other tensor objects than the captured ones: every step copies its batch (and the one-hot labels, validated once
             # per tensor object during the warm-up) into the graph's static buffers
             batch2 = [t.clone() for t in (disc_edge, disc_node, gen_edge, gen_node)]
+        except Exception as exc:      # a failed capture must not cost the line: the eager region is the value then
+            graphed, err = None, repr(exc)[:200]
+        ok = torch.tensor([0 if graphed is None else 1], device=dev, dtype=torch.int32)
+        if world > 1:      # every rank replays, or none does
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             for _ in range(max(1, args.warmup)):
                 glosses = graphed.step(*batch2)
             sync()
@@ -313,13 +322,18 @@ def main():
             tg = time.perf_counter() - tg
             if all(bool(torch.isfinite(v)) for v in glosses):
                 graph_region = {"elapsed": tg, "losses": [float(v.item()) for v in glosses]}
-            del graphed, batch2
-        except Exception as exc:      # a failed capture must not cost the line: the eager region is the value then
-            graph_region = {"error": repr(exc)[:200]}
+            else:
+                graph_region = {"error": "non-finite losses in the replayed region"}
+        else:
+            graph_region = {"error": err or "the capture failed on another rank"}
+        graphed = batch2 = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        both = [elapsed, graph_region["elapsed"] if graph_region and "elapsed" in graph_region else 0.0]
+        t = torch.tensor(both, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's time of each region
+        elapsed = float(t[0].item())
+        if graph_region and "elapsed" in graph_region:
+            graph_region["elapsed"] = float(t[1].item())
     replicas_identical = None
     allreduce = None
     if world > 1:
@@ -514,13 +528,14 @@ def main():
             # events around the roofline kernels), then K steps replayed from the captured hipGraph, every step copying its batch
             # into the graph's static buffers
             tg = graph_region["elapsed"]
-            out["timed_region"] = (("hipGraph replay of the whole step (trainer.GraphedGANStep), the batch copied into its static "
-                                    "buffers every step" if replayed else "eager launches") +
+            how = ("hipGraph replay of the whole step (trainer.GraphedGANStep)" if world == 1 else
+                   "three hipGraphs per step, cut at the two gradient all-reduces (trainer.GraphedGANStep under the process group)")
+            out["timed_region"] = ((how + ", the batch copied into the static buffers every step" if replayed else "eager launches") +
                                    ": the faster of the two launch modes on this box, K steps each (eager_same_step, "
                                    "hip_graph_replay_same_step); `roofline*`: the eager region (HIP events cannot be timed inside a "
                                    "replayed graph)")
             out["eager_same_step"] = eager_rec
-            out["hip_graph_replay_same_step"] = {"value": B * args.steps / tg, "unit": "molecules/s", "ms_per_step": 1e3 * tg / args.steps,
+            out["hip_graph_replay_same_step"] = {"value": B * world * args.steps / tg, "unit": "molecules/s", "ms_per_step": 1e3 * tg / args.steps,
                                                  "steps": args.steps, "losses": graph_region["losses"]}
         elif graph_region:
             out["timed_region"] = "eager launches (the hipGraph capture failed: see hip_graph_replay_same_step)"

@@ -374,7 +374,13 @@ def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
-    assert out["replicas_identical"] is True and out["config"]["hip_graph_replay"] is graph
+    assert out["replicas_identical"] is True
+    if graph:
+        assert out["config"]["hip_graph_replay"] is True and out["timed_region"].startswith("three hipGraphs")
+    else:      # the default line times the eager launches AND the three-graph replay, and takes the faster as `value`
+        eager, replay = out["eager_same_step"], out["hip_graph_replay_same_step"]
+        assert out["value"] == max(eager["value"], replay["value"]) and replay["value"] > 0
+        assert out["config"]["hip_graph_replay"] is (replay["value"] > eager["value"])
     ar = out["allreduce"]
     assert len(ar["per_rank_ms_per_step"]) == 2 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
 
