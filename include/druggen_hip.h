@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 230            /* 0.3.0: + DG_DTYPE_F32_H16 (fp16 hidden tensors of the float32 feed-forward), dg_set_edge_rows */
+#define DG_VERSION 231            /* 0.3.1: 0.3.0 (+ DG_DTYPE_F32_H16 .. _H32_DH16 hidden-tensor codes, dg_set_edge_rows) + dg_attn_half_f32_fwd for N <= 96 */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 /* float32 activations whose 384-wide feed-forward HIDDEN tensors (h = relu(fc1 x), dh, and their second-order twins:
