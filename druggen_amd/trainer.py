@@ -173,11 +173,33 @@ class GANStep:
         estimate = 9.0 * B * N * N * dim * es * depth
         return estimate > 0.85 * torch.cuda.get_device_properties(gen_edge.device).total_memory
 
-    def _d_step_low_memory(self, disc_edge, disc_node, gen_edge, gen_node, B, dev, eps):
+    def _low_memory_shares_generator(self, gen_edge) -> bool:
+        """Low-memory step: may the ONE generator forward (with its graph) still serve both steps?  The peak of the low-memory
+        step is two Discriminator block-pass sets (the penalty's graph and its double backward: 154 GB at B = 2048, N = 45,
+        L = 4 in fp32); keeping G's graph alive through the D step adds one of G's (76 GB there)."""
+        if not (self.share_generator_forward and self._d_loss_fn is discriminator_loss and self._g_loss_fn is generator_loss):
+            return False
+        if self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0:
+            return False
+        mode = os.environ.get("DG_LOW_MEMORY_SHARE", "auto")
+        if mode != "auto":
+            return mode == "on"
+        from .functional import activation_dtype
+        B, N = gen_edge.shape[0], gen_edge.shape[1]
+        dim = int(getattr(self.G, "dim", 128))
+        es = 2 if activation_dtype() == torch.bfloat16 else 4
+        unit = 9.0 * B * N * N * dim * es
+        estimate = unit * (2 * int(getattr(self.D, "depth", 1)) + int(getattr(self.G, "depth", 1)))
+        return estimate <= 0.85 * torch.cuda.get_device_properties(gen_edge.device).total_memory
+
+    def _d_step_low_memory(self, disc_edge, disc_node, gen_edge, gen_node, B, dev, eps, samples=None):
         """discriminator_loss (reference loss.py:52-72) + backward, one term at a time."""
         from .model.loss import gradient_penalty
-        with torch.no_grad():
-            _, _, node_sample, edge_sample = self.G(gen_edge, gen_node)
+        if samples is not None:
+            node_sample, edge_sample = samples
+        else:
+            with torch.no_grad():
+                _, _, node_sample, edge_sample = self.G(gen_edge, gen_node)
         loss_real = -torch.mean(self.D(disc_edge, disc_node))
         loss_real.backward()
         loss_fake = torch.mean(self.D(edge_sample, node_sample))
@@ -237,7 +259,11 @@ class GANStep:
         shared = None
         low = self._low_memory(gen_edge)
         if low:
-            d_loss = self._d_step_low_memory(disc_edge, disc_node, gen_edge, gen_node, B, dev, eps)
+            samples = None
+            if self._low_memory_shares_generator(gen_edge):      # one generator forward for both steps, as in the fast step
+                shared = self.G(gen_edge, gen_node)
+                samples = (shared[2].detach(), shared[3].detach())
+            d_loss = self._d_step_low_memory(disc_edge, disc_node, gen_edge, gen_node, B, dev, eps, samples)
         elif (self.share_generator_forward and self._d_loss_fn is discriminator_loss
                 and self._g_loss_fn is generator_loss
                 and not (self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0)):
