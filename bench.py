@@ -518,7 +518,10 @@ def main():
             "replicas_identical": replicas_identical,
             "allreduce": allreduce,
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
-            "step_memory_mode": "low (D terms differentiated one at a time)" if stepper._low_memory(gen_edge) else "fast",
+            "step_memory_mode": (("low (D terms differentiated one at a time; " +
+                                  ("one generator forward for both steps)" if stepper._low_memory_shares_generator(gen_edge)
+                                   else "the generator runs once per step)"))
+                                 if stepper._low_memory(gen_edge) else "fast"),
         }
         detail = {"kernels": kernels, "roofline_all": all_blocks}
         eager_rec = {"value": B * world * args.steps / elapsed, "unit": "molecules/s", "ms_per_step": 1e3 * elapsed / args.steps,
