@@ -237,10 +237,11 @@ def main():
                  "row_gemm_e_n384", "row_gemm_e_k384", "linear_wgrad_e128", "linear_wgrad_e_n384", "linear_wgrad_e_k384",
                  "ffn", "ffn_wgrad")
     # the attention kernel north_star names (scores + adjacency-modulated softmax + AV fused): the fused attention half
-    # where the shape has one (N <= 48: bf16 since round 3, float32 since round 4), else the attention core
+    # where the shape has one (bf16: N <= 48 since round 3; float32: N <= 48 since round 4, N <= 96 since round 5), else the attention core
     fused_half = ((act_dtype == "bf16" and dgf.attn_half_supported(torch.bfloat16, w["vertexes"], w["dim"])
                    and os.environ.get("DG_ATTN_HALF", "fused") != "unfused") or
-                  (act_dtype == "f32" and w["vertexes"] <= 48 and w["dim"] == 128
+                  (act_dtype == "f32" and w["vertexes"] <= (48 if os.environ.get("DG_ATTN_HALF_F32") == "n48" else 96)
+                   and w["dim"] == 128
                    and os.environ.get("DG_ATTN_HALF_F32", "fused") != "off" and os.environ.get("DG_ROW_GEMM") != "mfma32"))
     attn_key = "attn_half_fwd" if fused_half else "attn_fwd"
     top_key = None
