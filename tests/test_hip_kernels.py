@@ -331,7 +331,7 @@ def test_alternating_traversal_is_invisible_in_the_results(R):
         assert torch.equal(s_, outs[0][0]) and torch.equal(o, outs[0][1])
 
 
-@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45), (2, 49), (3, 90), (2, 96), (9, 64)])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 9), (3, 45), (5, 48), (37, 45), (2, 49), (3, 90), (2, 96), (9, 64), (260, 50), (1, 96)])
 def test_fused_float32_attention_half_forward(B, N):
     """dg_attn_half_f32_fwd -- e = y We^T + be, sc = alpha q_i k_j (e + 1) e, o_i = sum_j softmax_j(sc) v_j,
     y2 = LN(y + sc Woe^T + boe) (reference layers.py:114-135, 186-188) as ONE launch -- against the fp64 closed form and
