@@ -88,6 +88,9 @@ SIGNATURES = {
     "dg_edge_ffn_ln_bwd": (c_int, [_P] * 20 + [_P, c_size_t, c_int64, c_int, c_int, c_int, _P]),
     "dg_edge_ffn_ln_fwd_pair": (c_int, [ctypes.POINTER(FFNFwdArgs), ctypes.POINTER(FFNFwdArgs), c_int, c_int, c_int, _P]),
     "dg_edge_ffn_ln_bwd_pair": (c_int, [ctypes.POINTER(FFNBwdArgs), ctypes.POINTER(FFNBwdArgs), c_int, c_int, c_int, _P]),
+    "dg_ffn_f32_packed_bytes": (c_size_t, []),
+    "dg_ffn_f32_pack": (c_int, [_P, _P, _P, _P]),
+    "dg_ffn_ln_fwd_f32": (c_int, [ctypes.POINTER(FFNFwdArgs), ctypes.POINTER(FFNFwdArgs), _P]),
     "dg_ffn_bf16_padded_rows": (c_int64, [c_int64]),
     "dg_ffn_bf16_packed_bytes": (c_size_t, []),
     "dg_ffn_bf16_pack": (c_int, [_P, _P, _P, _P]),
@@ -123,7 +126,7 @@ KERNEL_IDS = {"attn_fwd": 0, "attn_bwd": 1, "attn_bwd2": 2, "ln_fwd": 3, "ln_bwd
               "attn_half_fwd": 11, "attn_half_bwd": 12,
               "row_gemm_e128": 13, "row_gemm_e_n384": 14, "row_gemm_e_k384": 15,
               "linear_wgrad_e128": 16, "linear_wgrad_e_n384": 17, "linear_wgrad_e_k384": 18,
-              "ffn_node": 19, "ffn_wgrad_node": 20}
+              "ffn_node": 19, "ffn_wgrad_node": 20, "ffn_f32": 21, "ffn_f32_node": 22}
 EDGE_ROWS = 65536        # DG_EDGE_ROWS of include/druggen_hip.h: the default of dg_set_edge_rows()
 _edge_rows = EDGE_ROWS
 

@@ -1,0 +1,592 @@
+// Fused float32 feed-forward forward:  y = LayerNorm(x + fc2(relu(fc1 x)))  with the [R,384] hidden tensor ON CHIP
+// (reference src/model/layers.py:50-53 `MLP.forward`, :191-192 the residual + ln5 / ln6 of `Encoder_Block`).
+//
+// The two-launch form (row_gemm_n384.hip writes h, row_gemm_k384.hip reads it back) moves 5.2 KB per row, 3.1 KB of it the
+// float32-class hidden tensor.  Here h never leaves the CU: per row the launch reads x (512 B) and writes y, the pre-LayerNorm
+// sum, and -- for the backward's weight gradient dW2 = dz^T h only -- the hi fp16 plane of h with one row scale (768 + 4 B,
+// the DG_DTYPE_F32_H16 layout) and the ReLU bit mask in row_gemm_n384.hip's layout (the backward's dh = (dz W2) * m launch
+// reads it unchanged).
+//
+// What made the fusion impossible on the producer / consumer kernels is the weights: W1 and W2 as fp16 hi + lo planes are
+// 2 x 192 KB, more than the LDS and 3/4 of the register file.  So the roles are swapped: the ACTIVATIONS are stationary in
+// registers and the WEIGHTS stream.
+//   * a workgroup = 8 waves walks 128-row tiles (round-robin); wave w owns 16 rows of the tile for the whole pass:
+//     x as MFMA B fragments (hi + lo fp16 under one power-of-two row scale, 32 VGPRs), the residual copy of x (32), the
+//     hidden row block h [16 x 384] (96 VGPRs: float32 while fc1 runs, then hi + lo planes under ONE row scale -- the row
+//     maximum is known only after the last fc1 block, which is why a wave keeps whole rows), the fc2 results (32).
+//   * both weights, pre-packed into fragment order (dg_ffn_f32_pack), travel L2 -> LDS by LDS-DMA (global_load_lds_dwordx4,
+//     no VGPRs) in 20 chunks per pass -- 12 x 16 KB of W1 (two 16-channel blocks each), 8 x 24 KB of W2 (one 16-channel
+//     output block each) -- through three 24 KB buffers, two chunks ahead; one s_barrier per chunk.  Every wave reads every
+//     fragment (conflict-free lane-linear ds_read_b128): 384 KB of LDS reads per wave and pass, the bound of the kernel
+//     (LDS 24.6 k cycles per 128 rows against 18.4 k of MFMA issue per SIMD).  L2 -> LDS traffic is 1 KB per row.
+//   * swapped products on v_mfma_f32_16x16x32_f16 (weights = A, activation rows = B): a lane ends with 4 consecutive
+//     channels of ONE row.  The channel order inside a pair of 16-channel blocks is chosen at pack time so that the lane's
+//     two results are 8 CONSECUTIVE channels: fc1's output is already fc2's B fragment (no transpose, no LDS round trip),
+//     and every store is 16 / 32 contiguous bytes per lane.
+//   * three products per k-step (w_lo.x_hi + w_hi.x_lo + w_hi.x_hi) on independent in-place chains, float32 class --
+//     the arithmetic of row_gemm_n384.hip / row_gemm_k384.hip's H32 instances (one row scale over the whole contraction).
+//   * the next tile's x rows arrive by LDS-DMA into a wave-private 8 KB region during the pass (fragment order: the
+//     permutation is applied on the SOURCE address); waits are counted s_waitcnt vmcnt(N) with N derived from the fixed
+//     issue order below (a store's acknowledgement is never waited for inside a pass).
+#include "common.h"
+
+#include "pair.h"
+#include "traversal.h"
+
+#ifndef FF_SAFE_WAIT
+#define FF_SAFE_WAIT 0      // 1: every chunk wait is vmcnt(0) (debug builds: rules the counted waits out)
+#endif
+namespace dg {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 128;                       // rows per workgroup pass (16 per wave)
+constexpr int kWaves = 8;
+constexpr int kW1Chunk = 16 * 1024;              // one pair of 16-channel fc1 blocks: [block 2][k-step 4][plane 2] fragments of 1 KB
+constexpr int kW2Chunk = 24 * 1024;              // one 16-channel fc2 output block: [k-step 12][plane 2] fragments
+constexpr int kW1Bytes = 12 * kW1Chunk, kW2Bytes = 8 * kW2Chunk;
+constexpr int kPackedBytes = kW1Bytes + kW2Bytes + (384 + 128) * 4;      // + inverse column scales of W1 [384], W2 [128]
+constexpr int kOffW = 0;                         // three chunk buffers
+constexpr int kOffX = 3 * kW2Chunk;              // [wave 8][fragment 8][lane 64][16 B]: the next tile's x rows
+constexpr int kOffTab = kOffX + kWaves * 8192;   // cs1 [384], b1 [384], cs2 [128], b2 [128], gamma [128], beta [128]
+constexpr int kOffBits = kOffTab + 1408 * 4;     // ReLU mask words of the pass: [stage 4][wave' 8][lane' 64]
+constexpr int kLds = kOffBits + 4 * 512 * 4;
+static_assert(kLds <= 160 * 1024, "LDS budget");
+
+// acc += A . B on v_mfma_f32_16x16x32_f16, ALWAYS in place; the first MFMA of a chain takes the constant 0; a vector read of
+// a result is fenced: see row_gemm_k384.hip (a renamed destination one slot behind its producer read a partly written
+// accumulator on gfx950).
+__device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+// packed fp16 pair { fp16(s0 - hi.lo), fp16(s1 - hi.hi) }: the lo plane of two scaled values whose hi plane is `hpk`
+__device__ __forceinline__ unsigned lo_pair(unsigned hpk, float s0, float s1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hpk), "v"(s1));
+    return d;
+}
+__device__ __forceinline__ unsigned scale_exponent(float absmax) {      // biased exponent, clamped away from 0
+    const unsigned e = __float_as_uint(absmax) >> 23;
+    return e < 15u ? 15u : e;
+}
+__device__ __forceinline__ float scale_of(unsigned e) { return __uint_as_float((268u - e) << 23); }      // 2^(14 - (e - 127))
+__device__ __forceinline__ float inv_scale_of(unsigned e) { return __uint_as_float((e - 14u) << 23); }
+
+// hi / lo fp16 planes of eight values under the scale sc: (x sc) = hi + lo up to 2^-22 of the row maximum
+__device__ __forceinline__ void split8(const float (&v)[8], float sc, f16x8& hi, f16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 s = f32x2{v[2 * i], v[2 * i + 1]} * sc;
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(s, f16x2));
+        h[i] = hp;
+        l[i] = lo_pair(hp, s[0], s[1]);
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
+// LDS-DMA, 16 bytes per lane, SGPR base + 32-bit lane offset + immediate.  The instruction offset applies to BOTH addresses:
+// LDS[lds_base + IMM + lane * 16 ..] = *(sbase + voff + IMM).
+// (common.h's dma16_async takes a 64-bit address per lane: twenty chunk addresses per pass are loop invariants that hipcc hoists
+// and spills, and a scratch reload in front of a DMA waits vmcnt(0) -- the whole pipeline drained at every issue.)
+template <int IMM>
+__device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"      // (an SGPR base fresh from v_readfirstlane)
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM)
+        : "memory");
+}
+
+// workgroup barrier that leaves VMEM in flight: __syncthreads()'s fence would wait vmcnt(0) for pending stores; the LDS side
+// (fragment reads, ds_or) is drained explicitly
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// s_waitcnt vmcnt(n) with n a constant after unrolling (the switch folds)
+__device__ __forceinline__ void vm_wait(int n) {
+#define DG_VMW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+    switch (n) {
+        DG_VMW(0) DG_VMW(1) DG_VMW(2) DG_VMW(3) DG_VMW(4) DG_VMW(5) DG_VMW(6) DG_VMW(7) DG_VMW(8) DG_VMW(9) DG_VMW(10) DG_VMW(11)
+        DG_VMW(12) DG_VMW(13) DG_VMW(14) DG_VMW(15) DG_VMW(16) DG_VMW(17) DG_VMW(18) DG_VMW(19) DG_VMW(20) DG_VMW(21) DG_VMW(22)
+        DG_VMW(23) DG_VMW(24) DG_VMW(25) DG_VMW(26) DG_VMW(27) DG_VMW(28) DG_VMW(29) DG_VMW(30) DG_VMW(31) DG_VMW(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef DG_VMW
+}
+
+struct FProb {
+    const float* x;           // [R,128]
+    const char* packed;       // dg_ffn_f32_pack
+    const float* b1;          // [384]
+    const float* b2;          // [128]
+    const float* gamma;       // [128]
+    const float* beta;
+    float* y;                 // [R,128]
+    _Float16* h;              // [R,384] fp16: the hi plane of h under one row scale (DG_DTYPE_F32_H16 buffer), KEEP only
+    float* hscale;            // [R] inverse row scales of that plane
+    unsigned* bits;           // ReLU mask words in row_gemm_n384.hip's layout ([stage of 32 rows][8][64]), KEEP only
+    float* pre;               // [R,128] pre-LayerNorm sum, KEEP only
+    float* mean;              // [R]
+    float* rstd;
+    int64_t R;
+    float eps;
+    int reverse;              // tiles in descending order (traversal.h)
+};
+
+// KEEP: the outputs only a backward reads (h plane, its scales, mask words, pre-LayerNorm sum) are written
+template <bool KEEP>
+__global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb p0, const FProb p1, const int nb0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool second = static_cast<int>(blockIdx.x) >= nb0;      // uniform
+    const float* __restrict__ const x = second ? p1.x : p0.x;
+    const char* __restrict__ const packed = second ? p1.packed : p0.packed;
+    float* __restrict__ const y = second ? p1.y : p0.y;
+    _Float16* __restrict__ const hplane = second ? p1.h : p0.h;
+    float* __restrict__ const hscale = second ? p1.hscale : p0.hscale;
+    unsigned* __restrict__ const gbits = second ? p1.bits : p0.bits;
+    float* __restrict__ const pre = second ? p1.pre : p0.pre;
+    float* __restrict__ const gmean = second ? p1.mean : p0.mean;
+    float* __restrict__ const grstd = second ? p1.rstd : p0.rstd;
+    const int64_t R = second ? p1.R : p0.R;
+    const float eps = second ? p1.eps : p0.eps;
+    const int reverse = second ? p1.reverse : p0.reverse;
+    const int bidx = second ? static_cast<int>(blockIdx.x) - nb0 : static_cast<int>(blockIdx.x);
+    const int nblk = second ? static_cast<int>(gridDim.x) - nb0 : nb0;
+    const int64_t tiles = (R + kTile - 1) / kTile;
+    const int T = static_cast<int>((tiles - bidx + nblk - 1) / nblk);      // >= 1: the launch has at most `tiles` workgroups
+    auto tile_of = [&](int t) {
+        const int64_t st = bidx + static_cast<int64_t>(t) * nblk;
+        const int64_t c = st < tiles ? st : tiles - 1;      // (prefetch past the end: any valid tile)
+        return reverse ? tiles - 1 - c : c;
+    };
+    const int n = lane & 15, kq = lane >> 4;
+    float* const tab = reinterpret_cast<float*>(smem + kOffTab);
+    const unsigned lds_w = lds_byte_address(smem + kOffW);
+    const unsigned lds_x = lds_byte_address(smem + kOffX) + static_cast<unsigned>(w) * 8192u;
+
+    // ---- streams: weight chunk c of a pass (0..11 fc1, 12..19 fc2) into buffer b; wave w copies its share of fragments
+    const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
+    auto dma_chunk = [&](int c, int b) {
+        c = c >= 20 ? c - 20 : c;
+        const int per = c < 12 ? 2 : 3;
+        // (uniform: the wave's first fragment of the chunk; the following ones are instruction offsets)
+        const char* src = (c < 12 ? packed + c * kW1Chunk : packed + kW1Bytes + (c - 12) * kW2Chunk) + w * per * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w + static_cast<unsigned>(b * kW2Chunk + w * per * 1024));
+        dma16_s<0>(src, lane16, dst);
+        dma16_s<1024>(src, lane16, dst);
+        if (per == 3) dma16_s<2048>(src, lane16, dst);
+    };
+    // the 16 rows of this wave in tile `tile`, as B fragments in the wave's LDS region: fragment f = (ks, half) holds, for lane
+    // (n, kq), x[row n][32 ks + 8 kq + 4 half .. + 3]; rows past the end read the last row (their results are dropped)
+    auto dma_x = [&](int64_t tile, int f) {
+        const int64_t r0t = tile * kTile + w * 16;
+        const int64_t rb = r0t < R - 1 ? r0t : R - 1;      // uniform
+        const int64_t rl = (r0t + n < R - 1 ? r0t + n : R - 1) - rb;
+        const unsigned voff = static_cast<unsigned>(rl) * 512u + static_cast<unsigned>(kq) * 32u;
+        // (the instruction offset (f >> 1) * 128 + (f & 1) * 16 moves the LDS address too: taken off the base)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_x + static_cast<unsigned>(f * 1024 - ((f >> 1) * 128 + (f & 1) * 16)));
+        const float* sb = x + rb * 128;
+        switch (f) {      // (f is a constant after unrolling: instruction offset (f >> 1) * 128 + (f & 1) * 16)
+            case 0: dma16_s<0>(sb, voff, dst); break;
+            case 1: dma16_s<16>(sb, voff, dst); break;
+            case 2: dma16_s<128>(sb, voff, dst); break;
+            case 3: dma16_s<144>(sb, voff, dst); break;
+            case 4: dma16_s<256>(sb, voff, dst); break;
+            case 5: dma16_s<272>(sb, voff, dst); break;
+            case 6: dma16_s<384>(sb, voff, dst); break;
+            default: dma16_s<400>(sb, voff, dst); break;
+        }
+    };
+
+    // ---- prologue: tables, mask words zeroed, chunks 0 and 1, the first tile's rows
+    {
+        const float* inv_cs = reinterpret_cast<const float*>(packed + kW1Bytes + kW2Bytes);
+        const float* b1 = second ? p1.b1 : p0.b1;
+        const float* b2 = second ? p1.b2 : p0.b2;
+        const float* gamma = second ? p1.gamma : p0.gamma;
+        const float* beta = second ? p1.beta : p0.beta;
+        for (int i = threadIdx.x; i < 384; i += 64 * kWaves) {
+            tab[i] = inv_cs[i];
+            tab[384 + i] = b1[i];
+        }
+        if (threadIdx.x < 128) {
+            const int i = threadIdx.x;
+            tab[768 + i] = inv_cs[384 + i];
+            tab[896 + i] = b2[i];
+            tab[1024 + i] = gamma[i];
+            tab[1152 + i] = beta[i];
+        }
+        *reinterpret_cast<u32x4*>(smem + kOffBits + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    dma_chunk(0, 0);
+    dma_chunk(1, 1);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) dma_x(tile_of(0), f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+
+    // younger VMEM instructions per wave behind the DMA of chunk c at the point where chunk c is waited for.  Issue order of a
+    // pass: iteration c = wait, barrier, DMA of chunk c + 2 (2 instructions for an fc1 chunk, 3 for an fc2 chunk), [c == 12: mask
+    // words, SB], [c >= 12: fragment c - 12 of the next tile's rows, 1], compute, [c == 11: h plane + scale, S1], [c == 19: y,
+    // pre, statistics, S2].  VMEM operations of a wave retire in order (vmcnt(N) = all but the youngest N are done).
+    constexpr int S1 = KEEP ? 13 : 0, SB = KEEP ? 1 : 0, S2 = KEEP ? 18 : 10;
+    auto younger = [&](int c) {
+        if (c == 0) return 1 + 2 + 1 + S2;      // rows 6, DMA(1), rows 7, S2
+        if (c == 1) return 1 + S2 + 2;          // rows 7, S2, DMA(2)
+        if (c <= 10) return 2;                  // DMA(c + 1), an fc1 chunk
+        if (c == 11) return 3;                  // DMA(12)
+        if (c == 12) return 3 + S1;             // DMA(13), S1
+        if (c == 13) return S1 + 3 + SB + 1;    // S1, DMA(14), mask words, rows 0
+        if (c == 14) return SB + 1 + 3 + 1;     // mask words, rows 0, DMA(15), rows 1
+        if (c <= 18) return 1 + 3 + 1;          // rows, DMA(c + 1), rows
+        return 1 + 2 + 1;                       // c == 19: rows 5, DMA(0) of the next pass, rows 6
+    };
+
+    int gb = 0;      // buffer of the chunk about to be consumed (uniform)
+#pragma nounroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t tile = tile_of(t);
+        const int64_t r0 = tile * kTile + w * 16;      // first row of this wave
+        const int64_t leftw = R - r0;
+        const int rows = leftw <= 0 ? 0 : (leftw < 16 ? static_cast<int>(leftw) : 16);      // 0: every store is dropped
+
+        // ---- x rows: LDS -> registers, row maximum, hi / lo planes (the float32 rows stay in the LDS region: fc2 reads its
+        // residual operand from there, fragment by fragment, and refills each fragment with the next tile's)
+        vm_wait(FF_SAFE_WAIT ? 0 : S2);      // the last fragment was requested in iteration 19, in front of the S2 stores
+        float xa[4][8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float4 v = *reinterpret_cast<const float4*>(smem + kOffX + w * 8192 + f * 1024 + lane * 16);
+            xa[f >> 1][(f & 1) * 4 + 0] = v.x;
+            xa[f >> 1][(f & 1) * 4 + 1] = v.y;
+            xa[f >> 1][(f & 1) * 4 + 2] = v.z;
+            xa[f >> 1][(f & 1) * 4 + 3] = v.w;
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(xa[ks][i]));
+        mx = xor_max<16>(mx);      // the four lanes (kq) of row n
+        const unsigned ex = scale_exponent(mx);
+        const float inv_sx = inv_scale_of(ex);
+        f16x8 xh[4], xl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) split8(xa[ks], scale_of(ex), xh[ks], xl[ks]);
+
+        // ---- fc1: h = relu(x W1^T + b1), 12 pairs of 16-channel blocks; lane (n, kq) ends with channels 32 j + 8 kq .. + 7
+        float hv[12][8];
+        const int rb = w & 1, stg = w >> 1;      // row block / stage of this wave's rows in the mask layout (32-row stages)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            vm_wait(FF_SAFE_WAIT ? 0 : younger(j));
+            wg_barrier();
+            dma_chunk(j + 2, gb >= 1 ? gb - 1 : 2);      // buffer (gb + 2) % 3
+            const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
+            f32x4 pa[3], pb[3];
+            // fragments one k-step ahead of their MFMAs (scheduling fences: hipcc otherwise requests all 16 at once, 64 VGPRs)
+            f16x8 fr[2][4];
+            auto read_frags = [&](int ks, f16x8 (&d)[4]) {
+                d[0] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 0) * 1024);            // block A hi, lo
+                d[1] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 1) * 1024);
+                d[2] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 0) * 1024);      // block B hi, lo
+                d[3] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 1) * 1024);
+            };
+            read_frags(0, fr[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) read_frags(ks + 1, fr[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 &wha = fr[ks & 1][0], &wla = fr[ks & 1][1], &whb = fr[ks & 1][2], &wlb = fr[ks & 1][3];
+                if (ks == 0) {
+                    mfma16_first(pa[0], wla, xh[0]);
+                    mfma16_first(pb[0], wlb, xh[0]);
+                    mfma16_first(pa[1], wha, xl[0]);
+                    mfma16_first(pb[1], whb, xl[0]);
+                    mfma16_first(pa[2], wha, xh[0]);
+                    mfma16_first(pb[2], whb, xh[0]);
+                } else {
+                    mfma16(pa[0], wla, xh[ks]);
+                    mfma16(pb[0], wlb, xh[ks]);
+                    mfma16(pa[1], wha, xl[ks]);
+                    mfma16(pb[1], whb, xl[ks]);
+                    mfma16(pa[2], wha, xh[ks]);
+                    mfma16(pb[2], whb, xh[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gb = gb == 2 ? 0 : gb + 1;
+            // epilogue: scales, bias, ReLU, mask bits
+            const float4 ca = ld4(tab + 32 * j + 8 * kq), cb = ld4(tab + 32 * j + 8 * kq + 4);
+            const float4 ba = ld4(tab + 384 + 32 * j + 8 * kq), bb = ld4(tab + 384 + 32 * j + 8 * kq + 4);
+            mfma_results_ready();
+            const float cav[4] = {ca.x, ca.y, ca.z, ca.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+            const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+            unsigned ma = 0, mb = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float va = fmaf((pa[0][i] + pa[1][i]) + pa[2][i], inv_sx * cav[i], bav[i]);
+                const float vb = fmaf((pb[0][i] + pb[1][i]) + pb[2][i], inv_sx * cbv[i], bbv[i]);
+                if (KEEP) {
+                    ma |= va > 0.f ? (1u << i) : 0u;
+                    mb |= vb > 0.f ? (1u << i) : 0u;
+                }
+                hv[j][i] = fmaxf(va, 0.f);
+                hv[j][4 + i] = fmaxf(vb, 0.f);
+            }
+            if (KEEP) {
+                // channel c = 32 j + 8 kq + 4 blk + i of row 16 rb + n of the stage: word (c / 48, lane' = ((c % 16) / 4) * 16 + n),
+                // bit (rb * 3 + (c % 48) / 16) * 4 + i  (row_gemm_n384.hip)
+                const int b16 = 2 * j + (kq >> 1);            // 16-channel block of the lane's eight channels
+                const int wv = b16 / 3, cbk = b16 - 3 * wv;
+                unsigned* const word = reinterpret_cast<unsigned*>(smem + kOffBits) + stg * 512 + wv * 64 + (2 * (kq & 1)) * 16 + n;
+                const int sh = (rb * 3 + cbk) * 4;
+                atomicOr(word, ma << sh);
+                atomicOr(word + 16, mb << sh);
+            }
+        }
+
+        // ---- h: ONE scale per row over all 384 channels, hi / lo planes; the hi plane leaves for the backward
+        float mh = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mh = fmaxf(mh, hv[j][i]);
+        mh = xor_max<16>(mh);
+        const unsigned eh = scale_exponent(mh);
+        const float inv_sh = inv_scale_of(eh);
+        f16x8 hh[12], hl[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) split8(hv[j], scale_of(eh), hh[j], hl[j]);
+        if (KEEP) {
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hplane + r0 * 384, 0, rows * 768, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hscale + r0, 0, rows * 4, 0x00020000);
+            const unsigned voff = static_cast<unsigned>(n) * 768u + static_cast<unsigned>(kq) * 16u;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh[j]), rh, voff, j * 64, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv_sh), rs, kq == 0 ? static_cast<unsigned>(n) * 4u : 0x7FFFFFF0u, 0, 0);
+        }
+
+        // ---- fc2: z = x + h W2^T + b2, 8 blocks of 16 output channels; lane (n, kq) ends with channels 32 p + 8 kq .. + 7
+        float z[4][8];
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+            vm_wait(FF_SAFE_WAIT ? 0 : younger(12 + ob));
+            wg_barrier();
+            dma_chunk(12 + ob + 2, gb >= 1 ? gb - 1 : 2);
+            if (KEEP && ob == 0) {
+                // every wave's fc1 bits of the pass are in LDS (the barrier above): 2048 words leave, 16 bytes per thread, and
+                // are zeroed for the next pass
+                const int64_t stages = (R + 31) / 32 - tile * 4;
+                const int nst = stages < 4 ? static_cast<int>(stages) : 4;
+                const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(gbits + tile * 2048, 0, nst * 2048, 0x00020000);
+                u32x4* const src = reinterpret_cast<u32x4*>(smem + kOffBits + threadIdx.x * 16);
+                const u32x4 v = *src;
+                *src = u32x4{0u, 0u, 0u, 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rbits, static_cast<unsigned>(threadIdx.x) * 16u, 0, 0);
+            }
+            // residual operand: fragment ob of this tile's rows (channels 32 p + 8 kq + 4 blk .. of row n); its slot is refilled
+            // with the same fragment of the next tile
+            const float4 xres = *reinterpret_cast<const float4*>(smem + kOffX + w * 8192 + ob * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_x(tile_of(t + 1), ob);
+            const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
+            f32x4 q0, q1, q2;
+            f16x8 fr[3][2];
+            auto read_frags = [&](int j, f16x8 (&d)[2]) {
+                d[0] = *reinterpret_cast<const f16x8*>(wb + (j * 2 + 0) * 1024);
+                d[1] = *reinterpret_cast<const f16x8*>(wb + (j * 2 + 1) * 1024);
+            };
+            read_frags(0, fr[0]);
+            read_frags(1, fr[1]);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                if (j < 10) read_frags(j + 2, fr[(j + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 &wh = fr[j % 3][0], &wl = fr[j % 3][1];
+                if (j == 0) {
+                    mfma16_first(q0, wl, hh[0]);
+                    mfma16_first(q1, wh, hl[0]);
+                    mfma16_first(q2, wh, hh[0]);
+                } else {
+                    mfma16(q0, wl, hh[j]);
+                    mfma16(q1, wh, hl[j]);
+                    mfma16(q2, wh, hh[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gb = gb == 2 ? 0 : gb + 1;
+            const int p = ob >> 1, blk = ob & 1;
+            const float4 cs = ld4(tab + 768 + 32 * p + 8 * kq + 4 * blk), bs = ld4(tab + 896 + 32 * p + 8 * kq + 4 * blk);
+            mfma_results_ready();
+            const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+            const float xrv[4] = {xres.x, xres.y, xres.z, xres.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[p][4 * blk + i] = fmaf((q0[i] + q1[i]) + q2[i], inv_sh * csv[i], bsv[i]) + xrv[i];
+        }
+
+        // ---- LayerNorm over the row (32 values per lane, four lanes per row) and the stores
+        float s1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1 += z[p][i];
+        const float mu = xor_sum<16>(s1) * (1.0f / 128.0f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = z[p][i] - mu;
+                s2 = fmaf(d, d, s2);
+            }
+        const float rstd = rsqrtf(xor_sum<16>(s2) * (1.0f / 128.0f) + eps);
+        {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 128, 0, rows * 512, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(KEEP ? pre + r0 * 128 : y, 0, KEEP ? rows * 512 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(gmean + r0, 0, rows * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(grstd + r0, 0, rows * 4, 0x00020000);
+            const unsigned voff = static_cast<unsigned>(n) * 512u + static_cast<unsigned>(kq) * 32u;
+            const unsigned soff = kq == 0 ? static_cast<unsigned>(n) * 4u : 0x7FFFFFF0u;
+            if (KEEP) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(z[p][0]), __float_as_uint(z[p][1]), __float_as_uint(z[p][2]),
+                                                                 __float_as_uint(z[p][3])}, rp, voff, p * 128, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(z[p][4]), __float_as_uint(z[p][5]), __float_as_uint(z[p][6]),
+                                                                 __float_as_uint(z[p][7])}, rp, voff, p * 128 + 16, 0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 g0 = ld4(tab + 1024 + 32 * p + 8 * kq), g1 = ld4(tab + 1024 + 32 * p + 8 * kq + 4);
+                const float4 e0 = ld4(tab + 1152 + 32 * p + 8 * kq), e1 = ld4(tab + 1152 + 32 * p + 8 * kq + 4);
+                const u32x4 o0 = {__float_as_uint(fmaf((z[p][0] - mu) * rstd, g0.x, e0.x)), __float_as_uint(fmaf((z[p][1] - mu) * rstd, g0.y, e0.y)),
+                                  __float_as_uint(fmaf((z[p][2] - mu) * rstd, g0.z, e0.z)), __float_as_uint(fmaf((z[p][3] - mu) * rstd, g0.w, e0.w))};
+                const u32x4 o1 = {__float_as_uint(fmaf((z[p][4] - mu) * rstd, g1.x, e1.x)), __float_as_uint(fmaf((z[p][5] - mu) * rstd, g1.y, e1.y)),
+                                  __float_as_uint(fmaf((z[p][6] - mu) * rstd, g1.z, e1.z)), __float_as_uint(fmaf((z[p][7] - mu) * rstd, g1.w, e1.w))};
+                __builtin_amdgcn_raw_buffer_store_b128(o0, ry, voff, p * 128, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, ry, voff, p * 128 + 16, 0);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rm, soff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), rr, soff, 0, 0);
+        }
+    }
+    // the DMAs issued for a pass that does not come must land before the LDS is handed to the next workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- pack: one wave per output channel.  W1 [384,128] (blocks 0..383), W2 [128,384] (blocks 384..511): the row is scaled by
+// the power of two that puts its largest magnitude into [2^14, 2^15), split hi / lo, and scattered into the fragment order of
+// the kernel above.  Channel c = 32 j + 8 g + 4 blk + i sits at MFMA row m = 4 g + i of block blk of pair j.
+__global__ __launch_bounds__(64) void ffn_f32_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, char* __restrict__ packed) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool first = b < 384;
+    const int c = first ? b : b - 384;
+    const int K = first ? 128 : 384;
+    const float* row = first ? w1 + static_cast<size_t>(c) * 128 : w2 + static_cast<size_t>(c) * 384;
+    const int per = K / 64;      // 2 or 6 consecutive k per thread
+    float v[6];
+    float mx = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = row[t * per + i];
+        mx = fmaxf(mx, fabsf(v[i]));
+    }
+    mx = xor_max<1>(mx);
+    const unsigned e = scale_exponent(mx);
+    const float sc = scale_of(e);
+    const int pj = c >> 5, rem = c & 31, m = 4 * (rem >> 3) + (rem & 3), blk = (rem >> 2) & 1;
+    for (int i = 0; i < per; ++i) {
+        const int k = t * per + i;
+        const int ks = k >> 5, kq = (k >> 3) & 3, tt = k & 7;
+        const float xs = v[i] * sc;
+        const _Float16 hi = static_cast<_Float16>(xs);
+        const _Float16 lo = static_cast<_Float16>(xs - static_cast<float>(hi));
+        size_t off;
+        if (first) off = static_cast<size_t>(pj) * kW1Chunk + static_cast<size_t>((blk * 4 + ks) * 2) * 1024 + (kq * 16 + m) * 16 + tt * 2;
+        else off = kW1Bytes + static_cast<size_t>(2 * pj + blk) * kW2Chunk + static_cast<size_t>(ks * 2) * 1024 + (kq * 16 + m) * 16 + tt * 2;
+        *reinterpret_cast<_Float16*>(packed + off) = hi;
+        *reinterpret_cast<_Float16*>(packed + off + 1024) = lo;
+    }
+    if (t == 0) reinterpret_cast<float*>(packed + kW1Bytes + kW2Bytes)[first ? c : 384 + c] = inv_scale_of(e);
+}
+
+int check_args(const dg_ffn_fwd_args* a, const char* who) {
+    if (!a || !a->x || !a->w1_packed || !a->b1 || !a->b2 || !a->gamma || !a->beta || !a->y || !a->mean || !a->rstd)
+        return fail(DG_E_ARG, "dg_ffn_ln_fwd_f32: null pointer (%s)", who);
+    const bool keep = a->h != nullptr;
+    if (keep != (a->relu_bits != nullptr) || keep != (a->pre_ln != nullptr))
+        return fail(DG_E_ARG, "dg_ffn_ln_fwd_f32: h, relu_bits and pre_ln go together (%s)", who);
+    if (a->R < 0) return fail(DG_E_SHAPE, "dg_ffn_ln_fwd_f32: negative row count (%s)", who);
+    return 0;
+}
+
+FProb make_prob(const dg_ffn_fwd_args* a) {
+    char* h = static_cast<char*>(a->h);
+    return FProb{static_cast<const float*>(a->x), static_cast<const char*>(a->w1_packed), a->b1, a->b2, a->gamma, a->beta,
+                 static_cast<float*>(a->y), reinterpret_cast<_Float16*>(h),
+                 h ? reinterpret_cast<float*>(h + dg_hidden_scale_offset(a->R, 384)) : nullptr, a->relu_bits,
+                 static_cast<float*>(a->pre_ln), a->mean, a->rstd, a->R, a->eps, take_direction(a->R)};
+}
+
+}  // namespace
+}  // namespace dg
+
+using namespace dg;
+
+extern "C" size_t dg_ffn_f32_packed_bytes(void) { return kPackedBytes; }
+
+extern "C" int dg_ffn_f32_pack(const float* w1, const float* w2, void* packed, dg_stream_t stream) {
+    if (!w1 || !w2 || !packed) return fail(DG_E_ARG, "dg_ffn_f32_pack: null pointer");
+    hipLaunchKernelGGL(ffn_f32_pack_kernel, dim3(512), dim3(64), 0, static_cast<hipStream_t>(stream), w1, w2, static_cast<char*>(packed));
+    return check_launch("dg_ffn_f32_pack");
+}
+
+extern "C" int dg_ffn_ln_fwd_f32(const dg_ffn_fwd_args* node, const dg_ffn_fwd_args* edge, dg_stream_t stream_) {
+    if (int st = check_args(edge, "edge")) return st;
+    if (node)
+        if (int st = check_args(node, "node")) return st;
+    if (node && (node->h != nullptr) != (edge->h != nullptr))
+        return fail(DG_E_ARG, "dg_ffn_ln_fwd_f32: both problems keep their backward outputs or neither does");
+    if (node && node->R == 0) node = nullptr;
+    if (edge->R == 0 && !node) return 0;
+    if (edge->R == 0) {
+        edge = node;
+        node = nullptr;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const FProb pe = make_prob(edge);
+    const FProb pn = node ? make_prob(node) : pe;
+    const int64_t t0 = (pe.R + kTile - 1) / kTile, t1 = node ? (pn.R + kTile - 1) / kTile : 0;
+    int nb0, nb1;
+    pair_split(t0, t1, 256, &nb0, &nb1);
+    ProfScope prof(pe.R < edge_rows() ? DG_K_FFN_F32_NODE : DG_K_FFN_F32, stream);
+    if (edge->h) {
+        DG_OPT_IN_LDS((&ffn_fused_f32_kernel<true>), kLds);
+        hipLaunchKernelGGL((ffn_fused_f32_kernel<true>), dim3(nb0 + nb1), dim3(64 * kWaves), kLds, stream, pe, pn, nb0);
+    } else {
+        DG_OPT_IN_LDS((&ffn_fused_f32_kernel<false>), kLds);
+        hipLaunchKernelGGL((ffn_fused_f32_kernel<false>), dim3(nb0 + nb1), dim3(64 * kWaves), kLds, stream, pe, pn, nb0);
+    }
+    return check_launch("dg_ffn_ln_fwd_f32");
+}

@@ -23,7 +23,7 @@ from . import _lib
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops", "traffic_floor_bytes",
-           "set_activation_dtype", "activation_dtype", "hidden_storage", "hidden_forward_storage", "hidden_to_float", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts"]
+           "set_activation_dtype", "activation_dtype", "hidden_storage", "hidden_forward_storage", "hidden_to_float", "activations", "as_one_hot", "one_hot_labels", "embed_sym_onehot", "OutSlot", "join_parts", "set_fused_ffn_f32"]
 
 # Algorithmic HBM bytes per kernel, accumulated per launch so that
 # bench.py can turn the HIP-event times of dg_prof_* into achieved GB/s.
@@ -1439,6 +1439,65 @@ def _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps):
     return ln_residual(x, linear(torch.relu(linear(x, w1, b1)), w2, b2), gamma, beta, eps)
 
 
+_ffn_f32_pack_cache = {}
+
+
+def _ffn_packed_f32(w1, w2):
+    """The fragment-order copy of (fc1.weight [384,128], fc2.weight [128,384]) that the fused float32 feed-forward forward
+    streams (dg_ffn_f32_pack), cached like ``packed_weight``: re-packed after an optimizer step."""
+    w1, w2 = _canon(w1), _canon(w2)
+    key = (id(w1), id(w2))
+    hit = _ffn_f32_pack_cache.get(key)
+    if (hit is not None and hit[0]() is w1 and hit[1]() is w2 and hit[2] == (w1._version, w2._version)
+            and hit[4] == (w1.data_ptr(), w2.data_ptr()) and hit[5] == _weights_epoch):
+        return hit[3]
+    if len(_ffn_f32_pack_cache) > 1024:
+        with _cache_lock:
+            for k in [k for k, v in list(_ffn_f32_pack_cache.items()) if v[0]() is None or v[1]() is None]:
+                _ffn_f32_pack_cache.pop(k, None)
+    lib = _lib.load()
+    packed = torch.empty(int(lib.dg_ffn_f32_packed_bytes()), dtype=torch.uint8, device=w1.device)
+    with _dev(w1):
+        _lib.check(lib.dg_ffn_f32_pack(_lib.fptr(_c(w1.detach())), _lib.fptr(_c(w2.detach())), packed.data_ptr(),
+                                       _lib.stream_of(w1)), "dg_ffn_f32_pack")
+    _ffn_f32_pack_cache[key] = (weakref.ref(w1), weakref.ref(w2), (w1._version, w2._version), packed,
+                                (w1.data_ptr(), w2.data_ptr()), _weights_epoch)
+    return packed
+
+
+_fused_ffn_f32 = os.environ.get("DG_FFN_F32", "fused") != "unfused"
+
+
+def set_fused_ffn_f32(on: bool) -> None:
+    """Route the float32 feed-forward FORWARD through the fused kernel (dg_ffn_ln_fwd_f32: the [R,384] hidden tensor stays on
+    chip; default) or through the two row-GEMM launches (A/B measurements, DG_FFN_F32=unfused at import)."""
+    global _fused_ffn_f32
+    _fused_ffn_f32 = bool(on)
+
+
+def fused_ffn_f32_supported(x2, w1, w2) -> bool:
+    """dg_ffn_ln_fwd_f32 serves float32 rows, dim 128, hidden 384, in the default hidden-storage mode: what it leaves for the
+    backward is the hi fp16 plane of h (a DG_DTYPE_F32_H16 buffer) -- exactly what the default mode's backward reads of the
+    pre-split h (dW2 = dz^T h_hi)."""
+    return (_fused_ffn_f32 and x2.is_cuda and x2.dtype == torch.float32 and tuple(w1.shape) == (384, 128)
+            and tuple(w2.shape) == (128, 384) and hidden_storage() == "dh16" and hidden_forward_storage() == "split")
+
+
+def _ffn_f32_fwd_args(p, keep):
+    """dg_ffn_fwd_args of one problem for dg_ffn_ln_fwd_f32 (``p``: the dict built by the feed-forward nodes)."""
+    return _lib.FFNFwdArgs(
+        _lib.ptr(p["x2"]), _ffn_packed_f32(p["w1"], p["w2"]).data_ptr(), _lib.fptr(_c(p["b1"])), None, _lib.fptr(_c(p["b2"])),
+        _lib.fptr(_c(p["gamma"])), _lib.fptr(_c(p["beta"])), _lib.ptr(p["y"]), _hptr(p["h"]) if keep else None,
+        p["bits"].data_ptr() if keep else None, _lib.ptr(p["pre"]), _lib.ptr(p["mean"]), _lib.ptr(p["rstd"]), p["R"], float(p["eps"]))
+
+
+def _account_ffn_f32(R, C, H, keep):
+    """Traffic of one problem of a fused forward launch: x in, y out (+ pre-LN sum, the hi plane of h with its row scales, one
+    mask bit per hidden element when a backward follows); the floor is x in + y out."""
+    key = "ffn_f32" if R >= _lib.edge_rows() else "ffn_f32_node"
+    _account(key, R * (4 * C * (3 if keep else 2) + ((2 * H + 4 + H // 8) if keep else 0)), 4 * R * C * H, floor=R * 4 * C * 2)
+
+
 class _FFNLN(Function):
     """LN(x + fc2(relu(fc1 x))) -- MLP + residual + LayerNorm of Encoder_Block (reference
     layers.py:50-53,191-192).  Forward: two row-GEMM launches (bias+ReLU epilogue; bias +
@@ -1457,22 +1516,33 @@ class _FFNLN(Function):
         # no input needs a gradient (e.g. the Generator's forward inside the D step): nothing is kept for a backward --
         # no pre-LayerNorm sum (one [R,C] write pass) and no ReLU bit mask
         keep = any(ctx.needs_input_grad)
+        fused = fused_ffn_f32_supported(x2, w1, w2)
+        if fused:      # h stays on chip; its hi fp16 plane leaves for the backward's dW2 (a DG_DTYPE_F32_H16 buffer)
+            code = _lib.F32_H16
         y = torch.empty(R, C, dtype=adt, device=dev)
-        h = _hidden_empty(R, H, adt, code, dev)
+        h = _hidden_empty(R, H, adt, code, dev) if (keep or not fused) else None
         pre = torch.empty(R, C, dtype=adt, device=dev) if keep else None
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         bits = torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev) if keep else None
         with _dev(x2):
-            _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), packed_weight(w1, 0, adt).data_ptr(), _lib.fptr(_c(b1)),
-                                              packed_weight(w2, 0, adt).data_ptr(), _lib.fptr(_c(b2)), _lib.fptr(_c(gamma)),
-                                              _lib.fptr(_c(beta)), _lib.ptr(y), _hptr(h),
-                                              None if bits is None else bits.data_ptr(),
-                                              _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
-                                              _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
-        hb = _hrow_bytes(code, es, H)
-        _account(_gemm_key(R, C, H), R * (es * C + hb), 2 * R * C * H)
-        _account(_gemm_key(R, H, C), R * (hb + es * (3 if keep else 2) * C), 2 * R * C * H, floor=R * (hb + es * 2 * C))
+            if fused:
+                arg = _ffn_f32_fwd_args(dict(x2=x2, w1=w1, w2=w2, b1=b1, b2=b2, gamma=gamma, beta=beta, y=y, h=h, bits=bits, pre=pre,
+                                             mean=mean, rstd=rstd, R=R, eps=eps), keep)
+                _lib.check(lib.dg_ffn_ln_fwd_f32(None, ctypes.byref(arg), _lib.stream_of(x2)), "dg_ffn_ln_fwd_f32")
+            else:
+                _lib.check(lib.dg_edge_ffn_ln_fwd(_lib.ptr(x2), packed_weight(w1, 0, adt).data_ptr(), _lib.fptr(_c(b1)),
+                                                  packed_weight(w2, 0, adt).data_ptr(), _lib.fptr(_c(b2)), _lib.fptr(_c(gamma)),
+                                                  _lib.fptr(_c(beta)), _lib.ptr(y), _hptr(h),
+                                                  None if bits is None else bits.data_ptr(),
+                                                  _lib.ptr(pre), _lib.ptr(mean), _lib.ptr(rstd), R, C, H, eps, code,
+                                                  _lib.stream_of(x2)), "dg_edge_ffn_ln_fwd")
+        if fused:
+            _account_ffn_f32(R, C, H, keep)
+        else:
+            hb = _hrow_bytes(code, es, H)
+            _account(_gemm_key(R, C, H), R * (es * C + hb), 2 * R * C * H)
+            _account(_gemm_key(R, H, C), R * (hb + es * (3 if keep else 2) * C), 2 * R * C * H, floor=R * (hb + es * 2 * C))
         if not keep:
             ctx.mark_non_differentiable(mean, rstd)
             return y.view(x.shape), None, mean, rstd
@@ -1612,26 +1682,45 @@ class _FFNLNPair(Function):
             R = x2.shape[0]
             dev, adt = x2.device, x2.dtype
             code = _hidden_code(adt)
+            fused = fused_ffn_f32_supported(x2, w1, w2) and (not probs or probs[0]["fused"])
+            if fused:      # (both problems or neither: one launch carries them)
+                code = _lib.F32_H16
+            elif probs and probs[0]["fused"]:
+                probs[0]["fused"] = False
+                probs[0]["code"] = _hidden_code(adt)
+                probs[0]["h"] = _hidden_empty(probs[0]["R"], probs[0]["H"], adt, probs[0]["code"], dev)
             probs.append(dict(
-                inp=inp, x2=x2, R=R, C=C, H=H, code=code, w1=w1, b1=b1, w2=w2, b2=b2, gamma=gamma, beta=beta,
-                y=torch.empty(R, C, dtype=adt, device=dev), h=_hidden_empty(R, H, adt, code, dev),
+                inp=inp, x2=x2, R=R, C=C, H=H, code=code, w1=w1, b1=b1, w2=w2, b2=b2, gamma=gamma, beta=beta, fused=fused,
+                y=torch.empty(R, C, dtype=adt, device=dev),
+                h=_hidden_empty(R, H, adt, code, dev) if (keep or not fused) else None,
                 pre=torch.empty(R, C, dtype=adt, device=dev) if keep else None,
                 mean=torch.empty(R, dtype=torch.float32, device=dev), rstd=torch.empty(R, dtype=torch.float32, device=dev),
                 bits=torch.empty(int(lib.dg_row_gemm_mask_words(R, C, H, code)), dtype=torch.int32, device=dev) if keep else None))
         ref = probs[0]["x2"]
+        fused = probs[0]["fused"] and probs[1]["fused"]
         cargs = []
         for p, eps in zip(probs, (eps_n, eps_e)):      # dg_ffn_fwd_args: h = relu(x W1^T + b1), y = LN(x + h W2^T + b2)
+            p["eps"] = eps
+            if fused:
+                cargs.append(_ffn_f32_fwd_args(p, keep))
+                continue
             cargs.append(_lib.FFNFwdArgs(
                 _lib.ptr(p["x2"]), packed_weight(p["w1"], 0, ref.dtype).data_ptr(), _lib.fptr(_c(p["b1"])),
                 packed_weight(p["w2"], 0, ref.dtype).data_ptr(), _lib.fptr(_c(p["b2"])), _lib.fptr(_c(p["gamma"])),
                 _lib.fptr(_c(p["beta"])), _lib.ptr(p["y"]), _hptr(p["h"]), None if p["bits"] is None else p["bits"].data_ptr(),
                 _lib.ptr(p["pre"]), _lib.ptr(p["mean"]), _lib.ptr(p["rstd"]), p["R"], float(eps)))
-        with _dev(ref):      # one call: node, edge, node, edge inside dg_launch_pair_begin / _end
-            _lib.check(lib.dg_edge_ffn_ln_fwd_pair(ctypes.byref(cargs[0]), ctypes.byref(cargs[1]), probs[0]["C"], probs[0]["H"],
-                                                   probs[0]["code"], _lib.stream_of(ref)), "dg_edge_ffn_ln_fwd_pair")
+        with _dev(ref):
+            if fused:      # ONE launch: the node rows ride in the launch over the edge rows, the hidden tensors stay on chip
+                _lib.check(lib.dg_ffn_ln_fwd_f32(ctypes.byref(cargs[0]), ctypes.byref(cargs[1]), _lib.stream_of(ref)), "dg_ffn_ln_fwd_f32")
+            else:          # one call: node, edge, node, edge inside dg_launch_pair_begin / _end
+                _lib.check(lib.dg_edge_ffn_ln_fwd_pair(ctypes.byref(cargs[0]), ctypes.byref(cargs[1]), probs[0]["C"], probs[0]["H"],
+                                                       probs[0]["code"], _lib.stream_of(ref)), "dg_edge_ffn_ln_fwd_pair")
         es = ref.element_size()
         for p in probs:
             R, C, H = p["R"], p["C"], p["H"]
+            if fused:
+                _account_ffn_f32(R, C, H, keep)
+                continue
             hb = _hrow_bytes(p["code"], es, H)
             _account(_gemm_key(R, C, H), R * (es * C + hb), 2 * R * C * H)
             _account(_gemm_key(R, H, C), R * (hb + es * (3 if keep else 2) * C), 2 * R * C * H, floor=R * (hb + es * 2 * C))

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 231            /* 0.3.1: 0.3.0 (+ DG_DTYPE_F32_H16 .. _H32_DH16 hidden-tensor codes, dg_set_edge_rows) + dg_attn_half_f32_fwd for N <= 96 */
+#define DG_VERSION 232            /* 0.3.2: 0.3.1 + dg_ffn_ln_fwd_f32 (fused float32 feed-forward forward) */
 #define DG_DTYPE_F32  0
 #define DG_DTYPE_BF16 1
 /* float32 activations whose 384-wide feed-forward HIDDEN tensors (h = relu(fc1 x), dh, and their second-order twins:
@@ -413,6 +413,21 @@ int dg_ffn_ln_bwd_bf16(const void* x, const void* pre_ln, const float* mean, con
                        void* workspace, size_t workspace_bytes, int64_t R, dg_stream_t stream);
 
 
+/* ---- the same feed-forward half as ONE FUSED forward kernel, float32 activations (csrc/ffn_fused_f32.hip) ----
+ *   y = LayerNorm(x + fc2(relu(fc1(x)))) * gamma + beta   (src/model/layers.py:50-53, 191-192),  C = 128, H = 384,
+ * float32-class arithmetic (fp16 hi + lo planes, three MFMA products, fp32 accumulation: the arithmetic of dg_row_gemm).
+ * The [R,384] hidden tensor never reaches HBM as float32: the rows stay in registers between fc1 and fc2, both weights
+ * stream L2 -> LDS from the fragment-order copy made by dg_ffn_f32_pack (dg_ffn_f32_packed_bytes() bytes; re-pack after every
+ * update of w1 [384,128] / w2 [128,384]).  Arguments: dg_ffn_fwd_args with `w1_packed` = that copy (`w2_packed` is ignored);
+ * `h` = a DG_DTYPE_F32_H16 buffer (dg_hidden_bytes(R, 384, DG_DTYPE_F32_H16): the hi fp16 plane of h under one row scale -- all
+ * the unfused backward reads of h, dW2 = dz^T h), `relu_bits` = dg_row_gemm_mask_words(R, 128, 384, DG_DTYPE_F32) words in the
+ * layout dg_row_gemm writes (dg_edge_ffn_ln_bwd(_pair) with dtype DG_DTYPE_F32_H16 runs on the result unchanged), `pre_ln`
+ * [R,128]; h, relu_bits and pre_ln are all NULL when no backward follows.  `node` may be NULL; otherwise its (few) rows ride
+ * in the launch over `edge`'s rows (own weights, own outputs).                                                            */
+size_t dg_ffn_f32_packed_bytes(void);
+int dg_ffn_f32_pack(const float* w1, const float* w2, void* packed, dg_stream_t stream);
+int dg_ffn_ln_fwd_f32(const dg_ffn_fwd_args* node, const dg_ffn_fwd_args* edge, dg_stream_t stream);
+
 /* ---- edge embedding + symmetrisation: src/model/models.py:57-61,92-94 (Generator) and
  * :159-163,197-199 (Discriminator) ---------------------------------------------------
  *   f(z) = act(W2.act(W1.z + b1) + b2),  out[b,i,j,:] = (f(a[b,i,j,:]) + f(a[b,j,i,:])) / 2
@@ -567,6 +582,8 @@ enum {
     /* fused bf16 feed-forward over NODE-level row counts (R < DG_EDGE_ROWS): DG_K_FFN / DG_K_FFN_WGRAD hold the edge-level launches */
     DG_K_FFN_NODE = 19,
     DG_K_FFN_WGRAD_NODE = 20,
+    DG_K_FFN_F32 = 21,         /* fused float32 feed-forward forward (dg_ffn_ln_fwd_f32), edge-level launches */
+    DG_K_FFN_F32_NODE = 22,    /* ... launches without an edge-level problem */
     DG_K_COUNT = 24
 };
 int dg_prof_enable(int mask);

@@ -1058,6 +1058,88 @@ def test_fused_ffn_ln_matches_composite_all_orders(shape, hidden, monkeypatch):
         assert _rel(a, b.double().cpu()) < GT
 
 
+def _ffn_f32_case(R, seed, scale=1.0):
+    C, H = 128, 384
+    f = lambda t: t.float().cuda().requires_grad_(True)
+    return dict(x=f(_gen((R, C), seed + 1) * scale), w1=f(_gen((H, C), seed + 2) * 0.1), b1=f(_gen((H,), seed + 3)),
+                w2=f(_gen((C, H), seed + 4) * 0.1), b2=f(_gen((C,), seed + 5)), gamma=f(1 + 0.1 * _gen((C,), seed + 6)),
+                beta=f(_gen((C,), seed + 7)))
+
+
+def _ffn_f32_masks(bits, R):
+    """[R,384] bool from the mask words of dg_row_gemm's 128 -> 384 layout ([stage of 32 rows][8][64] words, bit
+    (row block * 3 + channel block) * 4 + i): csrc/row_gemm_n384.hip."""
+    st = (R + 31) // 32
+    w = bits[:st * 512].view(st, 8, 4, 16).long().cpu()          # [stage, wave, channel quad, row in block]
+    out = torch.zeros(st * 32, 384, dtype=torch.bool)
+    for rb in range(2):
+        for cb in range(3):
+            for i in range(4):
+                b = ((w >> ((rb * 3 + cb) * 4 + i)) & 1).bool()
+                ch = 48 * torch.arange(8)[:, None] + 16 * cb + 4 * torch.arange(4)[None, :] + i            # [8,4]
+                rows = 32 * torch.arange(st)[:, None] + 16 * rb + torch.arange(16)[None, :]                 # [st,16]
+                out[rows[:, None, None, :].expand(st, 8, 4, 16), ch[None, :, :, None].expand(st, 8, 4, 16)] = b
+    return out[:R]
+
+
+@pytest.mark.parametrize("R,scale", [(1, 1.0), (17, 1.0), (129, 1.0), (1000, 1.0), (4097, 1e-9), (4097, 1e9), (33000, 1.0)])
+def test_fused_float32_feed_forward_forward(R, scale):
+    """dg_ffn_ln_fwd_f32 (csrc/ffn_fused_f32.hip: the [R,384] hidden tensor stays on chip) against float64: y, the pre-LayerNorm
+    sum, the row statistics at 2e-5; the hi plane of h it leaves for the backward at the 2^-12 of one fp16 plane; the ReLU mask
+    words equal to the sign of the float64 pre-activations wherever those are not within 1e-6 of zero; the gradients of the
+    unchanged backward kernels on its outputs equal to the two-launch path's to rounding; tail tiles of every length."""
+    from druggen_amd import functional as dgf
+    C, H = 128, 384
+    c = _ffn_f32_case(R, R % 11, scale)
+    d = lambda t: t.detach().double().cpu()
+    v64 = d(c["x"]) @ d(c["w1"]).t() + d(c["b1"])
+    h64 = torch.relu(v64)
+    pre64 = d(c["x"]) + h64 @ d(c["w2"]).t() + d(c["b2"])
+    y64 = torch.nn.functional.layer_norm(pre64, (C,), d(c["gamma"]), d(c["beta"]), 1e-5)
+    dy = _gen((R, C), 99).float().cuda()
+    ins = [c[k] for k in ("x", "w1", "b1", "w2", "b2", "gamma", "beta")]
+    got = {}
+    try:
+        for fused in (True, False):
+            dgf.set_fused_ffn_f32(fused)
+            y, pre, mean, rstd = dgf._FFNLN.apply(*ins, 1e-5)
+            sv = y.grad_fn.saved_tensors
+            got[fused] = dict(y=y.detach(), pre=pre.detach(), mean=mean, rstd=rstd, h=dgf.hidden_to_float(sv[7], R, H), bits=sv[11],
+                              hbytes=sv[7].numel(), g=torch.autograd.grad(y, ins, dy))
+    finally:
+        dgf.set_fused_ffn_f32(True)
+    a = got[True]
+    assert a["hbytes"] == int(_lib().load().dg_hidden_bytes(R, H, _lib().F32_H16))      # one fp16 plane + row scales
+    assert _rel(a["y"], y64) < TOL and _rel(a["pre"], pre64) < TOL
+    assert _rel(a["mean"], pre64.mean(-1)) < TOL and _rel(a["rstd"], 1 / torch.sqrt(pre64.var(-1, unbiased=False) + 1e-5)) < TOL
+    assert _rel(a["h"], h64) < 4e-4
+    wrong = _ffn_f32_masks(a["bits"], R) != (v64 > 0)
+    assert not wrong.any() or float((v64[wrong].abs() / v64.abs().max()).max()) < 1e-6
+    for ga, gb in zip(a["g"], got[False]["g"]):
+        assert _rel(ga, gb.double().cpu()) < 5e-4      # (dh's fp16 plane is the same 2^-11 method in both)
+
+
+def test_fused_float32_feed_forward_node_rows_ride_and_launches_repeat():
+    """The two-problem form (node rows ride in the launch over the edge rows, own weights) equals the two single launches bit
+    for bit, without backward outputs too, and repeated launches are bit-identical (the kernel's counted vmcnt waits never let
+    a weight fragment be read before it landed)."""
+    from druggen_amd import functional as dgf
+    cn, ce = _ffn_f32_case(180, 3), _ffn_f32_case(16200, 4)
+    arg = lambda c: (c["w1"], c["b1"], c["w2"], c["b2"], c["gamma"], c["beta"], 1e-5)
+    xo, yo, handle = dgf.ffn_ln_pair(cn["x"], arg(cn), ce["x"], arg(ce))
+    assert handle is not None
+    yn = dgf.ffn_ln(cn["x"], *arg(cn))
+    ye = dgf.ffn_ln(ce["x"], *arg(ce))
+    assert torch.equal(xo, yn) and torch.equal(yo, ye)
+    with torch.no_grad():
+        xo2, yo2, _ = dgf.ffn_ln_pair(cn["x"], arg(cn), ce["x"], arg(ce))
+    assert torch.equal(xo2, xo) and torch.equal(yo2, yo)
+    big = _ffn_f32_case(70001, 5)
+    y0 = dgf.ffn_ln(big["x"], *arg(big)).detach().clone()
+    for _ in range(20):
+        assert torch.equal(dgf.ffn_ln(big["x"], *arg(big)), y0)
+
+
 @pytest.mark.parametrize("shape", [(2, 9, 9), (7, 45)])
 def test_fused_linear_ln_matches_composite_all_orders(shape):
     import torch.nn.functional as F

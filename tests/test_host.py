@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dg_version() == 231
+    assert lib.dg_version() == 232
     assert lib.dg_last_error_string() is not None
 
 
