@@ -521,7 +521,6 @@ extern "C" int dg_attn_core_fwd(const void* q_, const void* k_, const void* v_, 
     const int wpb = g.slices < 4 ? g.slices : 4;
     const int rows_per_wave = 3;   // measured on MI355X: 3 rows/wave (RG = N/3) beats 9 by ~8 %
     int RG = (N + rows_per_wave - 1) / rows_per_wave;
-    if (const char* env = getenv("DG_ATTN_FWD_RG")) RG = atoi(env) > 0 ? atoi(env) : RG;
     if (RG > N) RG = N;
     dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * RG, (g.slices + wpb - 1) / wpb), block(64 * wpb);
     ProfScope prof(DG_K_ATTN_FWD, stream);
@@ -558,8 +557,7 @@ extern "C" int dg_attn_core_bwd_add(const void* q_, const void* k_, const void* 
         return fail(DG_E_SHAPE, "dg_attn_core_bwd: unsupported shape B=%d N=%d C=%d", B, N, C);
     if (B == 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const int rw_env = getenv("DG_ATTN_BWD_RW") ? atoi(getenv("DG_ATTN_BWD_RW")) : 0;
-    const bool rw8 = rw_env == 8 && g.jpl <= 6;
+    const bool rw8 = false;      // (eight row-group waves per workgroup measured slower than kRW: not offered)
     dim3 grid(static_cast<unsigned>((B + 7) / 8 * 8) * g.slices), block(64 * (rw8 ? 8 : kRW));
     ProfScope prof(DG_K_ATTN_BWD, stream);
     const int reverse = take_direction(static_cast<int64_t>(B) * N * N);      // per-molecule results: any order

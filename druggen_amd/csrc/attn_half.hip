@@ -922,7 +922,7 @@ extern "C" int dg_attn_half_fwd(const void* y, const void* q, const void* k, con
     a.v = static_cast<const bf16_t*>(v); a.pk = static_cast<const bf16x8*>(packed); a.be = be; a.boe = boe;
     a.gamma = gamma4; a.beta = beta4; a.o = static_cast<bf16_t*>(o); a.y2 = static_cast<bf16_t*>(y2);
     a.pre = static_cast<bf16_t*>(pre4); a.mean = mean4; a.rstd = rstd4; a.B = B; a.N = N; a.alpha = alpha; a.eps = eps;
-    a.abl = getenv("DG_HALF_ABL") ? atoi(getenv("DG_HALF_ABL")) : 0;
+    a.abl = 0;
     const long long items = static_cast<long long>(B) * N;      // tiles
     ProfScope prof(DG_K_ATTN_HALF_FWD, stream);
 #define LAUNCH(MB_, EDGE_, PER_CU_)                                                                               \

@@ -33,6 +33,9 @@
 #include "pair.h"
 #include "traversal.h"
 
+#ifndef FF_DBG
+#define FF_DBG 0      // ablation builds (scripts/build_variant.sh): 1 no MFMAs, 2 no global stores, 4 no weight-fragment reads, 8 no weight DMA,
+#endif                // 16 no fc1 epilogue arithmetic, 32 no h split
 #ifndef FF_SAFE_WAIT
 #define FF_SAFE_WAIT 0      // 1: every chunk wait is vmcnt(0) (debug builds: rules the counted waits out)
 #endif
@@ -44,6 +47,18 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FF_AUX
+#define FF_AUX 0      // cache-policy bits of the result stores (gfx950 buffer stores: 1 sc0, 2 nt, 16 sc1)
+#endif
+#define FF_STORE128(...) ff_store128(__VA_ARGS__)
+#define FF_STORE32(...) ff_store32(__VA_ARGS__)
+
+__device__ __forceinline__ void ff_store128(u32x4 data, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int imm, int) {
+    if (!(FF_DBG & 2)) __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voff, imm, FF_AUX);
+}
+__device__ __forceinline__ void ff_store32(unsigned data, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int imm, int) {
+    if (!(FF_DBG & 2)) __builtin_amdgcn_raw_buffer_store_b32(data, rsrc, voff, imm, FF_AUX);
+}
 
 constexpr int kTile = 128;                       // rows per workgroup pass (16 per wave)
 constexpr int kWaves = 8;
@@ -62,9 +77,18 @@ static_assert(kLds <= 160 * 1024, "LDS budget");
 // a result is fenced: see row_gemm_k384.hip (a renamed destination one slot behind its producer read a partly written
 // accumulator on gfx950).
 __device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    if (FF_DBG & 1) {
+        asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
+        return;
+    }
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma16_first(f32x4& acc, const f16x8& a, const f16x8& b) {
+    if (FF_DBG & 1) {
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
+        return;
+    }
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
@@ -189,6 +213,7 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
     auto dma_chunk = [&](int c, int b) {
         c = c >= 20 ? c - 20 : c;
         const int per = c < 12 ? 2 : 3;
+        if (FF_DBG & 8) return;
         // (uniform: the wave's first fragment of the chunk; the following ones are instruction offsets)
         const char* src = (c < 12 ? packed + c * kW1Chunk : packed + kW1Bytes + (c - 12) * kW2Chunk) + w * per * 1024;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w + static_cast<unsigned>(b * kW2Chunk + w * per * 1024));
@@ -245,24 +270,56 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
 
-    // younger VMEM instructions per wave behind the DMA of chunk c at the point where chunk c is waited for.  Issue order of a
-    // pass: iteration c = wait, barrier, DMA of chunk c + 2 (2 instructions for an fc1 chunk, 3 for an fc2 chunk), [c == 12: mask
-    // words, SB], [c >= 12: fragment c - 12 of the next tile's rows, 1], compute, [c == 11: h plane + scale, S1], [c == 19: y,
-    // pre, statistics, S2].  VMEM operations of a wave retire in order (vmcnt(N) = all but the youngest N are done).
-    constexpr int S1 = KEEP ? 13 : 0, SB = KEEP ? 1 : 0, S2 = KEEP ? 18 : 10;
-    auto younger = [&](int c) {
-        if (c == 0) return 1 + 2 + 1 + S2;      // rows 6, DMA(1), rows 7, S2
-        if (c == 1) return 1 + S2 + 2;          // rows 7, S2, DMA(2)
-        if (c <= 10) return 2;                  // DMA(c + 1), an fc1 chunk
-        if (c == 11) return 3;                  // DMA(12)
-        if (c == 12) return 3 + S1;             // DMA(13), S1
-        if (c == 13) return S1 + 3 + SB + 1;    // S1, DMA(14), mask words, rows 0
-        if (c == 14) return SB + 1 + 3 + 1;     // mask words, rows 0, DMA(15), rows 1
-        if (c <= 18) return 1 + 3 + 1;          // rows, DMA(c + 1), rows
-        return 1 + 2 + 1;                       // c == 19: rows 5, DMA(0) of the next pass, rows 6
+    // Counted waits.  VMEM operations of a wave retire in order (vmcnt(N) = all but the youngest N are done), stores included: a
+    // weight chunk requested behind a burst of stores is not confirmed before the burst is acknowledged.  The first version
+    // issued the h plane (13 stores) and y / pre / statistics (18) in two bursts per pass and ran 436 us, 306 us with the stores
+    // compiled out and the same 445 us with every wait a vmcnt(0): the store drain was ADDED to the compute time.  So the stores are
+    // spread: the results of pass t leave during the fc1 iterations 0..7 of pass t + 1 (two per iteration; z, the mean and rstd
+    // stay in registers across the pass boundary), the h plane during the fc2 iterations (one or two per iteration).
+    // Issue order of iteration c of a pass: wait for chunk c, barrier, DMA of chunk c + 2 (2 instructions for an fc1 chunk, 3 for
+    // an fc2 chunk), then post(c) further VMEM instructions, compute.  Behind the DMA of chunk c (issued first in iteration c - 2)
+    // and in front of its wait there are post(c - 2) + the DMA of chunk c + 1 + post(c - 1).
+    constexpr bool ST = !(FF_DBG & 2);
+    auto post = [&](int c) {      // VMEM instructions of iteration c behind its weight DMA
+        c = (c + 20) % 20;
+        if (c < 8) return ST ? (KEEP ? 2 : 1) + (c == 0 ? 2 : 0) : 0;      // pre + y of a 16-byte column pair (+ mean, rstd)
+        if (c < 12) return 0;
+        const int ob = c - 12;
+        return 1 + (ST && KEEP ? (ob < 4 ? 2 : 1) + (ob == 0 ? 2 : 0) : 0);      // rows fragment; h plane (+ scale, mask words)
     };
+    auto younger = [&](int c) { return post(c - 2) + ((c + 1) % 20 < 12 ? 2 : 3) + post(c - 1); };
 
     int gb = 0;      // buffer of the chunk about to be consumed (uniform)
+    // results of the previous pass that have not left yet: z = pre-LayerNorm sum (32 values per lane), its row statistics, the
+    // rows they belong to (0 rows before the first pass: every store is dropped by its descriptor's range, the counts stay)
+    float z[4][8] = {};
+    float mu_p = 0.f, rstd_p = 0.f;
+    int64_t r0_p = 0;
+    int rows_p = 0;
+    const unsigned yoff = static_cast<unsigned>(n) * 512u + static_cast<unsigned>(kq) * 32u;
+    const unsigned soff = kq == 0 ? static_cast<unsigned>(n) * 4u : 0x7FFFFFF0u;      // one lane per row writes the statistics
+    // (lane (n, kq) holds channels 32 p + 8 kq + 4 half .. + 3 of row n.  The W2 channel order 16 half + 4 kq -- 64 contiguous,
+    // aligned bytes per row and store instruction instead of every second 16-byte piece of the line -- was measured SLOWER:
+    // 460 vs 428 us at R = 518 400.)
+    auto store_results = [&](int i) {      // 16-byte column group i (p = i >> 1, half = i & 1) of the previous pass's rows
+        const int p = i >> 1, hf = i & 1;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0_p * 128, 0, rows_p * 512, 0x00020000);
+        if (KEEP) {
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pre + r0_p * 128, 0, rows_p * 512, 0x00020000);
+            FF_STORE128(u32x4{__float_as_uint(z[p][4 * hf]), __float_as_uint(z[p][4 * hf + 1]), __float_as_uint(z[p][4 * hf + 2]),
+                              __float_as_uint(z[p][4 * hf + 3])}, rp, yoff, p * 128 + hf * 16, 0);
+        }
+        const float4 g = ld4(tab + 1024 + 32 * p + 8 * kq + 4 * hf), e = ld4(tab + 1152 + 32 * p + 8 * kq + 4 * hf);
+        const u32x4 o = {__float_as_uint(fmaf((z[p][4 * hf] - mu_p) * rstd_p, g.x, e.x)), __float_as_uint(fmaf((z[p][4 * hf + 1] - mu_p) * rstd_p, g.y, e.y)),
+                         __float_as_uint(fmaf((z[p][4 * hf + 2] - mu_p) * rstd_p, g.z, e.z)), __float_as_uint(fmaf((z[p][4 * hf + 3] - mu_p) * rstd_p, g.w, e.w))};
+        FF_STORE128(o, ry, yoff, p * 128 + hf * 16, 0);
+        if (i == 0) {
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(gmean + r0_p, 0, rows_p * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(grstd + r0_p, 0, rows_p * 4, 0x00020000);
+            FF_STORE32(__float_as_uint(mu_p), rm, soff, 0, 0);
+            FF_STORE32(__float_as_uint(rstd_p), rr, soff, 0, 0);
+        }
+    };
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         const int64_t tile = tile_of(t);
@@ -272,7 +329,7 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
 
         // ---- x rows: LDS -> registers, row maximum, hi / lo planes (the float32 rows stay in the LDS region: fc2 reads its
         // residual operand from there, fragment by fragment, and refills each fragment with the next tile's)
-        vm_wait(FF_SAFE_WAIT ? 0 : S2);      // the last fragment was requested in iteration 19, in front of the S2 stores
+        vm_wait(FF_SAFE_WAIT ? 0 : post(19) - 1);      // the last fragment was requested in iteration 19, in front of its h-plane store
         float xa[4][8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
@@ -294,67 +351,37 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) split8(xa[ks], scale_of(ex), xh[ks], xl[ks]);
 
-        // ---- fc1: h = relu(x W1^T + b1), 12 pairs of 16-channel blocks; lane (n, kq) ends with channels 32 j + 8 kq .. + 7
+        // ---- fc1: h = relu(x W1^T + b1), 12 pairs of 16-channel blocks; lane (n, kq) ends with channels 32 j + 8 kq .. + 7.
+        // The epilogue of pair j - 1 (scales, bias, ReLU, mask bits: ~25 vector instructions per element quarter) is issued in
+        // four pieces BETWEEN the MFMA groups of pair j: the matrix pipe runs them for free, and the first piece covers the LDS
+        // round trip of the pair's first fragments.  Two accumulators per block (even / odd k-steps, terms smallest first) in
+        // two sets that alternate from pair to pair.
         float hv[12][8];
         const int rb = w & 1, stg = w >> 1;      // row block / stage of this wave's rows in the mask layout (32-row stages)
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            vm_wait(FF_SAFE_WAIT ? 0 : younger(j));
-            wg_barrier();
-            dma_chunk(j + 2, gb >= 1 ? gb - 1 : 2);      // buffer (gb + 2) % 3
-            const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
-            f32x4 pa[3], pb[3];
-            // fragments one k-step ahead of their MFMAs (scheduling fences: hipcc otherwise requests all 16 at once, 64 VGPRs)
-            f16x8 fr[2][4];
-            auto read_frags = [&](int ks, f16x8 (&d)[4]) {
-                d[0] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 0) * 1024);            // block A hi, lo
-                d[1] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 1) * 1024);
-                d[2] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 0) * 1024);      // block B hi, lo
-                d[3] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 1) * 1024);
-            };
-            read_frags(0, fr[0]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) read_frags(ks + 1, fr[(ks + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const f16x8 &wha = fr[ks & 1][0], &wla = fr[ks & 1][1], &whb = fr[ks & 1][2], &wlb = fr[ks & 1][3];
-                if (ks == 0) {
-                    mfma16_first(pa[0], wla, xh[0]);
-                    mfma16_first(pb[0], wlb, xh[0]);
-                    mfma16_first(pa[1], wha, xl[0]);
-                    mfma16_first(pb[1], whb, xl[0]);
-                    mfma16_first(pa[2], wha, xh[0]);
-                    mfma16_first(pb[2], whb, xh[0]);
-                } else {
-                    mfma16(pa[0], wla, xh[ks]);
-                    mfma16(pb[0], wlb, xh[ks]);
-                    mfma16(pa[1], wha, xl[ks]);
-                    mfma16(pb[1], whb, xl[ks]);
-                    mfma16(pa[2], wha, xh[ks]);
-                    mfma16(pb[2], whb, xh[ks]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            gb = gb == 2 ? 0 : gb + 1;
-            // epilogue: scales, bias, ReLU, mask bits
-            const float4 ca = ld4(tab + 32 * j + 8 * kq), cb = ld4(tab + 32 * j + 8 * kq + 4);
-            const float4 ba = ld4(tab + 384 + 32 * j + 8 * kq), bb = ld4(tab + 384 + 32 * j + 8 * kq + 4);
-            mfma_results_ready();
-            const float cav[4] = {ca.x, ca.y, ca.z, ca.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
-            const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-            unsigned ma = 0, mb = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float va = fmaf((pa[0][i] + pa[1][i]) + pa[2][i], inv_sx * cav[i], bav[i]);
-                const float vb = fmaf((pb[0][i] + pb[1][i]) + pb[2][i], inv_sx * cbv[i], bbv[i]);
-                if (KEEP) {
-                    ma |= va > 0.f ? (1u << i) : 0u;
-                    mb |= vb > 0.f ? (1u << i) : 0u;
-                }
-                hv[j][i] = fmaxf(va, 0.f);
-                hv[j][4 + i] = fmaxf(vb, 0.f);
-            }
+        f32x4 acc1[2][4];                        // [set][A even, A odd, B even, B odd]
+        float4 tca, tcb, tba, tbb;               // inverse column scales and bias of the pair whose epilogue is pending
+        unsigned ma = 0, mb = 0;
+        auto fc1_tables = [&](int j) {
+            tca = ld4(tab + 32 * j + 8 * kq);
+            tcb = ld4(tab + 32 * j + 8 * kq + 4);
+            tba = ld4(tab + 384 + 32 * j + 8 * kq);
+            tbb = ld4(tab + 384 + 32 * j + 8 * kq + 4);
+        };
+        auto fc1_epilogue = [&](int j, int i) {      // element quarter i of pair j (accumulator set j & 1)
+            const f32x4(&a)[4] = acc1[j & 1];
+            if (i == 0) asm volatile("s_nop 7" ::: "memory");      // (MFMA results of the pair -> first vector read: far away already)
+            const float ca = i == 0 ? tca.x : i == 1 ? tca.y : i == 2 ? tca.z : tca.w, cb = i == 0 ? tcb.x : i == 1 ? tcb.y : i == 2 ? tcb.z : tcb.w;
+            const float ba = i == 0 ? tba.x : i == 1 ? tba.y : i == 2 ? tba.z : tba.w, bb = i == 0 ? tbb.x : i == 1 ? tbb.y : i == 2 ? tbb.z : tbb.w;
+            const float va = fmaf(a[0][i] + a[1][i], inv_sx * ca, ba);
+            const float vb = fmaf(a[2][i] + a[3][i], inv_sx * cb, bb);
             if (KEEP) {
+                if (i == 0) ma = mb = 0;
+                ma |= va > 0.f ? (1u << i) : 0u;
+                mb |= vb > 0.f ? (1u << i) : 0u;
+            }
+            hv[j][i] = fmaxf(va, 0.f);
+            hv[j][4 + i] = fmaxf(vb, 0.f);
+            if (KEEP && i == 3) {
                 // channel c = 32 j + 8 kq + 4 blk + i of row 16 rb + n of the stage: word (c / 48, lane' = ((c % 16) / 4) * 16 + n),
                 // bit (rb * 3 + (c % 48) / 16) * 4 + i  (row_gemm_n384.hip)
                 const int b16 = 2 * j + (kq >> 1);            // 16-channel block of the lane's eight channels
@@ -364,7 +391,51 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                 atomicOr(word, ma << sh);
                 atomicOr(word + 16, mb << sh);
             }
+        };
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            vm_wait(FF_SAFE_WAIT ? 0 : younger(j));
+            wg_barrier();
+            dma_chunk(j + 2, gb >= 1 ? gb - 1 : 2);      // buffer (gb + 2) % 3
+            if (j < 8) store_results(j);                 // the previous pass's results, two stores per iteration
+            const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
+            // fragments one k-step ahead of their MFMAs (scheduling fences: hipcc otherwise requests all 16 at once, 64 VGPRs)
+            f16x8 fr[2][4];
+            auto read_frags = [&](int ks, f16x8 (&d)[4]) {
+                d[0] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 0) * 1024);            // block A hi, lo
+                d[1] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 1) * 1024);
+                d[2] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 0) * 1024);      // block B hi, lo
+                d[3] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 1) * 1024);
+            };
+            read_frags(0, fr[0]);
+            f32x4(&a)[4] = acc1[j & 1];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) read_frags(ks + 1, fr[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j > 0) fc1_epilogue(j - 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 &wha = fr[ks & 1][0], &wla = fr[ks & 1][1], &whb = fr[ks & 1][2], &wlb = fr[ks & 1][3];
+                f32x4 &ca = a[ks & 1], &cb = a[2 + (ks & 1)];
+                if (ks < 2) {
+                    mfma16_first(ca, wla, xh[ks]);
+                    mfma16_first(cb, wlb, xh[ks]);
+                } else {
+                    mfma16(ca, wla, xh[ks]);
+                    mfma16(cb, wlb, xh[ks]);
+                }
+                mfma16(ca, wha, xl[ks]);
+                mfma16(cb, whb, xl[ks]);
+                mfma16(ca, wha, xh[ks]);
+                mfma16(cb, whb, xh[ks]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gb = gb == 2 ? 0 : gb + 1;
+            fc1_tables(j);      // (read behind the last quarter of pair j - 1, used from the next iteration on)
         }
+        mfma_results_ready();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fc1_epilogue(11, i);
 
         // ---- h: ONE scale per row over all 384 channels, hi / lo planes; the hi plane leaves for the backward
         float mh = 0.f;
@@ -378,17 +449,22 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         f16x8 hh[12], hl[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) split8(hv[j], scale_of(eh), hh[j], hl[j]);
-        if (KEEP) {
-            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hplane + r0 * 384, 0, rows * 768, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hscale + r0, 0, rows * 4, 0x00020000);
-            const unsigned voff = static_cast<unsigned>(n) * 768u + static_cast<unsigned>(kq) * 16u;
-#pragma unroll
-            for (int j = 0; j < 12; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh[j]), rh, voff, j * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(inv_sh), rs, kq == 0 ? static_cast<unsigned>(n) * 4u : 0x7FFFFFF0u, 0, 0);
-        }
 
-        // ---- fc2: z = x + h W2^T + b2, 8 blocks of 16 output channels; lane (n, kq) ends with channels 32 p + 8 kq .. + 7
-        float z[4][8];
+        // ---- fc2: z = x + h W2^T + b2, 8 blocks of 16 output channels; lane (n, kq) ends with channels 32 p + 8 kq .. + 7.
+        // Three accumulation chains per block (w_lo.h_hi, w_hi.h_lo, w_hi.h_hi) in two alternating sets; the epilogue of block
+        // ob - 1 rides behind the second MFMA group of block ob.
+        f32x4 acc2[2][3];
+        float4 xres[2], tcs, tbs;
+        auto fc2_epilogue = [&](int ob) {
+            const int p = ob >> 1, blk = ob & 1;
+            const f32x4(&q)[3] = acc2[ob & 1];
+            const float4 xr = xres[ob & 1];
+            const float csv[4] = {tcs.x, tcs.y, tcs.z, tcs.w}, bsv[4] = {tbs.x, tbs.y, tbs.z, tbs.w};
+            const float xrv[4] = {xr.x, xr.y, xr.z, xr.w};
+            asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[p][4 * blk + i] = fmaf((q[0][i] + q[1][i]) + q[2][i], inv_sh * csv[i], bsv[i]) + xrv[i];
+        };
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
             vm_wait(FF_SAFE_WAIT ? 0 : younger(12 + ob));
@@ -403,15 +479,29 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                 u32x4* const src = reinterpret_cast<u32x4*>(smem + kOffBits + threadIdx.x * 16);
                 const u32x4 v = *src;
                 *src = u32x4{0u, 0u, 0u, 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(v, rbits, static_cast<unsigned>(threadIdx.x) * 16u, 0, 0);
+                FF_STORE128(v, rbits, static_cast<unsigned>(threadIdx.x) * 16u, 0, 0);
             }
             // residual operand: fragment ob of this tile's rows (channels 32 p + 8 kq + 4 blk .. of row n); its slot is refilled
             // with the same fragment of the next tile
-            const float4 xres = *reinterpret_cast<const float4*>(smem + kOffX + w * 8192 + ob * 1024 + lane * 16);
+            xres[ob & 1] = *reinterpret_cast<const float4*>(smem + kOffX + w * 8192 + ob * 1024 + lane * 16);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             dma_x(tile_of(t + 1), ob);
+            if (KEEP) {      // the hi plane of h for the backward: twelve 16-byte stores, one or two per iteration (+ the row scale)
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hplane + r0 * 384, 0, rows * 768, 0x00020000);
+                const unsigned voff = static_cast<unsigned>(n) * 768u + static_cast<unsigned>(kq) * 16u;
+                if (ob < 4) {
+                    FF_STORE128(__builtin_bit_cast(u32x4, hh[2 * ob]), rh, voff, (2 * ob) * 64, 0);
+                    FF_STORE128(__builtin_bit_cast(u32x4, hh[2 * ob + 1]), rh, voff, (2 * ob + 1) * 64, 0);
+                } else {
+                    FF_STORE128(__builtin_bit_cast(u32x4, hh[4 + ob]), rh, voff, (4 + ob) * 64, 0);
+                }
+                if (ob == 0) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hscale + r0, 0, rows * 4, 0x00020000);
+                    FF_STORE32(__float_as_uint(inv_sh), rs, soff, 0, 0);
+                }
+            }
             const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
-            f32x4 q0, q1, q2;
+            f32x4(&q)[3] = acc2[ob & 1];
             f16x8 fr[3][2];
             auto read_frags = [&](int j, f16x8 (&d)[2]) {
                 d[0] = *reinterpret_cast<const f16x8*>(wb + (j * 2 + 0) * 1024);
@@ -423,29 +513,29 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             for (int j = 0; j < 12; ++j) {
                 if (j < 10) read_frags(j + 2, fr[(j + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (j == 1 && ob > 0) fc2_epilogue(ob - 1);
+                __builtin_amdgcn_sched_barrier(0);
                 const f16x8 &wh = fr[j % 3][0], &wl = fr[j % 3][1];
                 if (j == 0) {
-                    mfma16_first(q0, wl, hh[0]);
-                    mfma16_first(q1, wh, hl[0]);
-                    mfma16_first(q2, wh, hh[0]);
+                    mfma16_first(q[0], wl, hh[0]);
+                    mfma16_first(q[1], wh, hl[0]);
+                    mfma16_first(q[2], wh, hh[0]);
                 } else {
-                    mfma16(q0, wl, hh[j]);
-                    mfma16(q1, wh, hl[j]);
-                    mfma16(q2, wh, hh[j]);
+                    mfma16(q[0], wl, hh[j]);
+                    mfma16(q[1], wh, hl[j]);
+                    mfma16(q[2], wh, hh[j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             gb = gb == 2 ? 0 : gb + 1;
             const int p = ob >> 1, blk = ob & 1;
-            const float4 cs = ld4(tab + 768 + 32 * p + 8 * kq + 4 * blk), bs = ld4(tab + 896 + 32 * p + 8 * kq + 4 * blk);
-            mfma_results_ready();
-            const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
-            const float xrv[4] = {xres.x, xres.y, xres.z, xres.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) z[p][4 * blk + i] = fmaf((q0[i] + q1[i]) + q2[i], inv_sh * csv[i], bsv[i]) + xrv[i];
+            tcs = ld4(tab + 768 + 32 * p + 8 * kq + 4 * blk);
+            tbs = ld4(tab + 896 + 32 * p + 8 * kq + 4 * blk);
         }
+        mfma_results_ready();
+        fc2_epilogue(7);
 
-        // ---- LayerNorm over the row (32 values per lane, four lanes per row) and the stores
+        // ---- LayerNorm statistics of the row (32 values per lane, four lanes per row); y leaves during the next pass
         float s1 = 0.f;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -460,38 +550,14 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                 const float d = z[p][i] - mu;
                 s2 = fmaf(d, d, s2);
             }
-        const float rstd = rsqrtf(xor_sum<16>(s2) * (1.0f / 128.0f) + eps);
-        {
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0 * 128, 0, rows * 512, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(KEEP ? pre + r0 * 128 : y, 0, KEEP ? rows * 512 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(gmean + r0, 0, rows * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(grstd + r0, 0, rows * 4, 0x00020000);
-            const unsigned voff = static_cast<unsigned>(n) * 512u + static_cast<unsigned>(kq) * 32u;
-            const unsigned soff = kq == 0 ? static_cast<unsigned>(n) * 4u : 0x7FFFFFF0u;
-            if (KEEP) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(z[p][0]), __float_as_uint(z[p][1]), __float_as_uint(z[p][2]),
-                                                                 __float_as_uint(z[p][3])}, rp, voff, p * 128, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(z[p][4]), __float_as_uint(z[p][5]), __float_as_uint(z[p][6]),
-                                                                 __float_as_uint(z[p][7])}, rp, voff, p * 128 + 16, 0);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float4 g0 = ld4(tab + 1024 + 32 * p + 8 * kq), g1 = ld4(tab + 1024 + 32 * p + 8 * kq + 4);
-                const float4 e0 = ld4(tab + 1152 + 32 * p + 8 * kq), e1 = ld4(tab + 1152 + 32 * p + 8 * kq + 4);
-                const u32x4 o0 = {__float_as_uint(fmaf((z[p][0] - mu) * rstd, g0.x, e0.x)), __float_as_uint(fmaf((z[p][1] - mu) * rstd, g0.y, e0.y)),
-                                  __float_as_uint(fmaf((z[p][2] - mu) * rstd, g0.z, e0.z)), __float_as_uint(fmaf((z[p][3] - mu) * rstd, g0.w, e0.w))};
-                const u32x4 o1 = {__float_as_uint(fmaf((z[p][4] - mu) * rstd, g1.x, e1.x)), __float_as_uint(fmaf((z[p][5] - mu) * rstd, g1.y, e1.y)),
-                                  __float_as_uint(fmaf((z[p][6] - mu) * rstd, g1.z, e1.z)), __float_as_uint(fmaf((z[p][7] - mu) * rstd, g1.w, e1.w))};
-                __builtin_amdgcn_raw_buffer_store_b128(o0, ry, voff, p * 128, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o1, ry, voff, p * 128 + 16, 0);
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rm, soff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), rr, soff, 0, 0);
-        }
+        rstd_p = rsqrtf(xor_sum<16>(s2) * (1.0f / 128.0f) + eps);
+        mu_p = mu;
+        r0_p = r0;
+        rows_p = rows;
     }
+    // the last pass's results
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store_results(i);
     // the DMAs issued for a pass that does not come must land before the LDS is handed to the next workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -360,7 +360,7 @@ bool ln_geometry(int C, LnGeom* g) {
 int ln_grid(int64_t R, int G) {
     const int64_t rpb = kBlock / G;
     int64_t passes = (R + rpb - 1) / rpb;
-    static const int64_t cap = getenv("DG_LN_GRID_CAP") ? atoll(getenv("DG_LN_GRID_CAP")) : 1024;  // ~4 blocks per CU (fewer dgamma/dbeta partials to finish), grid-stride beyond
+    const int64_t cap = 1024;  // ~4 blocks per CU (fewer dgamma/dbeta partials to finish), grid-stride beyond
     return static_cast<int>(passes < cap ? (passes < 1 ? 1 : passes) : cap);
 }
 

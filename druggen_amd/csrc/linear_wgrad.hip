@@ -640,7 +640,7 @@ bool wgrad_plan(int N, int K, WgradPlan* p) {
     struct Row {
         int nt, kt, wn, wk, tr;
     };
-    static const bool big = getenv("DG_WGRAD_BIG_TILES") && atoi(getenv("DG_WGRAD_BIG_TILES"));
+    constexpr bool big = false;
     static const Row table[] = {
         {4, 4, 2, 2, big ? 64 : 32},   // 128 x 128   (q,k,v,e,out_e,out_n)
         {12, 4, 4, 2, big ? 32 : 16},  // 384 x 128   (fc1: dW[3C, C])
@@ -810,21 +810,14 @@ extern "C" int dg_linear_wgrad(const void* dy_, const void* dy_mask_, const void
     if (workspace_bytes < dg_linear_wgrad_workspace_bytes(R, N, K))
         return fail(DG_E_WORKSPACE, "dg_linear_wgrad: workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // fp32 operands: fp16 hi + lo with running column scales by default; DG_WGRAD=x6 / mfma32 select the bf16x6 split
-    // or the plain fp32 MFMA (A/B measurements, tests)
-    static const int split = [] {
-        const char* e = getenv("DG_WGRAD");
-        return (e && strcmp(e, "mfma32") == 0) ? 0 : (e && strcmp(e, "x6") == 0) ? 1 : 2;
-    }();
-    // fp32, fp16 hi + lo arithmetic, the three encoder shapes: producer / consumer kernel (wgrad_stream.hip), every
-    // element converted once per workgroup.  DG_WGRAD=sym keeps the symmetric kernel below (A/B measurements).
-    static const bool stream_kernel = [] {
-        const char* e = getenv("DG_WGRAD");
-        return !(e && strcmp(e, "sym") == 0);
-    }();
+    // fp32 operands: fp16 hi + lo with running column scales (the bf16x6 split and the plain fp32 MFMA of rounds 1 - 2 are no
+    // longer selectable); the three encoder shapes run on the producer / consumer kernel (wgrad_stream.hip), every element
+    // converted once per workgroup, the other shapes on the symmetric kernel below
+    constexpr int split = 2;
+    constexpr bool stream_kernel = true;
     const bool use_stream = !bf && split == 2 && stream_kernel && !dy_mask_ && wgrad_stream_supported(N, K);
     if (hfmt && !use_stream)
-        return fail(DG_E_ARG, "dg_linear_wgrad: DG_DTYPE_F32_H16 / _H24 needs the producer / consumer weight-gradient kernel (DG_WGRAD selects another)");
+        return fail(DG_E_ARG, "dg_linear_wgrad: DG_DTYPE_F32_H16 / _H24 needs one of the producer / consumer weight-gradient shapes");
     int tpb;
     const bool may_wait = g_batch_on && g_batch_n < 8;      // (a launch may only wait for a carrier when its reduce is deferred too)
     const int S = use_stream ? wgrad_stream_blocks(R, N, K, may_wait)

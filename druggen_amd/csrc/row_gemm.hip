@@ -1602,17 +1602,14 @@ __global__ __launch_bounds__(512, 2) void row_gemm_h3_k384_kernel(const float* _
 
 namespace dg {
 
-// DG_ROW_GEMM=mfma32 selects the v_mfma_f32_32x32x2_f32 kernels (A/B comparisons); default: bf16x6.
-static bool use_x6() {
-    static const bool on = !(getenv("DG_ROW_GEMM") && strcmp(getenv("DG_ROW_GEMM"), "mfma32") == 0);
-    return on;
-}
+// The float32 row GEMMs run the fp16 hi + lo arithmetic (three MFMA products); the v_mfma_f32_32x32x2_f32 kernels of round 1
+// are no longer launched.
+static constexpr bool use_x6() { return true; }
 
 size_t row_gemm_f32_packed_floats(int n_out, int k_contract) {
     if (n_out < 1 || k_contract < 1) return 0;
     const size_t nt = (n_out + 31) / 32, kc = (k_contract + 127) / 128;
-    if (use_x6()) return nt * kc * 8 * 2 * 64 * 4 + nt * 32;   // fp16x3: [slab][k-step][plane][lane] x 8 fp16, inv_col_scale
-    return nt * kc * 16 * 64 * 4;
+    return nt * kc * 8 * 2 * 64 * 4 + nt * 32;   // fp16x3: [slab][k-step][plane][lane] x 8 fp16, inv_col_scale
 }
 
 int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mode, dg_stream_t stream_,
@@ -1623,14 +1620,8 @@ int row_gemm_f32_pack(const float* w, float* packed, int rows, int cols, int mod
     if (mode != 0 && mode != 1) return fail(DG_E_ARG, "dg_row_gemm_pack: mode must be 0 (forward) or 1 (dgrad)");
     const int n_out = mode == 0 ? rows : cols, k = mode == 0 ? cols : rows;
     const int nt = (n_out + 31) / 32, kc = (k + 127) / 128;
-    if (use_x6()) {
-        hipLaunchKernelGGL(pack_weight_h3_kernel, dim3(nt, kc), dim3(512), 0, static_cast<hipStream_t>(stream_), w, w1, w2,
-                           reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt);
-        return check_launch("dg_row_gemm_pack");
-    }
-    const int total = nt * kc * 16 * 64;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), w,
-                       packed, rows, cols, mode, nt, kc);
+    hipLaunchKernelGGL(pack_weight_h3_kernel, dim3(nt, kc), dim3(512), 0, static_cast<hipStream_t>(stream_), w, w1, w2,
+                       reinterpret_cast<f16x8*>(packed), rows, cols, mode, nt);
     return check_launch("dg_row_gemm_pack");
 }
 
@@ -1687,77 +1678,26 @@ int row_gemm_f32(const float* a, const float* packed, float* y, int64_t R, int K
         hipLaunchKernelGGL((row_gemm_h3_kernel<KC_, NG_, EX_>), dim3(seqs), dim3(512), lds_, stream, a,            \
                            reinterpret_cast<const f16x8*>(packed), y, R, ep);                                      \
     }
-        static const bool split_n = !(getenv("DG_GEMM_N384") && strcmp(getenv("DG_GEMM_N384"), "stream") == 0);
-        // default: producer / consumer kernel (row_gemm_n384.hip); DG_GEMM_N384=resident | stream select the round-2/3
-        // kernels (A/B measurements).  The three write their ReLU bit masks in layouts of their own: a process uses one.
-        static const bool pc_n = !getenv("DG_GEMM_N384") || strcmp(getenv("DG_GEMM_N384"), "pc") == 0;
-        if (K == 128 && N == 384 && pc_n) {
+        // 128 -> 384: the producer / consumer kernel (row_gemm_n384.hip)
+        if (K == 128 && N == 384) {
             if (int st = launch_row_gemm_n384(a, packed, y, yscale, R, bias, relu, relu_bits_out, mask_bits, stream, yfmt, ylo)) return st;
             return check_launch("dg_row_gemm");
         }
-        // 384 -> 128: producer / consumer kernel (row_gemm_k384.hip) by default; DG_GEMM_K384=paired selects the round-2/3
-        // kernel (two tiles per B set, epilogue in the mover waves) for A/B measurements
-        static const bool pc_k = !getenv("DG_GEMM_K384") || strcmp(getenv("DG_GEMM_K384"), "pc") == 0;
-        if (K == 384 && pc_k) {
+        // 384 -> 128: the producer / consumer kernel (row_gemm_k384.hip)
+        if (K == 384) {
             if (int st = launch_row_gemm_k384(a, ascale, packed, y, R, bias, relu, residual, gamma, beta, mean, rstd, pre_ln, eps, stream, afmt, alo))
                 return st;
             return check_launch("dg_row_gemm");
         }
-        if (afmt || yfmt)
-            return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 / _H24 needs the producer / consumer 384-wide kernels (DG_GEMM_N384 / DG_GEMM_K384 select older ones)");
-        if (K == 128 && N == 384 && split_n) {   // B resident in six consumer waves (two slabs each)
-            constexpr int lds6 = kH3Lds + 6 * 32 * 32 * 4;
-            DG_OPT_IN_LDS((&row_gemm_h3_kernel<1, 1, false, 6>), lds6);
-            hipLaunchKernelGGL((row_gemm_h3_kernel<1, 1, false, 6>), dim3(seqs), dim3(512), lds6, stream, a,
-                               reinterpret_cast<const f16x8*>(packed), y, R, ep);
-        } else if (K == 128 && N == 384) LAUNCH6(1, 3, false)
-        else if (K == 128 && exch) {
+        if (K == 128 && exch) {
             ep.reverse = take_direction(R);
             LAUNCH6(1, 1, true)
-        } else if (K == 128 && !(mask_bits || relu_bits_out) && getenv("DG_GEMM_PLAIN_EXCH")) LAUNCH6(1, 1, true)
-        else if (K == 128) {
+        } else {
             ep.reverse = take_direction(R);
             LAUNCH6(1, 1, false)
         }
-        else {
-            constexpr int lds384 = 2 * kH3Buf + kTR * 128 * 4;
-            DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<true>), lds384);
-            DG_OPT_IN_LDS((&row_gemm_h3_k384_kernel<false>), lds384);
-            if (exch)
-                hipLaunchKernelGGL(row_gemm_h3_k384_kernel<true>, dim3(seqs), dim3(512), lds384, stream, a,
-                                   reinterpret_cast<const f16x8*>(packed), y, R, ep);
-            else
-                hipLaunchKernelGGL(row_gemm_h3_k384_kernel<false>, dim3(seqs), dim3(512), lds384, stream, a,
-                                   reinterpret_cast<const f16x8*>(packed), y, R, ep);
-        }
 #undef LAUNCH6
-        return check_launch("dg_row_gemm");
     }
-    if (afmt || yfmt) return fail(DG_E_ARG, "dg_row_gemm: DG_DTYPE_F32_H16 / _H24 needs the fp16 hi + lo row GEMMs (DG_ROW_GEMM=mfma32 is set)");
-#define LAUNCH(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_) LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, false)
-#define LAUNCHX(KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, PER_CU_, XP_)                                               \
-    {                                                                                                              \
-        constexpr int lds_bytes = 2 * TR_ * KC_ * 128 * 4 + (XP_ ? TR_ * 128 * 4 : 0);                             \
-        DG_OPT_IN_LDS((&row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>), lds_bytes);                                                \
-        const int64_t tiles = (R + TR_ - 1) / TR_;                                                                 \
-        const int grid = static_cast<int>(tiles < 256 * PER_CU_ ? tiles : 256 * PER_CU_);                          \
-        hipLaunchKernelGGL((row_gemm_kernel<KC_, NG_, MG_, TR_, EX_, PIPE_, MINW_, XP_>), dim3(grid),              \
-                           dim3(NG_ * MG_ * 256), lds_bytes, stream, a, packed, y, R, ep);                         \
-    }
-    static const int variant = getenv("DG_GEMM_VARIANT") ? atoi(getenv("DG_GEMM_VARIANT")) : 0;
-    if (K == 128 && N == 128) {
-        if (exch) LAUNCH(1, 1, 1, 64, true, false, 1, 2)
-        else if (variant == 1) LAUNCH(1, 1, 2, 64, false, false, 4, 2)   /* 8 waves, 4 waves/SIMD */
-        else LAUNCH(1, 1, 1, 64, false, true, 1, 2)
-    } else if (K == 128 && N == 384) {
-        LAUNCH(1, 3, 1, 32, false, true, 1, 1)
-    } else {
-        if (!exch) LAUNCH(3, 1, 1, 32, false, true, 1, 1)             /* plain: pipelined direct stores */
-        else if (variant == 2) LAUNCH(3, 1, 1, 32, true, false, 1, 1)  /* unpipelined exchange (A/B testing) */
-        else LAUNCHX(3, 1, 1, 32, true, false, 1, 1, true)
-    }
-#undef LAUNCH
-#undef LAUNCHX
     return check_launch("dg_row_gemm");
 }
 

@@ -513,7 +513,7 @@ int launch(const Prob& p0, const Prob* p1, hipStream_t stream) {
                            p1 ? *p1 : p0, nb0);                                                                          \
     }
     // DG_DH_PRODUCTS=3: full three-product arithmetic for the backward's fp16-plane results too, =1: a single product (A/B, tests)
-    const int dh_products = getenv("DG_DH_PRODUCTS") ? atoi(getenv("DG_DH_PRODUCTS")) : 2;      // (read per launch: tests switch it)
+    const int dh_products = 2;
     if (p0.yfmt == 1) {
         if (mode == 1) DG_N384_LAUNCH(1, 1)
         else if (mode == 2 && dh_products == 2) {

@@ -91,12 +91,8 @@ static thread_local int g_pair_depth = 0;      // dg_launch_pair_begin / _end ne
 bool pair_mode() { return g_pair_depth > 0; }
 
 static thread_local int g_last_dir = 1;      // (the first edge-level launch ascends)
-static bool alternate_traversal() {
-    static const bool on = !(getenv("DG_TRAVERSAL") && strcmp(getenv("DG_TRAVERSAL"), "forward") == 0);
-    return on;
-}
 int take_direction(int64_t R) {
-    if (R < edge_rows() || !alternate_traversal()) return 0;
+    if (R < edge_rows()) return 0;
     g_last_dir = !g_last_dir;
     return g_last_dir;
 }

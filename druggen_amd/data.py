@@ -17,23 +17,38 @@ from .functional import _dev, attach_one_hot_labels
 __all__ = ["dense_one_hot_adjacency", "load_molecules", "label2onehot", "raise_deferred_checks"]
 
 
-_pending_checks = []      # (bad-label counter on the device, b_dim, recorded event) of batches densified with check="deferred"
+_pending_checks = []      # (pinned host counter, b_dim, event on the side stream) of batches densified with check="deferred"
+_side_streams = {}        # device index -> the stream that carries the counters' device -> host copies
+
+
+def _side_stream(dev):
+    st = _side_streams.get(dev.index)
+    if st is None:
+        st = _side_streams[dev.index] = torch.cuda.Stream(dev)
+    return st
 
 
 def raise_deferred_checks(wait: bool = False) -> None:
-    """Raise for batches densified with ``check="deferred"`` whose bond labels were out of range.  Only counters whose kernel
-    has already finished are read (``wait=True``: all of them): no stall of the launch queue."""
-    keep = []
-    for bad, b_dim, ev in _pending_checks:
-        if not wait and not ev.query():
-            keep.append((bad, b_dim, ev))
+    """Raise for batches densified with ``check="deferred"`` whose bond labels were out of range.  The counters were copied to
+    pinned host memory on a side stream behind their kernel; only copies that have already FINISHED are looked at
+    (``wait=True``: all of them, after waiting for their events) -- the compute stream is never touched, nothing is enqueued
+    and nothing is synchronised."""
+    keep, bad_batches = [], []
+    for host, b_dim, ev in _pending_checks:
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            keep.append((host, b_dim, ev))
             continue
-        n_bad = int(bad.item())
+        n_bad = int(host[0])      # a plain host read: the copy behind `ev` has completed
         if n_bad:
-            _pending_checks[:] = []
-            raise RuntimeError(f"{n_bad} adjacency entries of an EARLIER batch had a bond label outside [0, {b_dim}) "
-                               f"(densified with check='deferred': their rows were embedded as class 0)")
-    _pending_checks[:] = keep
+            bad_batches.append((n_bad, b_dim))
+    _pending_checks[:] = keep      # (finished counters are dropped, pending ones stay -- also when this call raises)
+    if bad_batches:
+        n_bad, b_dim = bad_batches[0]
+        more = f" (and {len(bad_batches) - 1} more such batches)" if len(bad_batches) > 1 else ""
+        raise RuntimeError(f"{n_bad} adjacency entries of an EARLIER batch had a bond label outside [0, {b_dim}){more} "
+                           f"(densified with check='deferred': those labels were clamped into [0, {b_dim - 1}] for the embedding)")
 
 
 def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: int, b_dim: int, check=True):
@@ -65,10 +80,20 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
                                   b_dim, labels.data_ptr(), a.data_ptr(), bad.data_ptr(), _lib.stream_of(a)),
                    "dg_densify")
     if check == "deferred":
-        raise_deferred_checks()      # counters of earlier batches that are complete by now
-        ev = torch.cuda.Event()
-        ev.record()
-        _pending_checks.append((bad, b_dim, ev))
+        raise_deferred_checks()      # counters of earlier batches whose host copies are complete by now
+        # counter -> pinned host memory on a SIDE stream that waits for the densify kernel: the compute stream sees one event
+        # record, and the host reads the value only after the copy's own event has completed
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        side = _side_stream(dev)
+        side.wait_event(done)
+        with torch.cuda.stream(side):
+            host.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        bad.record_stream(side)
+        _pending_checks.append((host, b_dim, ev))
         labels.clamp_(0, b_dim - 1)
         attach_one_hot_labels(a, labels)
     elif check:

@@ -20,6 +20,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
+from .options import options
 
 __all__ = ["attach_one_hot_labels", "attn_core", "ln_residual", "linear", "linear_relu", "linear_ln", "ffn_ln", "attn_block", "embed_sym", "inputs_only_backward",
            "second_order_forward", "in_second_order_forward", "readout", "traffic_reset", "traffic_bytes", "traffic_flops", "traffic_floor_bytes",
@@ -89,39 +90,33 @@ def _c(t):
 # --------------------------------------------------------------------------
 # storage of the [R,384] hidden tensors of the float32 feed-forward (DG_DTYPE_F32_H16, include/druggen_hip.h)
 # --------------------------------------------------------------------------
-def _env_default(name: str, *defaults) -> bool:
-    return os.environ.get(name) in (None, *defaults)
-
-
 _HIDDEN_MODES = ("f32", "dh16", "dh24", "f24", "f16")
 
 
 def hidden_storage() -> str:
-    """Storage of the [R,384] hidden tensors of the float32 feed-forward (DG_HIDDEN):
-      "f32"   plain float32 (also whenever an A/B switch selects a kernel older than the producer / consumer ones);
-      "dh16"  the BACKWARD's hidden tensors -- dh = (dz W2) * m and its second-order twin -- as ONE fp16 plane per row under an
-              exact power-of-two row scale (DG_DTYPE_F32_H16), the forward's h = relu(fc1 x) in float32;
-      "dh24"  the same tensors as the top 24 bits of every float32 (DG_DTYPE_F32_H24);
+    """Storage of the [R,384] hidden tensors of the float32 feed-forward (``options.hidden``, DG_HIDDEN at import):
+      "f32"   plain float32;
+      "dh16"  (default) the BACKWARD's hidden tensors -- dh = (dz W2) * m and its second-order twin -- as ONE fp16 plane per row
+              under an exact power-of-two row scale (DG_DTYPE_F32_H16); the forward's h = relu(fc1 x) stays float32 class: on chip
+              in the fused forward (dg_ffn_ln_fwd_f32), pre-split hi + lo planes in the two-launch forward (DG_DTYPE_F32_H32);
+      "dh24"  the backward's tensors as the top 24 bits of every float32 (DG_DTYPE_F32_H24), h float32;
       "f24" / "f16"   h as well.  Rounding h perturbs the forward pass, and a perturbed forward flips ReLU masks in the layers
               behind it: gradient errors of the order of the SQUARE ROOT of the perturbation on small batches (two-molecule
               goldens: 1.4e-3 - 4e-3 with f24's 2^-17, up to 1.5e-2 with f16's 2^-11) -- outside the 1e-3 parity bar, labelled
               modes like the bf16 configuration.  dh only travels through linear maps: its rounding stays a rounding."""
-    mode = os.environ.get("DG_HIDDEN", "dh16")
-    if mode not in _HIDDEN_MODES or mode == "f32":
-        return "f32"
-    if not (_env_default("DG_ROW_GEMM") and _env_default("DG_GEMM_N384", "pc") and _env_default("DG_GEMM_K384", "pc")
-            and _env_default("DG_WGRAD", "h3")):
-        return "f32"
-    return mode
+    return options.hidden
+
+
+def set_hidden_storage(mode: str) -> None:
+    """``options.hidden = mode`` (one of f32, dh16, dh24, f24, f16)."""
+    options.hidden = mode
 
 
 def hidden_forward_storage() -> str:
-    """Storage of the FORWARD's h = relu(fc1 x) in the default mode (DG_HIDDEN=dh16): "split" -- the float32-class hi / lo fp16
-    split under one row scale, done once by the launch that writes h (DG_DTYPE_F32_H32: fc2's launch only moves the planes, the
-    weight gradient dW2 = dz^T h reads the hi plane alone) -- or "f32" (DG_HIDDEN_FWD=f32; always with the other modes)."""
-    if hidden_storage() == "dh16" and os.environ.get("DG_HIDDEN_FWD", "split") != "f32":
-        return "split"
-    return "f32"
+    """Storage of the FORWARD's h = relu(fc1 x) when it goes through HBM in the default mode: "split" -- the float32-class
+    hi / lo fp16 split under one row scale, done once by the launch that writes h (DG_DTYPE_F32_H32: fc2's launch only moves the
+    planes, the weight gradient dW2 = dz^T h reads the hi plane alone) -- or "f32" (every other mode)."""
+    return "split" if hidden_storage() == "dh16" else "f32"
 
 
 def _hidden_code(adt) -> int:
@@ -500,7 +495,7 @@ def _reduce_batch(ref, on=True):
     """dg_linear_wgrad_batch_begin / _end around a block's backward: the fixed-order reductions of its weight gradients
     (``_wgrad_many(..., open_batch=False)``) and of its LayerNorms' dgamma / dbeta (``_ln_bwd_rows(batch_slot=i)``) run
     as ONE launch at the end (at most 8 of them; further ones reduce at once)."""
-    if not (on and ref.is_cuda and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"):
+    if not (on and ref.is_cuda):
         yield False
         return
     lib = _lib.load()
@@ -560,7 +555,7 @@ def _wgrad_many(items, open_batch=True, pair_from=None):
     if any(isinstance(dy, tuple) for dy, _, _ in items):      # a (dq, dk, dv) triple: one stacked [384,128] gradient
         return _wgrad_many_mixed(items, open_batch, pair_from)
     dims = [_wgrad_dims(dy, x) for dy, x, _ in items]
-    ok = (ref.is_cuda and len(items) <= 8 and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
+    ok = (ref.is_cuda and len(items) <= 8
           and all((dy.dtype == x.dtype or _is_h16(dy) or _is_h16(x)) and d[1] > 16 and d[2] > 16 for (dy, x, _), d in zip(items, dims)))
     needs = [int(lib.dg_linear_wgrad_workspace_bytes(*d)) for d in dims] if ok else []
     if not ok or any(n == 0 for n in needs):
@@ -602,8 +597,7 @@ def _wgrad_many_mixed(items, open_batch=True, pair_from=None):
     out = []
     with _dev(ref):
         ws = _scratch(ref, total, "wgrad_batch")
-        batch = open_batch and os.environ.get("DG_WGRAD_REDUCE", "batch") == "batch"
-        with _reduce_batch(ref, on=batch), contextlib.ExitStack() as pairing:
+        with _reduce_batch(ref, on=open_batch), contextlib.ExitStack() as pairing:
             for i, ((dy, x, b), off, n) in enumerate(zip(items, offs, needs)):
                 if i == pair_from:
                     pairing.enter_context(_pair_launches(ref))
@@ -879,8 +873,7 @@ class _NodeEmbedBwd(Function):
 def node_embed_supported(z, l1, l2, act_name) -> bool:
     return (z.is_cuda and z.dtype == torch.float32 and act_name in _HEAD_ACTS and 1 <= z.shape[-1] <= 16
             and tuple(l1.weight.shape) == (64, z.shape[-1]) and tuple(l2.weight.shape) == (128, 64)
-            and l1.bias is not None and l2.bias is not None and l1.weight.dtype == torch.float32
-            and os.environ.get("DG_NODE_EMBED", "fused") != "off")
+            and l1.bias is not None and l2.bias is not None and l1.weight.dtype == torch.float32)
 
 
 def node_embed(z, l1, l2, act_name):
@@ -979,8 +972,7 @@ def head_tail_supported(z1, layers, act_name) -> bool:
     """``layers`` = the three Linears after the head's first one."""
     return (z1.is_cuda and z1.dtype == torch.float32 and z1.dim() == 2 and act_name in _HEAD_ACTS
             and [tuple(l.weight.shape) for l in layers] == [(32, 64), (16, 32), (1, 16)]
-            and all(l.bias is not None and l.weight.dtype == torch.float32 for l in layers)
-            and os.environ.get("DG_HEAD_TAIL", "fused") != "off")
+            and all(l.bias is not None and l.weight.dtype == torch.float32 for l in layers))
 
 
 def head_tail(z1, layers, act_name):
@@ -992,7 +984,7 @@ def head_tail(z1, layers, act_name):
 def readout(x, weight, bias=None):
     """float32 ``F.linear(x.float(), weight, bias)`` for the Generator's readouts (dim 128 -> edge / node classes)."""
     ok = (x.is_cuda and x.dtype in _lib.DTYPES and weight.dim() == 2 and weight.shape[1] == 128 and 1 <= weight.shape[0] <= 16
-          and weight.dtype == torch.float32 and os.environ.get("DG_READOUT", "skinny") != "library")
+          and weight.dtype == torch.float32)
     if not ok:
         return linear(x.float(), weight, bias)
     return _Readout.apply(x, weight, bias)
@@ -1069,7 +1061,7 @@ def _join_alias_grads(own, extra):
 
 
 def _alias_outputs_enabled() -> bool:
-    return os.environ.get("DG_PENALTY_WGRAD", "joined") != "engine"
+    return options.penalty_wgrad == "joined"
 
 
 def packed_weight(w, mode: int, dtype=torch.float32):
@@ -1132,9 +1124,8 @@ def packed_weight3(w0, w1, w2, mode: int):
 def lin3_supported(x2, ws) -> bool:
     """Three Linear(128,128) per launch (dg_row_gemm_lin3 / _sum3, dg_linear_wgrad3): float32 rows on the fp16 hi + lo
     kernels.  DG_QKV=separate keeps three launches (A/B measurements)."""
-    return (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[-1] == 128 and _h3_row_gemm()
-            and all(tuple(w.shape) == (128, 128) and w.dtype == torch.float32 for w in ws)
-            and os.environ.get("DG_QKV", "fused") != "separate")
+    return (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[-1] == 128
+            and all(tuple(w.shape) == (128, 128) and w.dtype == torch.float32 for w in ws))
 
 
 def lin3(x2, ws, bs):
@@ -1187,8 +1178,6 @@ def repack_params(params) -> int:
     of packs refreshed."""
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return 0      # the device table is built with a host -> device copy
-    if os.environ.get("DG_PACK", "batch") != "batch" or not _h3_row_gemm():
-        return 0      # (DG_ROW_GEMM=mfma32: dg_row_gemm_pack_batch packs the fp16 hi + lo layout only)
     ids = {id(p) for p in params}
     total = 0
     for dtype in (torch.float32, torch.bfloat16):
@@ -1355,16 +1344,9 @@ def _ln_bwd_rows(pre, gamma, mean, rstd, dy2, dz_add=None, want_affine=True, bat
     return dz, dgamma, dbeta
 
 
-def _h3_row_gemm() -> bool:
-    """False under DG_ROW_GEMM=mfma32 (A/B switch: fp32-MFMA row GEMMs): the entry points that exist only for the fp16
-    hi + lo kernels (batched packs, LayerNorm-backward epilogue / prologue) are then not offered."""
-    return os.environ.get("DG_ROW_GEMM") != "mfma32"
-
-
 def row_gemm_ln_bwd_supported(a2, K: int) -> bool:
-    """dg_row_gemm_ln_bwd serves float32 rows, K = N = 128 (DG_LN_BWD_EPILOGUE=off: A/B measurements)."""
-    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and _h3_row_gemm()
-            and os.environ.get("DG_LN_BWD_EPILOGUE", "on") != "off")
+    """dg_row_gemm_ln_bwd serves float32 rows, K = N = 128 (options.ln_bwd_epilogue: the equivalence tests' hook)."""
+    return a2.is_cuda and a2.dtype == torch.float32 and K == 128 and options.ln_bwd_epilogue
 
 
 def row_gemm_ln_bwd(a2, packed, K, residual, pre, gamma, mean, rstd):
@@ -1386,9 +1368,8 @@ def row_gemm_ln_bwd(a2, packed, K, residual, pre, gamma, mean, rstd):
 
 
 def ln_bwd_row_gemm_supported(a2, K: int, N: int) -> bool:
-    """dg_row_gemm_ln_bwd_in serves float32 rows, K = N = 128 (DG_LN_BWD_PROLOGUE=off: A/B measurements)."""
-    return (a2.is_cuda and a2.dtype == torch.float32 and K == 128 and N == 128 and _h3_row_gemm()
-            and os.environ.get("DG_LN_BWD_PROLOGUE", "on") != "off")
+    """dg_row_gemm_ln_bwd_in serves float32 rows, K = N = 128 (options.ln_bwd_prologue: the equivalence tests' hook)."""
+    return a2.is_cuda and a2.dtype == torch.float32 and K == 128 and N == 128 and options.ln_bwd_prologue
 
 
 def ln_bwd_row_gemm(pre, gamma, mean, rstd, dy2, packed, want_affine=True, batch_slot=None):
@@ -1430,9 +1411,8 @@ def _ln_bwd2_rows(pre, gamma, mean, rstd, dy2, tz):
 
 
 def _fused_ffn_enabled() -> bool:
-    """DG_FFN_BF16=unfused keeps the bf16 feed-forward on the two-launch row-GEMM path (A/B measurements)."""
-    import os
-    return os.environ.get("DG_FFN_BF16", "fused") != "unfused"
+    """options.ffn_bf16 = "unfused" keeps the bf16 feed-forward on the two-launch row-GEMM path (A/B measurements)."""
+    return options.ffn_bf16 == "fused"
 
 
 def _composite_ffn_ln(x, w1, b1, w2, b2, gamma, beta, eps):
@@ -1465,22 +1445,18 @@ def _ffn_packed_f32(w1, w2):
     return packed
 
 
-_fused_ffn_f32 = os.environ.get("DG_FFN_F32", "fused") != "unfused"
-
-
 def set_fused_ffn_f32(on: bool) -> None:
     """Route the float32 feed-forward FORWARD through the fused kernel (dg_ffn_ln_fwd_f32: the [R,384] hidden tensor stays on
-    chip; default) or through the two row-GEMM launches (A/B measurements, DG_FFN_F32=unfused at import)."""
-    global _fused_ffn_f32
-    _fused_ffn_f32 = bool(on)
+    chip; default) or through the two row-GEMM launches (``options.ffn_f32``; DG_FFN_F32=unfused at import)."""
+    options.ffn_f32 = "fused" if on else "unfused"
 
 
 def fused_ffn_f32_supported(x2, w1, w2) -> bool:
     """dg_ffn_ln_fwd_f32 serves float32 rows, dim 128, hidden 384, in the default hidden-storage mode: what it leaves for the
     backward is the hi fp16 plane of h (a DG_DTYPE_F32_H16 buffer) -- exactly what the default mode's backward reads of the
     pre-split h (dW2 = dz^T h_hi)."""
-    return (_fused_ffn_f32 and x2.is_cuda and x2.dtype == torch.float32 and tuple(w1.shape) == (384, 128)
-            and tuple(w2.shape) == (128, 384) and hidden_storage() == "dh16" and hidden_forward_storage() == "split")
+    return (options.ffn_f32 == "fused" and x2.is_cuda and x2.dtype == torch.float32 and tuple(w1.shape) == (384, 128)
+            and tuple(w2.shape) == (128, 384) and hidden_storage() == "dh16")
 
 
 def _ffn_f32_fwd_args(p, keep):
@@ -1661,8 +1637,8 @@ class _FFNLNBwd(Function):
 
 
 def _ffn_pair_enabled() -> bool:
-    """DG_FFN_PAIR=off: the node and the edge feed-forward of a block as two autograd nodes (A/B measurements)."""
-    return os.environ.get("DG_FFN_PAIR", "on") != "off"
+    """options.ffn_pair = False: the node and the edge feed-forward of a block as two autograd nodes (equivalence tests)."""
+    return options.ffn_pair
 
 
 class _FFNLNPair(Function):
@@ -2098,19 +2074,18 @@ def _composite_attn_block(x1, y, wq, bq, wk, bk, wv, bv, we, be, woe, boe, won, 
 def attn_half_f32_supported(yf, N: int, C: int) -> bool:
     """dg_attn_half_f32_fwd (e projection + attention core + out_e + residual + ln4 as one float32 launch) serves C = 128 and
     row groups of at most 96 neighbours (above 48: two stages per row group, online softmax across them);
-    DG_ATTN_HALF_F32=off keeps the three launches, =n48 keeps them above 48 neighbours (A/B measurements)."""
-    mode = os.environ.get("DG_ATTN_HALF_F32", "fused")
-    return (yf.is_cuda and yf.dtype == torch.float32 and C == 128 and N <= (48 if mode == "n48" else 96) and _h3_row_gemm()
-            and mode != "off")
+    options.attn_half_f32 = "off" keeps the three launches, "n48" keeps them above 48 neighbours (A/B measurements)."""
+    mode = options.attn_half_f32
+    return yf.is_cuda and yf.dtype == torch.float32 and C == 128 and N <= (48 if mode == "n48" else 96) and mode != "off"
 
 
 def attn_half_f32_bwd1_supported(dy2f, B: int, N: int, C: int, graph: bool = False) -> bool:
     """dg_attn_half_f32_bwd1 (ln4 backward + out_e input gradient + attention-core backward as one float32 launch) serves
     C = 128 and row groups of at most 48 neighbours; its workgroups walk whole molecules, so it needs a batch that fills the
-    chip (B >= 128; DG_ATTN_HALF_F32_BWD=force lifts that for tests, =off keeps the two launches, =nograph keeps them only
-    for passes a second order differentiates)."""
-    mode = os.environ.get("DG_ATTN_HALF_F32_BWD", "fused")
-    return (dy2f.is_cuda and dy2f.dtype == torch.float32 and C == 128 and N <= 48 and _h3_row_gemm() and mode != "off"
+    chip (B >= 128; options.attn_half_f32_bwd = "force" lifts that for tests, "off" keeps the two launches, "nograph" keeps
+    them only for passes a second order differentiates)."""
+    mode = options.attn_half_f32_bwd
+    return (dy2f.is_cuda and dy2f.dtype == torch.float32 and C == 128 and N <= 48 and mode != "off"
             and (B >= 128 or mode == "force") and (not graph or mode != "nograph"))
 
 
@@ -2346,7 +2321,7 @@ class _AttnBlockBwd(Function):
         # fp32: the adjoint of e joins de inside the kernel (one read stream instead of a 3-pass add).  The bf16
         # variant of that kernel is latency-bound at 2 waves / SIMD and the extra operand set costs more than the add
         # it saves (configs[2], A/B on one box: 217.2 vs 213.7 ms per step): bf16 adds afterwards.
-        fold = ae is not None and adt == torch.float32 and os.environ.get("DG_ATTN_ADD", "kernel") != "post"
+        fold = ae is not None and adt == torch.float32
         aef = _c(cast(ae)).view(B, N, N, C) if fold else None      # joins de inside the kernel
         dq, dk, dv, de = fused1 if fused1 is not None else _attn_bwd_launch(qv, kv, vv, ev, ds, do, alpha, add_e=aef)
         pairs = [(got, extra.view(got.shape)) for got, extra in ((dq, aq), (dk, ak), (dv, av)) if extra is not None]
@@ -2481,15 +2456,15 @@ def _attn_half_packed(we, woe, dtype):
 
 
 def _fused_attn_half_enabled() -> bool:
-    """DG_ATTN_HALF=unfused keeps the attention half on the separate launches (A/B measurements)."""
-    return os.environ.get("DG_ATTN_HALF", "fused") != "unfused"
+    """options.attn_half = "unfused" keeps the bf16 attention half on the separate launches (A/B measurements)."""
+    return options.attn_half != "unfused"
 
 
 def attn_half_supported(dtype, N: int, C: int) -> bool:
     """Shapes the module path routes to the fused attention-half kernels.  The kernels accept N <= 96, but above 48 the
     backward keeps 6 row blocks of accumulators per lane and spills (N = 90, B = 64: 633 vs 645 molecules/s for the
-    separate launches), so BASELINE configs[4] stays on those; DG_ATTN_HALF=force routes every N <= 96 (tests)."""
-    limit = 96 if os.environ.get("DG_ATTN_HALF") == "force" else 48
+    separate launches), so BASELINE configs[4] stays on those; options.attn_half = "force" routes every N <= 96 (tests)."""
+    limit = 96 if options.attn_half == "force" else 48
     return dtype == torch.bfloat16 and C == 128 and 1 <= N <= limit
 
 
@@ -2760,7 +2735,7 @@ def _embed_bwd_launch(a, w1, b1, w2, b2, g, act, out_dtype, need_da, need_w):
     da = torch.empty_like(a) if need_da else None
     dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
     if (out_dtype == torch.bfloat16 and act in _PIECEWISE_LINEAR and E <= 8 and N <= 48
-            and os.environ.get("DG_EMBED_BF16", "fast") != "general"):
+            and options.embed_bf16 == "fast"):
         # bf16 gradients, relu / leaky: row-block streaming kernel (csrc/embed_bf16.hip)
         need = int(lib.dg_embed_sym_bwd_bf16_workspace_bytes(B, N))
         with _dev(a):

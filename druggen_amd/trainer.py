@@ -28,6 +28,7 @@ import torch.distributed as dist
 from . import _lib
 from .model.loss import discriminator_loss, generator_loss
 from .functional import as_one_hot, attach_one_hot_labels, bump_weights_epoch, one_hot_labels
+from .options import options
 from .optim import FlatAdamW
 
 __all__ = ["GANStep", "GraphedGANStep", "GradBucket", "broadcast_parameters"]
@@ -99,8 +100,12 @@ class GANStep:
     def __init__(self, G: torch.nn.Module, D: torch.nn.Module, *, g_lr: float = 1e-5, d_lr: float = 1e-5,
                  betas: Sequence[float] = (0.9, 0.999), lambda_gp: float = 10.0, group=None,
                  skip_d_wgrad_in_g_step: bool = True, d_loss_fn=discriminator_loss, g_loss_fn=generator_loss,
-                 optimizer: str = "auto", share_generator_forward: bool = True, memory: str = "auto"):
+                 optimizer: str = "auto", share_generator_forward: bool = True, memory: str = "auto",
+                 split_d_backward: bool = True):
         self.G, self.D = G, D
+        # the critic terms and the penalty are differentiated by two backward passes joined by ONE multi-tensor add (False: the
+        # reference's single backward over their sum, for users of per-parameter hooks on D)
+        self.split_d_backward = split_d_backward
         self.lambda_gp = lambda_gp
         self.group = group
         on_gpu = next(G.parameters()).is_cuda
@@ -181,7 +186,7 @@ class GANStep:
             return False
         if self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0:
             return False
-        mode = os.environ.get("DG_LOW_MEMORY_SHARE", "auto")
+        mode = options.low_memory_share
         if mode != "auto":
             return mode == "on"
         from .functional import activation_dtype
@@ -190,7 +195,9 @@ class GANStep:
         es = 2 if activation_dtype() == torch.bfloat16 else 4
         unit = 9.0 * B * N * N * dim * es
         estimate = unit * (2 * int(getattr(self.D, "depth", 1)) + int(getattr(self.G, "depth", 1)))
-        return estimate <= 0.85 * torch.cuda.get_device_properties(gen_edge.device).total_memory
+        # (0.75: the estimate is rough -- B = 2048, N = 45, L = 4 in fp32 measures 230 GB against an estimate of 229 -- and a
+        # fragmented allocator or a slightly larger N must fall back to the second generator forward, not run out of memory)
+        return estimate <= 0.75 * torch.cuda.get_device_properties(gen_edge.device).total_memory
 
     def _d_step_low_memory(self, disc_edge, disc_node, gen_edge, gen_node, B, dev, eps, samples=None):
         """discriminator_loss (reference loss.py:52-72) + backward, one term at a time."""
@@ -247,10 +254,19 @@ class GANStep:
     def step(self, disc_edge, disc_node, gen_edge, gen_node, eps=None):
         """One iteration on this rank's shard.  Returns (d_loss, g_loss) as
         0-dim device tensors (local-shard values; no host sync)."""
+        # edge-level = at least half of this shard's B N^2 edge rows (profiler keys, traversal direction, the LayerNorm-backward
+        # prologue's level test): a large batch's node-level launches (B = 2048: 92 160 / 184 320 rows) must not be filed with
+        # the edge-level ones.  Scoped to the step: the previous threshold comes back when it returns (a later, smaller
+        # forward / backward in the same process is classified by ITS caller again).
+        prev_rows = _lib.edge_rows()
+        _lib.set_edge_rows(max(_lib.EDGE_ROWS, gen_node.shape[0] * gen_node.shape[1] ** 2 // 2))
+        try:
+            return self._step(disc_edge, disc_node, gen_edge, gen_node, eps)
+        finally:
+            _lib.set_edge_rows(prev_rows)
+
+    def _step(self, disc_edge, disc_node, gen_edge, gen_node, eps=None):
         B, dev = gen_node.shape[0], gen_node.device
-        # edge-level = at least half of this shard's B N^2 edge rows (profiler keys, traversal direction): a large batch's
-        # node-level launches (B = 2048: 92 160 / 184 320 rows) must not be filed with the edge-level ones
-        _lib.set_edge_rows(max(_lib.EDGE_ROWS, B * gen_node.shape[1] ** 2 // 2))
         # dataset graphs are one-hot (reference utils.py:15-23): checked once per tensor object, then the edge
         # embedding of these two batches is a table gather instead of an MLP over B N^2 rows
         gen_edge, disc_edge = as_one_hot(gen_edge), as_one_hot(disc_edge)
@@ -269,7 +285,7 @@ class GANStep:
                 and not (self.G.training and float(getattr(self.G, "dropout", 0.0) or 0.0) > 0.0)):
             shared = self.G(gen_edge, gen_node)
             kw["generator_outputs"] = shared
-        if not low and self._d_loss_fn is discriminator_loss and os.environ.get("DG_D_BACKWARD", "split") == "split":
+        if not low and self._d_loss_fn is discriminator_loss and self.split_d_backward:
             # The critic terms and the penalty share nothing but D's parameters.  One backward over their sum makes the
             # autograd engine add the two contributions of every parameter with a kernel of its own (~140 tiny adds per
             # step); two backward passes and ONE multi-tensor add give the same sums in the same order.
@@ -278,7 +294,7 @@ class GANStep:
             main.backward()
             params = [p for p in self.D.parameters() if p.requires_grad]
             # (torch.autograd.grad: tensor / post-accumulate-grad hooks on D's parameters fire for `main` only, not for
-            # the penalty term; DG_D_BACKWARD=joint runs the reference's single backward for hook users)
+            # the penalty term; GANStep(split_d_backward=False) runs the reference's single backward for hook users)
             g2 = torch.autograd.grad(pen, params, allow_unused=True)
             have, add = [], []
             for p, g in zip(params, g2):

@@ -6,8 +6,9 @@ numpy restatements of
     algorithm is restated: index = (batch[src], src - ptr[batch[src]],
     dst - ptr[batch[dst]]), values scatter-ADDed) followed by the reference's
     ``label2onehot`` (``src/data/utils.py:15-23``) as called from
-    ``load_molecules`` (``src/data/utils.py:128-142``)  -- "parity unpinned": no
-    reference-owned vectors exist for it;
+    ``load_molecules`` (``src/data/utils.py:128-142``).  The reference owns no vectors
+    for it; pinned to PyG's own published ones -- the "Examples" of the
+    ``to_dense_adj`` docstring -- in ``tests/test_host.py``;
   * ``torch.optim.AdamW`` single-tensor update (reference ``train.py:213-214``);
   * ``torch.max(x, -1)[1]`` (reference ``inference.py:197-198``).
 """

@@ -32,3 +32,23 @@ def _default_edge_rows():
         from druggen_amd import _lib
         _lib.set_edge_rows(0)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _default_options():
+    """Every test starts from, and leaves, the shipped options (druggen_amd/options.py): a test that switches one (the
+    equivalence tests of a fused launch against the launches it replaces) cannot leak into the next."""
+    from druggen_amd.options import options
+    before = options.as_dict()
+    yield
+    options.set(**before)
+
+
+@pytest.fixture
+def hidden_mode():
+    """``hidden_mode("f32")``: options.hidden for the rest of the test (restored by the fixture above)."""
+    from druggen_amd.options import options
+
+    def set_mode(mode):
+        options.hidden = mode
+    return set_mode

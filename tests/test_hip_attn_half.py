@@ -199,18 +199,13 @@ def test_fused_attn_block_node_against_float32_module(B, N, need_edge):
     lib = _lib()
     lib.prof_enable(True, kernels=["attn_half_fwd", "attn_half_bwd"])
     lib.prof_reset()
-    os.environ["DG_ATTN_HALF"] = "force"       # N = 90 is not routed to the fused kernels by default (functional.py)
-    try:
+    from druggen_amd.options import options
+    with options.override(attn_half="force"):       # N = 90 is not routed to the fused kernels by default (functional.py)
         fused = run(x1, y, gouts)
-    finally:
-        del os.environ["DG_ATTN_HALF"]
     assert lib.prof_read("attn_half_fwd")[0] == 1 and lib.prof_read("attn_half_bwd")[0] == 1      # the fused kernels ran
     lib.prof_enable(False)
-    os.environ["DG_ATTN_HALF"] = "unfused"
-    try:
+    with options.override(attn_half="unfused"):
         unfused = run(x1, y, gouts)
-    finally:
-        del os.environ["DG_ATTN_HALF"]
     truth = run(x1.detach().float().requires_grad_(True), y.detach().float().requires_grad_(True), [g.float() for g in gouts])
     for f_, u_, t_ in zip(fused, unfused, truth):
         ef, eu = _rel(f_.detach(), t_.detach()), _rel(u_.detach(), t_.detach())

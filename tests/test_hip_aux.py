@@ -38,6 +38,20 @@ def test_densify_matches_to_dense_adj_plus_onehot(B, N, E):
     assert np.array_equal(xt.cpu().numpy(), x_ref) and np.array_equal(graphs.cpu().numpy(), g_ref)
 
 
+def test_densify_reproduces_pyg_docstring_examples():
+    """dg_densify on the vectors of PyG's own to_dense_adj docstring (tests/test_host.py: PYG_*; batches padded to N = 2 nodes
+    per graph are the ones the loader produces): the dense labels, incl. the edge that leaves its graph, then one-hot."""
+    from druggen_amd import data
+    import test_host as th
+    ei = torch.tensor(th.PYG_EDGE_INDEX, device="cuda")
+    for attr, want in ((torch.ones(5, dtype=torch.long), th.PYG_DENSE), (torch.tensor(th.PYG_EDGE_ATTR), th.PYG_DENSE_ATTR)):
+        a = data.dense_one_hot_adjacency(ei, attr.cuda(), 2, 2, 6)
+        assert a.shape == (2, 2, 2, 6) and bool((a.sum(-1) == 1).all())
+        assert a.argmax(-1).cpu().tolist() == want
+        from druggen_amd.functional import one_hot_labels
+        assert one_hot_labels(a).cpu().tolist() == want      # the labels the loader attaches for the table-gather embedding
+
+
 def test_densify_edge_cases():
     from druggen_amd import data
     # no edges at all -> every entry is class 0
@@ -79,6 +93,17 @@ def test_densify_deferred_check_never_syncs_and_raises_later():
     with pytest.raises(RuntimeError, match="EARLIER batch"):
         data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3, check="deferred")
     data.raise_deferred_checks(wait=True)      # the queue is clean again
+    # the polling must not read the counter on the compute stream (a .item() there waits for everything queued before
+    # it, i.e. the previous training step).  With ~0.1 s of work queued in front, a deferred densify AND a poll return while
+    # that work is still running.
+    torch.cuda._sleep(int(2e8))
+    marker = torch.cuda.Event()
+    marker.record()
+    data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3, check="deferred")
+    data.raise_deferred_checks()
+    assert not marker.query(), "the deferred check synchronised with the compute stream"
+    torch.cuda.synchronize()
+    data.raise_deferred_checks(wait=True)
 
 
 def test_loader_attaches_labels_and_the_model_takes_the_table_path_without_a_sync():

@@ -195,11 +195,9 @@ def test_embed_sym_bf16_output_matches_fp32_kernel():
     for x16, x32 in zip(g16, g32):
         # bf16 configuration: the streaming kernel (csrc/embed_bf16.hip), one bf16 MFMA per product
         assert _rel(x16, x32) < 6e-3
-    os.environ["DG_EMBED_BF16"] = "general"
-    try:
+    from druggen_amd.options import options
+    with options.override(embed_bf16="general"):
         g16g = torch.autograd.grad(out16, ps, gr)
-    finally:
-        del os.environ["DG_EMBED_BF16"]
     for x16, x32 in zip(g16g, g32):
         assert _rel(x16, x32) < 1e-4       # general kernel: identical bf16-valued upstream gradient, fp32 arithmetic in both
 
@@ -345,11 +343,9 @@ def test_embed_sym_bwd_bf16_streaming_kernel(act, B, N, E):
     ee = f(torch.nn.functional.linear(f(torch.nn.functional.linear(ad, ws[0], ws[1])), ws[2], ws[3]))
     ref = torch.autograd.grad((ee + ee.permute(0, 2, 1, 3)) / 2, [ad] + ws, g.double())
     fast = dgf._embed_bwd_launch(a, w1, b1, w2, b2, g, act, torch.bfloat16, True, True)
-    os.environ["DG_EMBED_BF16"] = "general"
-    try:
+    from druggen_amd.options import options
+    with options.override(embed_bf16="general"):
         general = dgf._embed_bwd_launch(a, w1, b1, w2, b2, g, act, torch.bfloat16, True, True)
-    finally:
-        del os.environ["DG_EMBED_BF16"]
     for name, x, y, z in zip("da dw1 db1 dw2 db2".split(), fast, general, ref):
         assert _rel(x, z) < 6e-3, (name, _rel(x, z))
         assert _rel(y, z) < 1e-4, name

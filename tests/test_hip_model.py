@@ -335,9 +335,9 @@ def test_headline_depth_batch_32_against_fp64_oracle():
 
 
 @pytest.mark.parametrize("name", ["c1_b4", "c2_b2", "c1_tanh_b4"])
-def test_forced_fused_attention_half_backward_matches_golden_and_the_two_launch_path(name, monkeypatch):
+def test_forced_fused_attention_half_backward_matches_golden_and_the_two_launch_path(name):
     """`dg_attn_half_f32_bwd1` is the default for float32 at B >= 128 but every golden case is smaller and took
-    the two-launch path.  DG_ATTN_HALF_F32_BWD=force routes every batch size through it: D and G gradients plus the
+    the two-launch path.  options.attn_half_f32_bwd = "force" routes every batch size through it: D and G gradients plus the
     penalty's second order (inside d_loss) must match the reference goldens at 1e-3 and the `off` path at 3e-4 (the two paths
     round differently, and the backward's fp16-plane tensors of DESIGN 3.16 carry those differences on)."""
     case = cases.CASES[name]
@@ -345,7 +345,8 @@ def test_forced_fused_attention_half_backward_matches_golden_and_the_two_launch_
     inp = harness.torch_inputs(case, torch.float32, "cuda")
     res = {}
     for mode in ("off", "force"):
-        monkeypatch.setenv("DG_ATTN_HALF_F32_BWD", mode)
+        from druggen_amd.options import options
+        options.attn_half_f32_bwd = mode
         cfg, G, D = _build(case)
         res[mode] = harness.run_step(G, D, _d_loss, _g_loss, inp, case["lambda_gp"])
         harness.compare_step(case, fx, "ref64", res[mode], TOL_OUT, TOL_GRAD)
@@ -360,13 +361,13 @@ def test_forced_fused_attention_half_backward_matches_golden_and_the_two_launch_
         assert num <= (3e-4 ** 2) * den, (grp, num, den)
 
 
-def test_fp16_hidden_plane_mode_is_a_labelled_1e_2_method_at_batch_32(monkeypatch):
-    """DG_HIDDEN=f16 (the FORWARD's hidden tensor h as one fp16 plane + row scales too) is an opt-in mode OUTSIDE the 1e-3
+def test_fp16_hidden_plane_mode_is_a_labelled_1e_2_method_at_batch_32(hidden_mode):
+    """options.hidden = "f16" (DG_HIDDEN=f16 at import) (the FORWARD's hidden tensor h as one fp16 plane + row scales too) is an opt-in mode OUTSIDE the 1e-3
     bar: rounding h perturbs the forward and flips ReLU masks behind it.  At the headline model, B = 32, its losses stay
     within 1e-3 and every gradient tensor within 1e-2 of the fp64 oracle (measured worst 4.0e-3); the default (dh16: only the
     backward's hidden tensors) holds 1e-3 (the test above)."""
     from druggen_amd import functional as dgf
-    monkeypatch.setenv("DG_HIDDEN", "f16")
+    hidden_mode("f16")
     assert dgf.hidden_storage() == "f16"
     cfg = orc.NetConfig(act="relu", vertexes=45, edges=5, nodes=13, dropout=0.0, dim=128, depth=4, heads=8, mlp_ratio=3)
     global TOL_GRAD

@@ -222,6 +222,29 @@ def test_aux_oracle_to_dense_adj_semantics():
     assert oh.shape == (2, 3, 3, 4) and np.all(oh.sum(-1) == 1) and oh[1, 1, 2, 2] == 1
 
 
+# PyG's own published vectors for to_dense_adj: the "Examples" block of its docstring (torch_geometric/utils/to_dense_adj.py, the
+# 2.2 series the reference pins: environment.yml:171 `pyg=2.2.0`) -- data, not code.  They pin the oracle's restatement (and, in
+# tests/test_hip_aux.py, dg_densify) to the package's documented behaviour, including an edge (3 -> 0) that leaves its graph.
+PYG_EDGE_INDEX = [[0, 0, 1, 2, 3], [0, 1, 0, 3, 0]]
+PYG_BATCH = [0, 0, 1, 1]
+PYG_DENSE = [[[1, 1], [1, 0]], [[0, 1], [1, 0]]]                                   # to_dense_adj(edge_index, batch)
+PYG_DENSE_MAX4 = [[[1, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]],        # ... max_num_nodes=4
+                  [[0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]]]
+PYG_EDGE_ATTR = [1, 2, 3, 4, 5]
+PYG_DENSE_ATTR = [[[1, 2], [3, 0]], [[0, 4], [5, 0]]]                               # to_dense_adj(edge_index, batch, edge_attr)
+
+
+def test_aux_oracle_reproduces_pyg_docstring_examples():
+    from oracle import aux_oracle as aux
+    ei, batch = np.array(PYG_EDGE_INDEX), np.array(PYG_BATCH)
+    ones = np.ones(5, dtype=np.int64)
+    assert aux.to_dense_adj(ei, batch, ones, 2).tolist() == PYG_DENSE
+    assert aux.to_dense_adj(ei, batch, ones, 4).tolist() == PYG_DENSE_MAX4
+    assert aux.to_dense_adj(ei, batch, np.array(PYG_EDGE_ATTR), 2).tolist() == PYG_DENSE_ATTR
+    # single graph (batch of zeros), the first example's first graph
+    assert aux.to_dense_adj(np.array([[0, 0, 1], [0, 1, 0]]), np.zeros(2, dtype=np.int64), np.ones(3, dtype=np.int64), 2).tolist() == [PYG_DENSE[0]]
+
+
 # ---- SMILES -> graph (druggen_amd.smiles; reference src/data/dataset.py:119-160,280-316, utils.py:70-126) ----
 def test_smiles_parser_known_molecules():
     from druggen_amd import smiles as sm
