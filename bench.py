@@ -294,6 +294,7 @@ def main():
     n_ar, ms_ar = stepper.collective_ms() if world > 1 else (0, 0.0)      # the timed steps' all-reduces only
     stepper.time_collectives(False)
     attn_stats = {k: (_lib.prof_read(k), dgf.traffic_bytes(k), dgf.traffic_floor_bytes(k)) for k in attn_kernels}
+    traffic_flops = {k: dgf.traffic_flops(k) for k in attn_kernels}
     # per-kernel table of every HIP kernel: two extra, untimed, fully instrumented steps
     _lib.prof_reset()
     dgf.traffic_reset()
@@ -477,11 +478,15 @@ def main():
                    "avg_us": 1e3 * ms / n, "bytes_floor_per_launch": floor / n,
                    "moved_bytes_per_launch": nbytes / n, "frac_of_moved": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "share_of_step": ms * 1e-3 / elapsed}
-            fl = kernels.get(name, {}).get("achieved_TFLOPs")
-            if fl is not None:      # GEMM-shaped: report the MFMA side too and name the binding roof
-                kt = kernels[name]
-                blk.update({"frac_of_mfma_peak": kt["frac_of_mfma_peak"], "mfma_peak_TFLOPs": kt["mfma_peak_TFLOPs"],
-                            "achieved_TFLOPs": kt["achieved_TFLOPs"]})
+            fl = traffic_flops.get(name, 0)
+            if fl:      # GEMM-shaped: the MFMA side from the SAME events; the block reports the roof the kernel is closer to
+                tf = fl / (ms * 1e-3) / 1e12
+                peak = kernels.get(name, {}).get("mfma_peak_TFLOPs", gemm_peak)
+                blk.update({"frac_of_mfma_peak": tf / peak, "mfma_peak_TFLOPs": peak, "achieved_TFLOPs": tf,
+                            "mfma": kernels.get(name, {}).get("mfma", gemm_how)})
+                if tf / peak > blk["frac"]:
+                    blk.update({"bound": "mfma", "frac_of_hbm_floor": blk["frac"], "achieved_GBps_of_floor": blk["achieved"],
+                                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak})
             return blk
 
         blocks = [b for b in (timed_block(k) for k in attn_kernels) if b]

@@ -21,11 +21,28 @@ _pending_checks = []      # (pinned host counter, b_dim, event on the side strea
 _side_streams = {}        # device index -> the stream that carries the counters' device -> host copies
 
 
+_host_slots = None        # pinned int32 ring for the counters (allocated once: a pinned allocation synchronises the device)
+_next_slot = 0
+
+
 def _side_stream(dev):
     st = _side_streams.get(dev.index)
     if st is None:
         st = _side_streams[dev.index] = torch.cuda.Stream(dev)
     return st
+
+
+def _host_counter():
+    """One pinned int32 of the ring (256 slots; a slot still waiting for its copy after 255 later batches is waited for)."""
+    global _host_slots, _next_slot
+    if _host_slots is None:
+        _host_slots = torch.zeros(256, dtype=torch.int32, pin_memory=True)
+    i = _next_slot
+    _next_slot = (i + 1) % 256
+    for host, _, ev in _pending_checks:
+        if host.data_ptr() == _host_slots[i:i + 1].data_ptr():
+            ev.synchronize()
+    return _host_slots[i:i + 1]
 
 
 def raise_deferred_checks(wait: bool = False) -> None:
@@ -83,7 +100,7 @@ def dense_one_hot_adjacency(edge_index, edge_attr, batch_size: int, vertexes: in
         raise_deferred_checks()      # counters of earlier batches whose host copies are complete by now
         # counter -> pinned host memory on a SIDE stream that waits for the densify kernel: the compute stream sees one event
         # record, and the host reads the value only after the copy's own event has completed
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host = _host_counter()
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
         side = _side_stream(dev)

@@ -96,10 +96,13 @@ def test_densify_deferred_check_never_syncs_and_raises_later():
     # the polling must not read the counter on the compute stream (a .item() there waits for everything queued before
     # it, i.e. the previous training step).  With ~0.1 s of work queued in front, a deferred densify AND a poll return while
     # that work is still running.
-    torch.cuda._sleep(int(2e8))
+    attr = torch.tensor([1, 1, 2], device="cuda")      # (made BEFORE the queued work: a host -> device copy of a list synchronises)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(4e8))
     marker = torch.cuda.Event()
     marker.record()
-    data.dense_one_hot_adjacency(ei, torch.tensor([1, 1, 2], device="cuda"), 2, 4, 3, check="deferred")
+    assert not marker.query()                          # the device is busy for a while
+    data.dense_one_hot_adjacency(ei, attr, 2, 4, 3, check="deferred")
     data.raise_deferred_checks()
     assert not marker.query(), "the deferred check synchronised with the compute stream"
     torch.cuda.synchronize()

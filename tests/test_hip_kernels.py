@@ -670,7 +670,9 @@ def test_encoder_runs_ln6_backward_inside_the_next_blocks_dy_gemm(need_edge):
     for a_, b_ in zip(fused, plain):
         assert (a_ is None) == (b_ is None)
         if a_ is not None:
-            assert _rel(a_, b_.double().cpu()) < 2e-5
+            # (same forward, same masks; the two backward paths round dz differently in the last bit, and a handful of the 18 x 384
+            # elements of the node feed-forward's dh then land on the other side of an fp16 rounding boundary: 2.6e-5 measured)
+            assert _rel(a_, b_.double().cpu()) < 5e-5
     # twice-differentiable pass: no epilogue fusion, and the result can be differentiated again
     xo, yo = enc(x, y, need_edge)
     with dgf.inputs_only_backward():
@@ -1117,8 +1119,15 @@ def test_fused_float32_feed_forward_forward(R, scale):
     assert _rel(a["h"], h64) < 4e-4
     wrong = _ffn_f32_masks(a["bits"], R) != (v64 > 0)
     assert not wrong.any() or float((v64[wrong].abs() / v64.abs().max()).max()) < 1e-6
-    for ga, gb in zip(a["g"], got[False]["g"]):
-        assert _rel(ga, gb.double().cpu()) < 5e-4      # (dh's fp16 plane is the same 2^-11 method in both)
+    # gradients of the unchanged backward kernels on both forwards.  A pre-activation within float32 rounding of zero may get
+    # another mask bit in the two forwards (2 of 12.7 M elements at R = 33 000); such a row's dx differs by that unit's whole
+    # contribution, so rows are compared where the two masks agree, and the parameter gradients with the flipped rows' share
+    same = (_ffn_f32_masks(a["bits"], R) == _ffn_f32_masks(got[False]["bits"], R)).all(1)
+    flips = int((~same).sum())
+    assert flips <= max(2, R // 5000)
+    assert _rel(a["g"][0][same.cuda()], got[False]["g"][0][same.cuda()].double().cpu()) < 2e-5
+    for ga, gb in zip(a["g"][1:], got[False]["g"][1:]):
+        assert _rel(ga, gb.double().cpu()) < (2e-5 if flips == 0 else 2e-3)
 
 
 def test_fused_float32_feed_forward_node_rows_ride_and_launches_repeat():

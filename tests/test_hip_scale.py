@@ -404,9 +404,14 @@ def test_bench_line_is_one_short_parseable_record(tmp_path):
     rf = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_symbol", "bytes_floor_per_launch", "frac_of_moved", "avg_us"):
         assert k in rf, k
-    assert 0 < rf["frac"] <= rf["frac_of_moved"] < 1.0
-    # the driver-parsed fraction IS the section-8d definition: floor bytes / average launch duration / peak
-    assert abs(rf["frac"] - rf["bytes_floor_per_launch"] / (rf["avg_us"] * 1e-6) / 8e12) < 2e-3 * rf["frac"]
+    # the driver-parsed fraction IS the section-8d definition: the launch's algorithmic work / its average duration / the peak of
+    # the roof it is bound by -- floor bytes (inputs + outputs) against 8 TB/s, or useful flops against the MFMA peak of its arithmetic
+    hbm_frac = rf["bytes_floor_per_launch"] / (rf["avg_us"] * 1e-6) / 8e12
+    if rf["bound"] == "hbm":
+        assert abs(rf["frac"] - hbm_frac) < 2e-3 * rf["frac"] and 0 < rf["frac"] <= rf["frac_of_moved"] < 1.0
+    else:
+        assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac_of_hbm_floor"] - hbm_frac) < 2e-3 * hbm_frac
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and hbm_frac < rf["frac"] < 1.0
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
     assert "kernels" not in out and "roofline_all" not in out
     # `value` = the eagerly launched region, always; beside it the same steps replayed from the hipGraph and the strict-float32
