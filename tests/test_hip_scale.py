@@ -95,6 +95,80 @@ def test_full_size_gan_step_runs_and_is_reproducible(name, B, N, E, L):
     assert torch.equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize("name,dtype,B", [("configs[2] bf16", "bf16", 2048), ("configs[3] f32 low-memory", "f32", 2048)])
+def test_full_gan_step_at_batch_2048_is_finite_and_reproducible(name, dtype, B):
+    """The WHOLE iteration -- both losses, the gradient penalty's second order, FlatAdamW -- at the per-GPU sizes of BASELINE
+    configs[2] (bf16 activations) and configs[3] (float32: the low-memory step with the shared generator graph), through
+    GANStep.step as bench.py runs it: finite losses, and bit-identical parameters when repeated from the same state."""
+    from druggen_amd import functional as dgf
+    from druggen_amd.trainer import GANStep
+    a, x = _batch(B, 45, 5, seed=11)
+    da, dx = _batch(B, 45, 5, seed=12)
+    eps = (torch.rand(B, 1, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)),
+           torch.rand(B, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)))
+    runs = []
+    with dgf.activations(dtype):
+        for _ in range(2):
+            G, D = _nets(45, 5, 4, seed=5)
+            st = GANStep(G, D, lambda_gp=10.0)
+            if dtype == "f32":
+                assert st._low_memory(a)
+            d_loss, g_loss = st.step(da, dx, a, x, eps=eps)
+            assert torch.isfinite(d_loss) and torch.isfinite(g_loss)
+            runs.append((float(d_loss), float(g_loss), torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone()))
+            del st, G, D
+            torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][2], runs[1][2])
+
+
+def test_low_memory_step_equals_fast_step_at_batch_512():
+    """memory="low" (the three Discriminator terms differentiated one after the other, the generator's graph shared) against the
+    default step at B = 512, the headline model: same losses, D gradient bucket within 1e-3, parameters after the step within
+    5 % of their movement."""
+    from druggen_amd.trainer import GANStep
+    B = 512
+    a, x = _batch(B, 45, 5, seed=21)
+    da, dx = _batch(B, 45, 5, seed=22)
+    eps = (torch.rand(B, 1, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)),
+           torch.rand(B, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)))
+    outs = []
+    for mode in ("fast", "low"):
+        G, D = _nets(45, 5, 4, seed=6)
+        start = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone()
+        st = GANStep(G, D, g_lr=1e-3, d_lr=1e-3, lambda_gp=10.0, memory=mode)
+        losses = st.step(da, dx, a, x, eps=eps)
+        outs.append((torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone(),
+                     st.d_optimizer.flat_grad.clone(), [float(v) for v in losses]))
+        del st, G, D
+        torch.cuda.empty_cache()
+    assert float((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm()) < 1e-3
+    for u, v in zip(outs[0][2], outs[1][2]):
+        assert abs(u - v) <= 1e-3 * max(1.0, abs(u))
+    assert float((outs[0][0] - outs[1][0]).norm()) <= 0.05 * float((outs[0][0] - start).norm())
+
+
+def test_bench_n8_gloo_line_on_one_gpu(tmp_path):
+    """N = 8 readiness without the hardware: bench.py exactly as the driver's scaling run launches it -- torch.distributed.run,
+    eight ranks, `--gpus 8` -- with the `gloo` backend and every rank on cuda:0: ONE parseable line with n_gpus = 8, identical
+    replicas and the all-reduce record populated, so that the first real SCALE run cannot die on rendezvous or device-index
+    plumbing (under `nccl` rank r takes device r: bench.py `dev_index`)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extra", "--eager", "--batch", "8", "--vertexes", "9", "--depth", "1"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8"
+    assert out["replicas_identical"] is True
+    ar = out["allreduce"]
+    assert len(ar["per_rank_ms_per_step"]) == 8 and ar["collectives_per_step"] == 2 and ar["max_ms_per_step"] > 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
