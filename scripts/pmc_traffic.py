@@ -30,6 +30,7 @@ KEYS = [
     ("row_gemm_e_k384", r"row_gemm_k384_kernel|row_gemm_h3_k384_kernel|row_gemm_bf16_kernel(<3, 1>|ILi3ELi1E)"),
     ("row_gemm_e_n384", r"row_gemm_n384_kernel|row_gemm_h3_kernel(<1, 1, (false|true), 6>|ILi1ELi1ELb[01]ELi6E)|row_gemm_bf16_kernel(<1, 3>|ILi1ELi3E)"),
     ("row_gemm_e128", r"row_gemm_h3_kernel(<1, 1, (false|true), 4>|ILi1ELi1ELb[01]ELi4E)|row_gemm_bf16_kernel(<1, 1>|ILi1ELi1E)"),
+    ("ffn_f32", r"ffn_fused_f32_kernel"),
     ("ffn", r"ffn_fwd_bf16|ffn_bwd_dx_bf16"),
     ("ffn_wgrad", r"ffn_bwd_dw_bf16"),
     ("linear_wgrad_e_n384", r"wgrad_(stream_)?kernel(<(float, )?12, 4,|I(f)?Li12ELi4E)"),
