@@ -29,7 +29,7 @@ sites = collections.Counter()
 for fn in ("dg_row_gemm_pack", "dg_row_gemm_pack3"):
     orig = getattr(lib, fn)
     def wrapped(*args, _orig=orig, _fn=fn):
-        fr = [f for f in traceback.extract_stack() if "functional.py" in f.filename]
+        fr = [f for f in traceback.extract_stack() if os.sep + "functional" + os.sep in f.filename]
         who = " < ".join(f"{f.name}:{f.lineno}" for f in fr[-4:])
         ptr = args[0] if isinstance(args[0], int) else getattr(args[0], "value", args[0])
         sites[(_fn, names.get(ptr, hex(ptr) if isinstance(ptr, int) else str(ptr)), args[4] if _fn == "dg_row_gemm_pack" else args[5], who)] += 1

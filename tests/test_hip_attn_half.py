@@ -200,7 +200,7 @@ def test_fused_attn_block_node_against_float32_module(B, N, need_edge):
     lib.prof_enable(True, kernels=["attn_half_fwd", "attn_half_bwd"])
     lib.prof_reset()
     from druggen_amd.options import options
-    with options.override(attn_half="force"):       # N = 90 is not routed to the fused kernels by default (functional.py)
+    with options.override(attn_half="force"):       # N = 90 is not routed to the fused kernels by default (functional/attention.py)
         fused = run(x1, y, gouts)
     assert lib.prof_read("attn_half_fwd")[0] == 1 and lib.prof_read("attn_half_bwd")[0] == 1      # the fused kernels ran
     lib.prof_enable(False)
