@@ -15,6 +15,7 @@ B="python $R/bench.py"
 $B 2>$O/bench_c2.err | tail -1 > $O/bench_c2.json
 cp $R/gpurun_out/bench_detail_c2_f32.json $O/bench_detail_c2_f32.json 2>/dev/null
 $B --config c3 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c3.json
+cp $R/gpurun_out/bench_detail_c3_bf16.json $O/bench_detail_c3_bf16.json 2>/dev/null      # (before the traced runs overwrite it: events cost ~100 us per launch under the tracer)
 $B --config c4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4.json
 $B --config c5 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5.json
 $B --config c5 --batch 512 --steps 3 --warmup 1 --no-cpu-baseline 2>$O/bench_c5_b512.err | tail -1 > $O/bench_c5_b512.json
