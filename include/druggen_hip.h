@@ -20,9 +20,11 @@
  *    calls only enqueue work and return, there is no implicit synchronisation;
  *  - return value 0 = success, negative = library error (DG_E_*), positive =
  *    hipError_t; dg_last_error_string() gives a thread-local description;
- *  - no global mutable state except the opt-in profiler (dg_prof_*), so the
- *    library is re-entrant for nn.DataParallel's one-thread-per-GPU replicas
- *    (reference train.py:220-223).
+ *  - no environment variable is read and there is no global mutable state except
+ *    the opt-in profiler (dg_prof_*) and the edge-row threshold (dg_set_edge_rows);
+ *    reduce batches, riding launches and the traversal direction are per host
+ *    thread.  The library is re-entrant for nn.DataParallel's one-thread-per-GPU
+ *    replicas (reference train.py:220-223).
  *
  * Shapes: B molecules, N = vertexes, C = dim (C % 4 == 0, C >= 8, N <= 96 for
  * the attention kernels), R = number of rows of a [R, C] row matrix.
