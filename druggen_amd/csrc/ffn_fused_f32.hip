@@ -34,8 +34,9 @@
 #include "traversal.h"
 
 #ifndef FF_DBG
-#define FF_DBG 0      // ablation builds (scripts/build_variant.sh): 1 no MFMAs, 2 no global stores, 4 no weight-fragment reads, 8 no weight DMA,
-#endif                // 16 no fc1 epilogue arithmetic, 32 no h split
+#define FF_DBG 0      // ablation builds (scripts/build_variant.sh; results wrong, timing only): 1 no MFMAs, 2 no global stores, 4 no
+#endif                // weight-fragment reads, 8 no weight DMA, 16 no fc1 epilogue arithmetic, 32 no h split, 64 no x split, 128 no
+                      // LayerNorm statistics, 256 no workgroup barriers in the pass, 512 no counted waits
 #ifndef FF_SAFE_WAIT
 #define FF_SAFE_WAIT 0      // 1: every chunk wait is vmcnt(0) (debug builds: rules the counted waits out)
 #endif
@@ -143,9 +144,22 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
 // workgroup barrier that leaves VMEM in flight: __syncthreads()'s fence would wait vmcnt(0) for pending stores; the LDS side
 // (fragment reads, ds_or) is drained explicitly
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pass_barrier() {
+    if (FF_DBG & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else wg_barrier();
+}
+// ablation builds: a "split" that only converts
+__device__ __forceinline__ void fake_split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+    u32x4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2 * i], v[2 * i + 1]}, f16x2));
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = hi;
+}
 
 // s_waitcnt vmcnt(n) with n a constant after unrolling (the switch folds)
 __device__ __forceinline__ void vm_wait(int n) {
+    if (FF_DBG & 512) return;
 #define DG_VMW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
     switch (n) {
         DG_VMW(0) DG_VMW(1) DG_VMW(2) DG_VMW(3) DG_VMW(4) DG_VMW(5) DG_VMW(6) DG_VMW(7) DG_VMW(8) DG_VMW(9) DG_VMW(10) DG_VMW(11)
@@ -340,16 +354,21 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             xa[f >> 1][(f & 1) * 4 + 3] = v.w;
         }
         float mx = 0.f;
+        if (!(FF_DBG & 64)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(xa[ks][i]));
-        mx = xor_max<16>(mx);      // the four lanes (kq) of row n
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(xa[ks][i]));
+            mx = xor_max<16>(mx);      // the four lanes (kq) of row n
+        }
         const unsigned ex = scale_exponent(mx);
         const float inv_sx = inv_scale_of(ex);
         f16x8 xh[4], xl[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) split8(xa[ks], scale_of(ex), xh[ks], xl[ks]);
+        for (int ks = 0; ks < 4; ++ks) {
+            if (FF_DBG & 64) fake_split8(xa[ks], xh[ks], xl[ks]);
+            else split8(xa[ks], scale_of(ex), xh[ks], xl[ks]);
+        }
 
         // ---- fc1: h = relu(x W1^T + b1), 12 pairs of 16-channel blocks; lane (n, kq) ends with channels 32 j + 8 kq .. + 7.
         // The epilogue of pair j - 1 (scales, bias, ReLU, mask bits: ~25 vector instructions per element quarter) is issued in
@@ -370,6 +389,11 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         auto fc1_epilogue = [&](int j, int i) {      // element quarter i of pair j (accumulator set j & 1)
             const f32x4(&a)[4] = acc1[j & 1];
             if (i == 0) asm volatile("s_nop 7" ::: "memory");      // (MFMA results of the pair -> first vector read: far away already)
+            if (FF_DBG & 16) {
+                hv[j][i] = a[0][i] + a[1][i];
+                hv[j][4 + i] = a[2][i] + a[3][i];
+                return;
+            }
             const float ca = i == 0 ? tca.x : i == 1 ? tca.y : i == 2 ? tca.z : tca.w, cb = i == 0 ? tcb.x : i == 1 ? tcb.y : i == 2 ? tcb.z : tcb.w;
             const float ba = i == 0 ? tba.x : i == 1 ? tba.y : i == 2 ? tba.z : tba.w, bb = i == 0 ? tbb.x : i == 1 ? tbb.y : i == 2 ? tbb.z : tbb.w;
             const float va = fmaf(a[0][i] + a[1][i], inv_sx * ca, ba);
@@ -395,13 +419,17 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             vm_wait(FF_SAFE_WAIT ? 0 : younger(j));
-            wg_barrier();
+            pass_barrier();
             dma_chunk(j + 2, gb >= 1 ? gb - 1 : 2);      // buffer (gb + 2) % 3
             if (j < 8) store_results(j);                 // the previous pass's results, two stores per iteration
             const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
             // fragments one k-step ahead of their MFMAs (scheduling fences: hipcc otherwise requests all 16 at once, 64 VGPRs)
             f16x8 fr[2][4];
             auto read_frags = [&](int ks, f16x8 (&d)[4]) {
+                if (FF_DBG & 4) {
+                    d[0] = d[1] = d[2] = d[3] = xh[ks];
+                    return;
+                }
                 d[0] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 0) * 1024);            // block A hi, lo
                 d[1] = *reinterpret_cast<const f16x8*>(wb + (ks * 2 + 1) * 1024);
                 d[2] = *reinterpret_cast<const f16x8*>(wb + ((4 + ks) * 2 + 0) * 1024);      // block B hi, lo
@@ -439,16 +467,21 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
 
         // ---- h: ONE scale per row over all 384 channels, hi / lo planes; the hi plane leaves for the backward
         float mh = 0.f;
+        if (!(FF_DBG & 32)) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j)
+            for (int j = 0; j < 12; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mh = fmaxf(mh, hv[j][i]);
-        mh = xor_max<16>(mh);
+                for (int i = 0; i < 8; ++i) mh = fmaxf(mh, hv[j][i]);
+            mh = xor_max<16>(mh);
+        }
         const unsigned eh = scale_exponent(mh);
         const float inv_sh = inv_scale_of(eh);
         f16x8 hh[12], hl[12];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) split8(hv[j], scale_of(eh), hh[j], hl[j]);
+        for (int j = 0; j < 12; ++j) {
+            if (FF_DBG & 32) fake_split8(hv[j], hh[j], hl[j]);
+            else split8(hv[j], scale_of(eh), hh[j], hl[j]);
+        }
 
         // ---- fc2: z = x + h W2^T + b2, 8 blocks of 16 output channels; lane (n, kq) ends with channels 32 p + 8 kq .. + 7.
         // Three accumulation chains per block (w_lo.h_hi, w_hi.h_lo, w_hi.h_hi) in two alternating sets; the epilogue of block
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
             vm_wait(FF_SAFE_WAIT ? 0 : younger(12 + ob));
-            wg_barrier();
+            pass_barrier();
             dma_chunk(12 + ob + 2, gb >= 1 ? gb - 1 : 2);
             if (KEEP && ob == 0) {
                 // every wave's fc1 bits of the pass are in LDS (the barrier above): 2048 words leave, 16 bytes per thread, and
@@ -504,6 +537,10 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             f32x4(&q)[3] = acc2[ob & 1];
             f16x8 fr[3][2];
             auto read_frags = [&](int j, f16x8 (&d)[2]) {
+                if (FF_DBG & 4) {
+                    d[0] = d[1] = hh[j];
+                    return;
+                }
                 d[0] = *reinterpret_cast<const f16x8*>(wb + (j * 2 + 0) * 1024);
                 d[1] = *reinterpret_cast<const f16x8*>(wb + (j * 2 + 1) * 1024);
             };
@@ -536,21 +573,26 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         fc2_epilogue(7);
 
         // ---- LayerNorm statistics of the row (32 values per lane, four lanes per row); y leaves during the next pass
-        float s1 = 0.f;
+        float mu = 0.f;
+        if (FF_DBG & 128) {
+            rstd_p = 1.f;
+        } else {
+            float s1 = 0.f;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s1 += z[p][i];
-        const float mu = xor_sum<16>(s1) * (1.0f / 128.0f);
-        float s2 = 0.f;
+                for (int i = 0; i < 8; ++i) s1 += z[p][i];
+            mu = xor_sum<16>(s1) * (1.0f / 128.0f);
+            float s2 = 0.f;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float d = z[p][i] - mu;
-                s2 = fmaf(d, d, s2);
-            }
-        rstd_p = rsqrtf(xor_sum<16>(s2) * (1.0f / 128.0f) + eps);
+                for (int i = 0; i < 8; ++i) {
+                    const float d = z[p][i] - mu;
+                    s2 = fmaf(d, d, s2);
+                }
+            rstd_p = rsqrtf(xor_sum<16>(s2) * (1.0f / 128.0f) + eps);
+        }
         mu_p = mu;
         r0_p = r0;
         rows_p = rows;
