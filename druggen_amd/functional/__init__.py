@@ -5,6 +5,18 @@ backward expressed as a second Function whose own backward calls the
 second-order kernel.  That keeps the reference's gradient penalty
 (``src/model/loss.py:32-39``: ``autograd.grad(..., create_graph=True)`` followed
 by ``d_loss.backward()``, ``train.py:367``) working unchanged on these modules.
+
+One module per autograd node family, layered (each imports the ones before it; this package re-exports all of them, private
+helpers included, so ``druggen_amd.functional.<name>`` resolves whatever module ``<name>`` lives in):
+
+    _runtime    shared state: traffic accounting, hidden-tensor storage modes, workspaces, activation dtype, pass flags,
+                reduce-batch / riding-launch scopes, the packed-weight caches' epoch
+    layernorm   residual + LayerNorm and its two backward orders
+    dense       nn.Linear: weight gradients, packed weights, row GEMMs with fused prologue / epilogue, q / k / v per launch
+    heads       readouts, node embedding chain, Discriminator head
+    ffn         feed-forward half of an Encoder_Block (float32 fused forward / two launches, bf16 fused)
+    attention   attention core and the fused attention half (float32, bf16)
+    embed       edge embedding + symmetrisation, one-hot table form, output slots
 """
 from __future__ import annotations
 

@@ -320,7 +320,7 @@ def packed_weight3(w0, w1, w2, mode: int):
 
 def lin3_supported(x2, ws) -> bool:
     """Three Linear(128,128) per launch (dg_row_gemm_lin3 / _sum3, dg_linear_wgrad3): float32 rows on the fp16 hi + lo
-    kernels.  DG_QKV=separate keeps three launches (A/B measurements)."""
+    kernels."""
     return (x2.is_cuda and x2.dtype == torch.float32 and x2.shape[-1] == 128
             and all(tuple(w.shape) == (128, 128) and w.dtype == torch.float32 for w in ws))
 

@@ -7,6 +7,7 @@ from druggen_amd import functional as dgf
 B, N, E = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 5
 act = sys.argv[4] if len(sys.argv) > 4 else "relu"
 torch.manual_seed(0)
+from druggen_amd.options import options      # noqa: E402
 dev = "cuda"
 a = torch.softmax(2 * torch.randn(B, N, N, E, device=dev), -1)
 w1, b1 = torch.randn(64, E, device=dev) * 0.5, torch.randn(64, device=dev) * 0.1
@@ -14,7 +15,7 @@ w2, b2 = torch.randn(128, 64, device=dev) * 0.15, torch.randn(128, device=dev) *
 g = torch.randn(B, N, N, 128, device=dev).bfloat16()
 
 def run(mode, need_da=True):
-    os.environ["DG_EMBED_BF16"] = mode
+    options.set(embed_bf16=mode)
     return dgf._embed_bwd_launch(a, w1, b1, w2, b2, g, act, torch.bfloat16, need_da, True)
 
 fast = run("fast"); torch.cuda.synchronize()

@@ -20,9 +20,11 @@ for need_edge in (True, False):
         outs = (x2, y2) if need_edge else (x2,)
         g = torch.autograd.grad(outs, [x1, y] + params, gouts)
         return outs, g
-    import os
-    os.environ["DG_ATTN_HALF"] = "fused"; of, gf = run()
-    os.environ["DG_ATTN_HALF"] = "unfused"; ou, gu = run()
+    from druggen_amd.options import options
+    with options.override(attn_half="fused"):
+        of, gf = run()
+    with options.override(attn_half="unfused"):
+        ou, gu = run()
     # fp32 truth through the same module in float32 activations
     x1f, yf = x1.detach().float().requires_grad_(True), y.detach().float().requires_grad_(True)
     x2, y2 = dgf.attn_block(x1f, yf, attn, ln3, ln4, need_edge)

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""Node-level row GEMMs (R = B*N rows): time per launch for the shapes of the step.  DG_ROW_GEMM=mfma32 selects the
-fp32-MFMA kernels."""
+"""Node-level row GEMMs (R = B*N rows): time per launch for the shapes of the step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +24,7 @@ for K, N in ((128, 128), (128, 384), (384, 128)):
     pk = dgf.packed_weight(w, 0)
     t0 = timeit(lambda: dgf.row_gemm(a, pk, K, N, bias=b))
     t1 = timeit(lambda: dgf.row_gemm(a, pk, K, N, bias=b, residual=res, ln=(g, be, 1e-5), want_pre=True)) if N == 128 else 0.0
-    print(f"R={R} {K}->{N}: plain {t0:6.1f} us   +res+LN {t1:6.1f} us   mode={os.environ.get('DG_ROW_GEMM', 'h3')}")
+    print(f"R={R} {K}->{N}: plain {t0:6.1f} us   +res+LN {t1:6.1f} us")
 x = torch.randn(R, 128, device="cuda"); dy = torch.randn(R, 128, device="cuda")
 print(f"wgrad 128x128 R={R}: {timeit(lambda: dgf._wgrad(dy, x, True)):6.1f} us")
 pre = torch.randn(R, 128, device="cuda"); gm = torch.rand(128, device="cuda") + 0.5

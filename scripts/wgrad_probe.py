@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Edge-level weight-gradient launches at configs[1] size (R = 518 400 rows, fp32): time per launch for the shapes
-of the step.  DG_WGRAD=x6 / mfma32 / (default: fp16 hi+lo with running column scales) selects the arithmetic."""
+of the step (fp16 hi + lo planes with running column scales: the producer / consumer kernel of csrc/wgrad_stream.hip)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,4 +23,4 @@ for N, K in ((128, 128), (384, 128), (128, 384)):
     torch.cuda.synchronize()
     us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
     gb = (N + K) * dy.element_size() * R / 1e9
-    print(f"wgrad {N}x{K} R={R}: {us:8.1f} us  {gb / us * 1e6:6.0f} GB/s  mode={os.environ.get('DG_WGRAD', 'h3')}")
+    print(f"wgrad {N}x{K} R={R}: {us:8.1f} us  {gb / us * 1e6:6.0f} GB/s")
