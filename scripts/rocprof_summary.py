@@ -44,7 +44,7 @@ def main():
         disp = {}
         for name, full, dur in cur.execute(
                 "select name, (grid_x >= 256 * workgroup_x), duration from kernels where name like '%row_gemm%' "
-                "or name like '%wgrad_kernel%' or name like '%wgrad_stream%' or name like '%ffn_%bf16%' or name like '%attn_half%'"):
+                "or name like '%wgrad_kernel%' or name like '%wgrad_stream%' or name like '%ffn_%bf16%' or name like '%ffn_fused%' or name like '%attn_half%'"):
             disp.setdefault(name, {0: [], 1: []})[1 if full else 0].append(dur)
         table = []
         for name, d in disp.items():
