@@ -36,7 +36,8 @@
 #ifndef FF_DBG
 #define FF_DBG 0      // ablation builds (scripts/build_variant.sh; results wrong, timing only): 1 no MFMAs, 2 no global stores, 4 no
 #endif                // weight-fragment reads, 8 no weight DMA, 16 no fc1 epilogue arithmetic, 32 no h split, 64 no x split, 128 no
-                      // LayerNorm statistics, 256 no workgroup barriers in the pass, 512 no counted waits
+                      // LayerNorm statistics, 256 no workgroup barriers in the pass, 512 no counted waits, 1024 / 2048 / 4096 no stores of the pre-LayerNorm sum / the h plane / y
+                      // (build those with -DFF_SAFE_WAIT=1: the counted waits assume every store)
 #ifndef FF_SAFE_WAIT
 #define FF_SAFE_WAIT 0      // 1: every chunk wait is vmcnt(0) (debug builds: rules the counted waits out)
 #endif
@@ -320,13 +321,14 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0_p * 128, 0, rows_p * 512, 0x00020000);
         if (KEEP) {
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pre + r0_p * 128, 0, rows_p * 512, 0x00020000);
-            FF_STORE128(u32x4{__float_as_uint(z[p][4 * hf]), __float_as_uint(z[p][4 * hf + 1]), __float_as_uint(z[p][4 * hf + 2]),
-                              __float_as_uint(z[p][4 * hf + 3])}, rp, yoff, p * 128 + hf * 16, 0);
+            if (!(FF_DBG & 1024))
+                FF_STORE128(u32x4{__float_as_uint(z[p][4 * hf]), __float_as_uint(z[p][4 * hf + 1]), __float_as_uint(z[p][4 * hf + 2]),
+                                  __float_as_uint(z[p][4 * hf + 3])}, rp, yoff, p * 128 + hf * 16, 0);
         }
         const float4 g = ld4(tab + 1024 + 32 * p + 8 * kq + 4 * hf), e = ld4(tab + 1152 + 32 * p + 8 * kq + 4 * hf);
         const u32x4 o = {__float_as_uint(fmaf((z[p][4 * hf] - mu_p) * rstd_p, g.x, e.x)), __float_as_uint(fmaf((z[p][4 * hf + 1] - mu_p) * rstd_p, g.y, e.y)),
                          __float_as_uint(fmaf((z[p][4 * hf + 2] - mu_p) * rstd_p, g.z, e.z)), __float_as_uint(fmaf((z[p][4 * hf + 3] - mu_p) * rstd_p, g.w, e.w))};
-        FF_STORE128(o, ry, yoff, p * 128 + hf * 16, 0);
+        if (!(FF_DBG & 4096)) FF_STORE128(o, ry, yoff, p * 128 + hf * 16, 0);
         if (i == 0) {
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(gmean + r0_p, 0, rows_p * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(grstd + r0_p, 0, rows_p * 4, 0x00020000);
@@ -522,7 +524,8 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             if (KEEP) {      // the hi plane of h for the backward: twelve 16-byte stores, one or two per iteration (+ the row scale)
                 const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hplane + r0 * 384, 0, rows * 768, 0x00020000);
                 const unsigned voff = static_cast<unsigned>(n) * 768u + static_cast<unsigned>(kq) * 16u;
-                if (ob < 4) {
+                if (FF_DBG & 2048) {
+                } else if (ob < 4) {
                     FF_STORE128(__builtin_bit_cast(u32x4, hh[2 * ob]), rh, voff, (2 * ob) * 64, 0);
                     FF_STORE128(__builtin_bit_cast(u32x4, hh[2 * ob + 1]), rh, voff, (2 * ob + 1) * 64, 0);
                 } else {
