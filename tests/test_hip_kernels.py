@@ -1130,6 +1130,53 @@ def test_fused_float32_feed_forward_forward(R, scale):
         assert _rel(ga, gb.double().cpu()) < (2e-5 if flips == 0 else 2e-3)
 
 
+def test_fused_float32_feed_forward_degenerate_rows():
+    """Rows and channels on which the kernel's power-of-two scales have nothing to hold on to: rows of x that are all zero, rows
+    whose hidden units are ALL switched off (h = 0: the row scale of the stored plane clamps), a fc1 unit and a fc2 output with
+    all-zero weights, one row 1e15 times larger than its neighbours -- y, the pre-LayerNorm sum, the stored plane and the
+    gradients through the unchanged backward stay finite and equal to float64 / the two-launch path."""
+    from druggen_amd import functional as dgf
+    C, H, R = 128, 384, 333
+    c = _ffn_f32_case(R, 7)
+    with torch.no_grad():
+        c["x"][::3] = 0.0                      # zero rows (their h = relu(b1): not zero)
+        c["x"][1] *= 1e15                      # one huge row between ordinary ones (its variance, 1e30, still a float32)
+        c["w1"][5] = 0.0                       # a hidden unit without weights
+        c["w2"][9] = 0.0                       # an output channel without weights
+        c["b1"][:] = c["b1"] - 0.2
+    off = _ffn_f32_case(R, 8)
+    with torch.no_grad():
+        off["b1"][:] = -1e4                    # every hidden unit off in every row: h = 0, y = LN(x + b2)
+    for case in (c, off):
+        d = lambda t: t.detach().double().cpu()
+        h64 = torch.relu(d(case["x"]) @ d(case["w1"]).t() + d(case["b1"]))
+        pre64 = d(case["x"]) + h64 @ d(case["w2"]).t() + d(case["b2"])
+        y64 = torch.nn.functional.layer_norm(pre64, (C,), d(case["gamma"]), d(case["beta"]), 1e-5)
+        ins = [case[k] for k in ("x", "w1", "b1", "w2", "b2", "gamma", "beta")]
+        dy = _gen((R, C), 98).float().cuda()
+        got = {}
+        try:
+            for fused in (True, False):
+                dgf.set_fused_ffn_f32(fused)
+                y, pre, mean, rstd = dgf._FFNLN.apply(*ins, 1e-5)
+                sv = y.grad_fn.saved_tensors
+                got[fused] = dict(y=y.detach(), pre=pre.detach(), h=dgf.hidden_to_float(sv[7], R, H), g=torch.autograd.grad(y, ins, dy))
+        finally:
+            dgf.set_fused_ffn_f32(True)
+        a, b = got[True], got[False]
+        assert all(bool(torch.isfinite(t).all()) for t in (a["y"], a["pre"], a["h"]) + tuple(a["g"]))
+        rows = torch.ones(R, dtype=torch.bool)
+        rows[1] = False                        # (the 1e15 row dominates a whole-tensor norm: compared on its own)
+        assert _rel(a["y"][rows.cuda()], y64[rows]) < TOL and _rel(a["y"][1], y64[1]) < TOL
+        assert _rel(a["pre"][rows.cuda()], pre64[rows]) < TOL and _rel(a["pre"][1], pre64[1]) < TOL
+        if float(h64.abs().max()) == 0.0:
+            assert float(a["h"].abs().max()) == 0.0
+        else:
+            assert _rel(a["h"][rows.cuda()], h64[rows]) < 4e-4 and _rel(a["h"][1], h64[1]) < 4e-4
+        for ga, gb in zip(a["g"], b["g"]):
+            assert _rel(ga, gb.double().cpu()) < 2e-3
+
+
 def test_fused_float32_feed_forward_node_rows_ride_and_launches_repeat():
     """The two-problem form (node rows ride in the launch over the edge rows, own weights) equals the two single launches bit
     for bit, without backward outputs too, and repeated launches are bit-identical (the kernel's counted vmcnt waits never let
