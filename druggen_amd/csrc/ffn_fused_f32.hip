@@ -62,6 +62,14 @@ __device__ __forceinline__ void ff_store32(unsigned data, __amdgpu_buffer_rsrc_t
     if (!(FF_DBG & 2)) __builtin_amdgcn_raw_buffer_store_b32(data, rsrc, voff, imm, FF_AUX);
 }
 
+#ifndef FF_PROF
+#define FF_PROF 0      // developer builds: s_memtime around the sections of every iteration (1), around the y / pre-LN stores only (2), around
+#endif                 // the h-plane stores only (3); totals of workgroup 0 per wave into mean[300000 ..] (scripts/ffn_f32_prof.py)
+__device__ __forceinline__ unsigned long long ff_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 constexpr int kTile = 128;                       // rows per workgroup pass (16 per wave)
 constexpr int kWaves = 8;
 constexpr int kW1Chunk = 16 * 1024;              // one pair of 16-channel fc1 blocks: [block 2][k-step 4][plane 2] fragments of 1 KB
@@ -316,19 +324,23 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
     // (lane (n, kq) holds channels 32 p + 8 kq + 4 half .. + 3 of row n.  The W2 channel order 16 half + 4 kq -- 64 contiguous,
     // aligned bytes per row and store instruction instead of every second 16-byte piece of the line -- was measured SLOWER:
     // 460 vs 428 us at R = 518 400.)
+    unsigned long long st_ticks = 0;
     auto store_results = [&](int i) {      // 16-byte column group i (p = i >> 1, half = i & 1) of the previous pass's rows
         const int p = i >> 1, hf = i & 1;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + r0_p * 128, 0, rows_p * 512, 0x00020000);
+        const float4 g = ld4(tab + 1024 + 32 * p + 8 * kq + 4 * hf), e = ld4(tab + 1152 + 32 * p + 8 * kq + 4 * hf);
+        const u32x4 o = {__float_as_uint(fmaf((z[p][4 * hf] - mu_p) * rstd_p, g.x, e.x)), __float_as_uint(fmaf((z[p][4 * hf + 1] - mu_p) * rstd_p, g.y, e.y)),
+                         __float_as_uint(fmaf((z[p][4 * hf + 2] - mu_p) * rstd_p, g.z, e.z)), __float_as_uint(fmaf((z[p][4 * hf + 3] - mu_p) * rstd_p, g.w, e.w))};
+        unsigned long long ta = 0;
+        if (FF_PROF == 2) ta = ff_now();
         if (KEEP) {
             const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pre + r0_p * 128, 0, rows_p * 512, 0x00020000);
             if (!(FF_DBG & 1024))
                 FF_STORE128(u32x4{__float_as_uint(z[p][4 * hf]), __float_as_uint(z[p][4 * hf + 1]), __float_as_uint(z[p][4 * hf + 2]),
                                   __float_as_uint(z[p][4 * hf + 3])}, rp, yoff, p * 128 + hf * 16, 0);
         }
-        const float4 g = ld4(tab + 1024 + 32 * p + 8 * kq + 4 * hf), e = ld4(tab + 1152 + 32 * p + 8 * kq + 4 * hf);
-        const u32x4 o = {__float_as_uint(fmaf((z[p][4 * hf] - mu_p) * rstd_p, g.x, e.x)), __float_as_uint(fmaf((z[p][4 * hf + 1] - mu_p) * rstd_p, g.y, e.y)),
-                         __float_as_uint(fmaf((z[p][4 * hf + 2] - mu_p) * rstd_p, g.z, e.z)), __float_as_uint(fmaf((z[p][4 * hf + 3] - mu_p) * rstd_p, g.w, e.w))};
         if (!(FF_DBG & 4096)) FF_STORE128(o, ry, yoff, p * 128 + hf * 16, 0);
+        if (FF_PROF == 2) st_ticks += ff_now() - ta;
         if (i == 0) {
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(gmean + r0_p, 0, rows_p * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(grstd + r0_p, 0, rows_p * 4, 0x00020000);
@@ -336,6 +348,7 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             FF_STORE32(__float_as_uint(rstd_p), rr, soff, 0, 0);
         }
     };
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0, pt2 = 0;      // fc1: wait, issue, compute; fc2: the same
 #pragma nounroll
     for (int t = 0; t < T; ++t) {
         const int64_t tile = tile_of(t);
@@ -420,10 +433,13 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         };
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
+            if (FF_PROF) pt0 = ff_now();
             vm_wait(FF_SAFE_WAIT ? 0 : younger(j));
             pass_barrier();
+            if (FF_PROF) pt1 = ff_now();
             dma_chunk(j + 2, gb >= 1 ? gb - 1 : 2);      // buffer (gb + 2) % 3
             if (j < 8) store_results(j);                 // the previous pass's results, two stores per iteration
+            if (FF_PROF) pt2 = ff_now();
             const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
             // fragments one k-step ahead of their MFMAs (scheduling fences: hipcc otherwise requests all 16 at once, 64 VGPRs)
             f16x8 fr[2][4];
@@ -459,6 +475,12 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                 mfma16(ca, wha, xh[ks]);
                 mfma16(cb, whb, xh[ks]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (FF_PROF) {
+                const unsigned long long pt3 = ff_now();
+                prof[0] += pt1 - pt0;
+                prof[1] += pt2 - pt1;
+                prof[2] += pt3 - pt2;
             }
             gb = gb == 2 ? 0 : gb + 1;
             fc1_tables(j);      // (read behind the last quarter of pair j - 1, used from the next iteration on)
@@ -502,8 +524,10 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
         };
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
+            if (FF_PROF) pt0 = ff_now();
             vm_wait(FF_SAFE_WAIT ? 0 : younger(12 + ob));
             pass_barrier();
+            if (FF_PROF) pt1 = ff_now();
             dma_chunk(12 + ob + 2, gb >= 1 ? gb - 1 : 2);
             if (KEEP && ob == 0) {
                 // every wave's fc1 bits of the pass are in LDS (the barrier above): 2048 words leave, 16 bytes per thread, and
@@ -524,6 +548,8 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
             if (KEEP) {      // the hi plane of h for the backward: twelve 16-byte stores, one or two per iteration (+ the row scale)
                 const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hplane + r0 * 384, 0, rows * 768, 0x00020000);
                 const unsigned voff = static_cast<unsigned>(n) * 768u + static_cast<unsigned>(kq) * 16u;
+                unsigned long long ta = 0;
+                if (FF_PROF == 3) ta = ff_now();
                 if (FF_DBG & 2048) {
                 } else if (ob < 4) {
                     FF_STORE128(__builtin_bit_cast(u32x4, hh[2 * ob]), rh, voff, (2 * ob) * 64, 0);
@@ -531,11 +557,13 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                 } else {
                     FF_STORE128(__builtin_bit_cast(u32x4, hh[4 + ob]), rh, voff, (4 + ob) * 64, 0);
                 }
+                if (FF_PROF == 3) st_ticks += ff_now() - ta;
                 if (ob == 0) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hscale + r0, 0, rows * 4, 0x00020000);
                     FF_STORE32(__float_as_uint(inv_sh), rs, soff, 0, 0);
                 }
             }
+            if (FF_PROF) pt2 = ff_now();
             const char* wb = smem + kOffW + gb * kW2Chunk + lane * 16;
             f32x4(&q)[3] = acc2[ob & 1];
             f16x8 fr[3][2];
@@ -566,6 +594,12 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
                     mfma16(q[2], wh, hh[j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (FF_PROF) {
+                const unsigned long long pt3 = ff_now();
+                prof[3] += pt1 - pt0;
+                prof[4] += pt2 - pt1;
+                prof[5] += pt3 - pt2;
             }
             gb = gb == 2 ? 0 : gb + 1;
             const int p = ob >> 1, blk = ob & 1;
@@ -605,6 +639,8 @@ __global__ __launch_bounds__(64 * kWaves) void ffn_fused_f32_kernel(const FProb 
     for (int i = 0; i < 8; ++i) store_results(i);
     // the DMAs issued for a pass that does not come must land before the LDS is handed to the next workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FF_PROF && bidx == 0 && !second && lane == 0 && R > 300064)
+        for (int i = 0; i < 6; ++i) gmean[300000 + w * 6 + i] = static_cast<float>(FF_PROF > 1 && i == 1 ? st_ticks : prof[i]);
 }
 
 // ---- pack: one wave per output channel.  W1 [384,128] (blocks 0..383), W2 [128,384] (blocks 384..511): the row is scaled by
